@@ -1,0 +1,147 @@
+"""Version-independent known-answer tests for the UNPINNED parts of the oracle (SURVEY 8c i-viii)."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import cogvideox as ocv
+from oracle import scheduler as osch
+from oracle import scorer
+
+
+def tiny_cfg(**kw):
+    base = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=32, text_embed_dim=48,
+                sample_width=8, sample_height=8, sample_frames=9, max_text_seq_length=6)
+    base.update(kw)
+    return ocv.CogVideoXConfig(**base)
+
+
+def tiny_inputs(cfg, B=1, F=3, H=8, W=8, seed=0, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, F, cfg.in_channels, H, W, generator=g).to(dtype)
+    txt = torch.randn(B, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g).to(dtype)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    return x, txt, t
+
+
+def test_forward_shape_and_lora_b0_identity():
+    cfg = tiny_cfg()
+    sd = ocv.init_state_dict(cfg, dtype=torch.float64)
+    lora = ocv.init_lora(cfg, r=4, dtype=torch.float64)  # B = 0
+    x, txt, t = tiny_inputs(cfg)
+    y0 = ocv.forward(sd, cfg, x, txt, t)
+    y1 = ocv.forward(sd, cfg, x, txt, t, lora=lora)
+    assert y0.shape == x.shape
+    assert torch.equal(y0, y1)
+
+
+def test_ln2_and_grads_only_in_lora_b():
+    cfg = tiny_cfg()
+    sd = ocv.init_state_dict(cfg, dtype=torch.float64)
+    lora = {k: v.requires_grad_(True) for k, v in ocv.init_lora(cfg, r=4, dtype=torch.float64).items()}
+    abar = osch.alphas_cumprod()
+    g = torch.Generator().manual_seed(3)
+    xw = torch.randn(1, 16, 3, 8, 8, generator=g).double()
+    xl = torch.randn(1, 16, 3, 8, 8, generator=g).double()
+    txt = torch.randn(1, 6, cfg.text_embed_dim, generator=g).double()
+    t = torch.tensor([417])
+    eps = torch.randn(1, 3, 16, 8, 8, generator=g).double()
+    out = ocv.dpo_pair_step(sd, cfg, lora, abar, xw, xl, txt, t, eps, beta=1.0)
+    assert abs(float(out["loss"].detach()) - math.log(2.0)) < 1e-12
+    out["loss"].backward()
+    for k, v in lora.items():
+        if "lora_A" in k:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0
+        else:
+            assert float(v.grad.abs().max()) > 0.0
+
+
+def test_adaln_zero_modulation_gives_identity_block():
+    cfg = tiny_cfg()
+    sd = ocv.init_state_dict(cfg, dtype=torch.float64)
+    for n in ("norm1", "norm2"):
+        sd[f"transformer_blocks.0.{n}.linear.weight"].zero_()
+        sd[f"transformer_blocks.0.{n}.linear.bias"].zero_()
+    g = torch.Generator().manual_seed(1)
+    hid = torch.randn(1, 48, cfg.inner_dim, generator=g).double()
+    enc = torch.randn(1, 6, cfg.inner_dim, generator=g).double()
+    temb = torch.randn(1, cfg.time_embed_dim, generator=g).double()
+    h2, e2 = ocv.block_forward(sd, cfg, 0, hid, enc, temb)
+    assert torch.equal(h2, hid) and torch.equal(e2, enc)
+
+
+def test_rope_properties():
+    cos, sin = ocv.rope_3d_tables(3, 4, 5, 64)
+    assert cos.shape == (60, 64)
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(1, 1, 60, 64, generator=g)
+    r = ocv.apply_rotary_emb(q, cos, sin)
+    # per-pair norms preserved
+    n0 = q.reshape(60, 32, 2).norm(dim=-1)
+    n1 = r.reshape(60, 32, 2).norm(dim=-1)
+    assert torch.allclose(n0, n1, atol=1e-5)
+    # <rope(q,p), rope(k,p')> depends only on p - p' per axis: same vectors at two position pairs with equal offsets
+    qv = torch.randn(64, generator=g)
+    kv = torch.randn(64, generator=g)
+
+    def at(vec, f, h, w):
+        i = (f * 4 + h) * 5 + w
+        return ocv.apply_rotary_emb(vec.view(1, 1, 1, 64), cos[i:i + 1], sin[i:i + 1]).flatten()
+
+    d1 = at(qv, 0, 1, 1) @ at(kv, 1, 2, 3)
+    d2 = at(qv, 1, 2, 2) @ at(kv, 2, 3, 4)
+    assert abs(float(d1 - d2)) < 1e-4
+
+
+def test_qk_norm_zero_mean_unit_var():
+    cfg = tiny_cfg()
+    sd = ocv.init_state_dict(cfg, dtype=torch.float64)
+    for n in ("norm_q", "norm_k"):
+        sd[f"transformer_blocks.0.attn1.{n}.weight"].fill_(1.0)
+        sd[f"transformer_blocks.0.attn1.{n}.bias"].zero_()
+    g = torch.Generator().manual_seed(5)
+    hid = torch.randn(1, 48, cfg.inner_dim, generator=g).double()
+    enc = torch.randn(1, 6, cfg.inner_dim, generator=g).double()
+    temb = torch.randn(1, cfg.time_embed_dim, generator=g).double()
+    cap = {}
+    ocv.block_forward(sd, cfg, 0, hid, enc, temb, capture=cap)
+    for t in (cap["q"], cap["k"]):
+        assert float(t.mean(-1).abs().max()) < 1e-9
+        assert float((t.var(-1, unbiased=False) - 1).abs().max()) < 1e-4
+
+
+def test_scheduler_identities():
+    abar = osch.alphas_cumprod()
+    assert abar.shape == (1000,) and float(abar[-1]) == 0.0
+    assert abs(float(abar[0]) - (1 - 0.00085)) < 1e-9          # alpha_bar_0 preserved by the zero-SNR rescale (s=1)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 4, 5, 6, generator=g).double()
+    eps = torch.randn(2, 3, 4, 5, 6, generator=g).double()
+    t = torch.tensor([10, 999])
+    xt = osch.add_noise(abar, x, eps, t)
+    v = osch.get_velocity(abar, x, eps, t)
+    a = abar[t].view(2, 1, 1, 1, 1)
+    assert torch.allclose(a.sqrt() * xt - (1 - a).sqrt() * v, x, atol=1e-12)
+    assert torch.allclose(xt[1], eps[1])
+
+
+def test_eight_point_and_sampson():
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(64, 3)) + np.array([0, 0, 5.0])
+    K = np.array([[400.0, 0, 160], [0, 400.0, 120], [0, 0, 1]])
+    a = 0.1
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    t = np.array([0.3, 0.05, 0.1])
+    p1 = (K @ X.T).T
+    p1 = p1[:, :2] / p1[:, 2:]
+    p2 = (K @ (R @ X.T + t[:, None])).T
+    p2 = p2[:, :2] / p2[:, 2:]
+    Fm = scorer.find_fundamental(p1, p2)
+    d = scorer.sampson_distance_sq(p1, p2, Fm)
+    assert d.max() < 1e-12
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ft = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+    Ft = Ft / Ft[2, 2]
+    assert np.allclose(Fm, Ft, rtol=1e-5, atol=1e-8)
+    assert abs(np.linalg.det(Fm)) < 1e-12
+    assert scorer.epipolar_pair_error(p1, p2) < 2e-4   # sqrt(0 + 1e-8)
