@@ -1,0 +1,234 @@
+"""HIP kernels (through the C-ABI) vs the CPU oracle on the same seeded inputs.  -m gpu only."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cogvideox as ocv
+from oracle import dpo as odpo
+from oracle import scheduler as osch
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from videogpa_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------------------ DPO loss
+def test_dpo_loss_golden(ops, golden_dir):
+    """fp32 inputs from the reference goldens (train/loss.py outputs).  Tolerance: 2e-6 rel on the scalars
+    (fp64 tree reduction here vs torch fp32 reduction there), grads 1e-5 rel of max."""
+    cases = torch.load(os.path.join(golden_dir, "dpo_loss.pt"), weights_only=False)
+    for c in cases:
+        ins = [dev(x).requires_grad_(i < 2) for i, x in enumerate(c["inputs"])]
+        loss, margin, wr, lr, acc, errs = ops.dpo_loss(*ins, beta=c["beta"], label_smoothing=c["label_smoothing"], loss_type=c["loss_type"])
+        # logits are beta * (difference of O(1) fp32 means): absolute error scales with beta * eps_fp32
+        tol = 5e-6 * max(1.0, c["beta"])
+        assert abs(loss.item() - c["loss"].item()) <= tol * max(1.0, abs(c["loss"].item())), (c["beta"], c["loss_type"], loss.item(), c["loss"].item())
+        assert abs(margin.item() - c["reward_margin"].item()) < 2e-6
+        assert abs(wr.item() - c["winner_reward"].item()) < 5e-6 * abs(c["winner_reward"].item())
+        assert abs(lr.item() - c["loser_reward"].item()) < 5e-6 * abs(c["loser_reward"].item())
+        assert acc.item() == c["accuracy"].item()
+        if c["grad_v_win"] is not None:
+            loss.backward()
+            for g, ref in ((ins[0].grad, c["grad_v_win"]), (ins[1].grad, c["grad_v_lose"])):
+                ref = ref.cuda()
+                scale = ref.abs().max().item() + 1e-30
+                assert (g - ref).abs().max().item() <= max(1e-5, 50 * tol) * scale
+
+
+def test_dpo_loss_ln2_and_bf16(ops):
+    g = torch.Generator().manual_seed(5)
+    shape = (2, 13, 16, 12, 18)
+    v = [torch.randn(shape, generator=g).to(torch.bfloat16) for _ in range(4)]
+    out = ops.dpo_loss(dev(v[0]), dev(v[1]), dev(v[0]).clone(), dev(v[1]).clone(), dev(v[2]), dev(v[3]), beta=500.0)
+    assert abs(out[0].item() - math.log(2.0)) < 1e-6
+    # bf16 inputs vs oracle on the same (bf16-rounded) values in fp64
+    t = [torch.randn(shape, generator=g).to(torch.bfloat16) for _ in range(6)]
+    ins = [dev(x).requires_grad_(i < 2) for i, x in enumerate(t)]
+    out = ops.dpo_loss(*ins, beta=3.0)
+    ref_in = [x.double().requires_grad_(i < 2) for i, x in enumerate(t)]
+    ref = odpo.dpo_loss(*ref_in, beta=3.0)
+    assert abs(out[0].item() - ref["loss"].item()) < 1e-5
+    out[0].backward()
+    ref["loss"].backward()
+    for a, b in ((ins[0].grad, ref_in[0].grad), (ins[1].grad, ref_in[1].grad)):
+        assert a.dtype == torch.bfloat16
+        sc = b.abs().max().item()
+        assert (a.double().cpu() - b).abs().max().item() < 1e-2 * sc  # bf16 output rounding (2^-8 rel)
+
+
+# ------------------------------------------------------------------------------------------ noise / velocity
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_noise_velocity_bit_exact(ops, dtype):
+    g = torch.Generator().manual_seed(11)
+    B, shape = 3, (5, 16, 6, 10)
+    x = (torch.randn(B, 2, *shape, generator=g) * 0.7).to(dtype)
+    eps = torch.randn(B, *shape, generator=g).to(dtype)
+    t = torch.tensor([0, 417, 999])
+    abar = osch.alphas_cumprod()
+    a = abar.to(dtype)[t]           # diffusers casts the table to the sample dtype first
+    sa, sb = a ** 0.5, (1 - a) ** 0.5
+    sa_tab = torch.zeros(1000, dtype=torch.float32)
+    sb_tab = torch.zeros(1000, dtype=torch.float32)
+    ad = abar.to(dtype)
+    sa_tab[:] = (ad ** 0.5).float()
+    sb_tab[:] = ((1 - ad) ** 0.5).float()
+    xt, v = ops.noise_velocity_paired(dev(x), dev(eps), dev(t), dev(sa_tab), dev(sb_tab))
+    bc = (B, 1, 1, 1, 1)
+    for p in range(2):
+        ref_xt = sa.view(bc) * x[:, p] + sb.view(bc) * eps
+        ref_v = sa.view(bc) * eps - sb.view(bc) * x[:, p]
+        assert torch.equal(xt[:, p].cpu(), ref_xt)
+        assert torch.equal(v[:, p].cpu(), ref_v)
+
+
+# ------------------------------------------------------------------------------------------ AdaLN pieces
+@pytest.mark.parametrize("D,text_len", [(128, 6), (3072, 5), (512, 0)])
+def test_ln_modulate_fwd_bwd(ops, D, text_len):
+    g = torch.Generator().manual_seed(D)
+    B, S = 2, 37
+    x = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    mod = 0.3 * torch.randn(B, 4, D, generator=g)
+    mod[:, 1] += 1
+    mod[:, 3] += 1
+    dy = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    xd = dev(x).requires_grad_(True)
+    y = ops.ln_modulate(xd, dev(w), dev(b), dev(mod), text_len, 1e-5)
+    y.backward(dev(dy))
+    xr = x.double().requires_grad_(True)
+    n = F.layer_norm(xr, (D,), w.double(), b.double(), 1e-5)
+    sc = torch.cat([mod[:, 3:4].expand(B, text_len, D), mod[:, 1:2].expand(B, S - text_len, D)], 1).double()
+    sh = torch.cat([mod[:, 2:3].expand(B, text_len, D), mod[:, 0:1].expand(B, S - text_len, D)], 1).double()
+    yr = n * sc + sh
+    yr.backward(dy.double())
+    assert (y.double().cpu() - yr).abs().max().item() < 0.03          # bf16 output rounding of O(4) values
+    assert (y.double().cpu() - yr.detach().to(torch.bfloat16).double()).abs().max().item() <= 0.032
+    gerr = (xd.grad.double().cpu() - xr.grad).abs().max().item()
+    assert gerr < 0.02 * xr.grad.abs().max().item() + 1e-3
+    # plain LN (no modulation)
+    y2 = ops.ln_modulate(dev(x), dev(w), dev(b), None, 0, 1e-5)
+    assert (y2.double().cpu() - n.detach()).abs().max().item() < 0.03
+
+
+def test_gate_residual_and_gelu(ops):
+    g = torch.Generator().manual_seed(3)
+    B, S, D, Lt = 2, 19, 256, 4
+    x = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    y = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    gates = torch.randn(B, 2, D, generator=g).to(torch.bfloat16).float()
+    xd, yd = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+    out = ops.gate_residual(xd, yd, dev(gates), Lt)
+    gfull = torch.cat([gates[:, 1:2].expand(B, Lt, D), gates[:, 0:1].expand(B, S - Lt, D)], 1).to(torch.bfloat16)
+    ref = x + gfull * y                      # torch bf16 semantics: round(g*y) then round(x + .)
+    assert torch.equal(out.cpu(), ref)
+    dout = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    out.backward(dev(dout))
+    assert torch.equal(xd.grad.cpu(), dout)
+    assert torch.equal(yd.grad.cpu(), gfull * dout)
+
+    u = (3 * torch.randn(4, 33, 64, generator=g)).to(torch.bfloat16)
+    ud = dev(u).requires_grad_(True)
+    o = ops.gelu_tanh(ud)
+    ur = u.double().requires_grad_(True)
+    orf = F.gelu(ur, approximate="tanh")
+    assert (o.double().cpu() - orf).abs().max().item() < 0.04
+    do = torch.randn(4, 33, 64, generator=g).to(torch.bfloat16)
+    o.backward(dev(do))
+    orf.backward(do.double())
+    assert (ud.grad.double().cpu() - ur.grad).abs().max().item() < 0.03
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, do=None):
+    """fp64 softmax(QK^T/8)V on bf16-valued inputs [B,H,S,64]."""
+    q, k, v = (t.double().requires_grad_(do is not None) for t in (q, k, v))
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    o = torch.softmax(s, -1) @ v
+    if do is None:
+        return o
+    o.backward(do.double())
+    return o.detach(), q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 1, 128), (2, 3, 200), (1, 2, 333), (1, 1, 1000)])
+def test_attention_fwd_bwd_raw(ops, B, H, S):
+    g = torch.Generator().manual_seed(S)
+    q, k, v, do = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16) for _ in range(4))
+    q = q * 1.5   # sharper softmax
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o, lse = ops.attention_fwd_raw(qd, kd, vd)
+    o_ref, dq_ref, dk_ref, dv_ref = _attn_ref(q, k, v, do)
+    o_bhsd = o.view(B, S, H, 64).permute(0, 2, 1, 3).double().cpu()
+    err = (o_bhsd - o_ref).abs().max().item()
+    assert err < 0.02, f"attention fwd max err {err}"
+    s = (q.double() @ k.double().transpose(-1, -2)) / 8.0
+    lse_ref = torch.logsumexp(s, -1) / math.log(2.0)
+    assert (lse.double().cpu() - lse_ref).abs().max().item() < 2e-3
+    dq, dk, dv = (torch.empty(B, H, S, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    ov = o.view(B, S, H, 64).permute(0, 2, 1, 3)
+    ops.attention_bwd_raw(qd, kd, vd, ov, dev(do), lse, dq, dk, dv)
+    for name, a, r in (("dq", dq, dq_ref), ("dk", dk, dk_ref), ("dv", dv, dv_ref)):
+        e = (a.double().cpu() - r).abs().max().item()
+        assert e < 0.03 * r.abs().max().item() + 2e-3, f"{name} max err {e} (ref max {r.abs().max().item()})"
+
+
+def test_attention_online_softmax_rescale(ops):
+    """Force a late, large running-max jump (a spiked key in the last tile) -- guide rule 26."""
+    g = torch.Generator().manual_seed(77)
+    B, H, S = 1, 1, 256
+    q, k, v = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16) for _ in range(3))
+    k[0, 0, 250] = (q[0, 0, 17].float() * 4).to(torch.bfloat16)
+    o, _ = ops.attention_fwd_raw(dev(q), dev(k), dev(v))
+    o_ref = _attn_ref(q, k, v)
+    err = (o.view(B, S, H, 64).permute(0, 2, 1, 3).double().cpu() - o_ref).abs().max().item()
+    assert err < 0.03, err
+
+
+@pytest.mark.parametrize("use_rope", [False, True])
+def test_qknorm_attention_fused(ops, use_rope):
+    g = torch.Generator().manual_seed(9)
+    B, H, Lt, Fr, gh, gw = 2, 2, 6, 2, 4, 5
+    Sv = Fr * gh * gw
+    S = Lt + Sv
+    qkv = torch.randn(B, S, 3 * H * 64, generator=g).to(torch.bfloat16)
+    wq, wk = (1 + 0.2 * torch.randn(64, generator=g) for _ in range(2))
+    bq, bk = (0.2 * torch.randn(64, generator=g) for _ in range(2))
+    rope = ocv.rope_3d_tables(Fr, gh, gw, 64) if use_rope else None
+    do = torch.randn(B, S, H * 64, generator=g).to(torch.bfloat16)
+    qd = dev(qkv).requires_grad_(True)
+    o = ops.qknorm_attention(qd, dev(wq), dev(bq), dev(wk), dev(bk), H, Lt, None if rope is None else (dev(rope[0]), dev(rope[1])))
+    o.backward(dev(do))
+
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x.view(B, S, 3, H, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    q = F.layer_norm(q, (64,), wq.double(), bq.double(), 1e-6)
+    k = F.layer_norm(k, (64,), wk.double(), bk.double(), 1e-6)
+    if use_rope:
+        cos, sin = rope[0].double(), rope[1].double()
+
+        def rot(t):
+            tr, ti = t.reshape(*t.shape[:-1], -1, 2).unbind(-1)
+            t_rot = torch.stack([-ti, tr], dim=-1).flatten(3)
+            return t * cos + t_rot * sin
+        q = torch.cat([q[:, :, :Lt], rot(q[:, :, Lt:])], 2)
+        k = torch.cat([k[:, :, :Lt], rot(k[:, :, Lt:])], 2)
+    orf = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, H * 64)
+    orf.backward(do.double())
+    assert (o.double().cpu() - orf).abs().max().item() < 0.03
+    e = (qd.grad.double().cpu() - x.grad).abs().max().item()
+    assert e < 0.03 * x.grad.abs().max().item() + 2e-3, e

@@ -1,0 +1,67 @@
+"""ctypes binding of the C-ABI HIP library (include/videogpa_hip.h).  No fallback: if the library is missing
+or a call fails, this raises -- the product path never silently runs on something else."""
+import ctypes
+import os
+from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvgpa_hip.so")
+
+P, I64, I32, F32, SZ = c_void_p, c_int64, c_int32, c_float, c_size_t
+
+# name -> (restype, [argtypes]) ; must mirror include/videogpa_hip.h (tests/test_cabi.py checks the symbol set)
+SIGNATURES = {
+    "vgpa_dpo_loss_workspace_bytes": (SZ, [I64]),
+    "vgpa_dpo_loss_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, F32, I32, I32, P, P, P, P, SZ, P]),
+    "vgpa_dpo_loss_bwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I32, F32, I32, P, P, P, P, P]),
+    "vgpa_noise_velocity_paired": (I32, [P, P, P, P, P, I64, I64, I32, I32, P, P, P]),
+    "vgpa_ln_modulate_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P, P, P, P]),
+    "vgpa_ln_modulate_bwd": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P]),
+    "vgpa_gate_residual": (I32, [P, P, P, P, I64, I64, I64, I64, I64, P, P]),
+    "vgpa_gelu_tanh_fwd": (I32, [P, I64, P, P]),
+    "vgpa_gelu_tanh_bwd": (I32, [P, P, I64, P, P]),
+    "vgpa_qknorm_rope_fwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
+    "vgpa_qknorm_rope_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
+    "vgpa_attn_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
+    "vgpa_attn_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
+    "vgpa_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
+}
+
+_ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "workspace too small"}
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"videogpa_amd: HIP library not built ({LIB_PATH} missing). Run `python -m videogpa_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU / PyTorch fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args):
+    """Call a status-returning entry point; tensors are passed as raw device pointers."""
+    fn = getattr(load(), name)
+    rc = fn(*[_conv(a) for a in args])
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

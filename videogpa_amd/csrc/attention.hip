@@ -1,0 +1,520 @@
+// 3D full attention (all T*H*W + text tokens, non-causal, head_dim 64) for gfx950: flash-style forward and
+// a split backward (dQ kernel; dK/dV kernel), hand-written around v_mfma_f32_32x32x16_bf16.
+// Replaces F.scaled_dot_product_attention inside diffusers' CogVideoXAttnProcessor2_0 as reached from
+// train/CogVideoX-5B/03_train.py:134-151; oracle: oracle/cogvideox.py::block_forward (softmax(QK^T/8)V).
+//
+// Design (MI355X-first):
+//  * 256-thread workgroup = 4 waves; a wave owns 32 query rows (fwd, dQ) or 32 key rows (dK/dV) and keeps its
+//    operand fragments and accumulators in registers for the whole sweep over the other sequence axis.
+//  * Every product is computed TRANSPOSED (S^T = K Q^T, O^T = V^T P^T, ...) so the softmax row a lane works on
+//    is the MFMA column lane&31: running max / sum / LSE / delta are lane-local scalars, and the fp32
+//    accumulator registers of one product are, after a bf16 pack, directly the B operand of the next one
+//    (the k-slot permutation this implies is applied to the A-side LDS reads instead of shuffling P).
+//  * K/V (or Q/dO) tiles of 64 rows are staged HBM -> registers -> LDS, double-buffered, one barrier per tile;
+//    row pitch 144 B makes the 16-byte fragment reads bank-conflict free.  Operands that are contracted over
+//    their row index are read with the gfx950 hardware transpose read (ds_read_b64_tr_b16), so every tensor
+//    stays row-major [tokens, 64] in HBM and no transposed copy is ever written.
+//  * Loads clamp the row index to S-1 and the tail is masked, so S needs no padding (17 776 = 277*64 + 48).
+//  * blockIdx is remapped so that the workgroups an XCD runs concurrently share (batch, head) and hit K/V in
+//    that XCD's private L2.
+#include "common.h"
+
+#define HD 64          // head dim
+#define PITCH 72       // LDS row pitch in bf16 elements (144 B)
+#define TILE 64        // rows of the streamed operand per iteration
+#define WG_ROWS 128    // rows of the stationary operand per workgroup (4 waves x 32)
+#define TILE_ELEMS (TILE * PITCH)
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+struct TStride {  // element strides of a [B, H, S, 64] view (last dim contiguous)
+    int64_t b, h, s;
+};
+
+__device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
+
+// 8 consecutive fp32 accumulator registers -> bf16x8 MFMA operand
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int base) {
+    bf16x8_t r;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        f32x2_t f = {a[base + i], a[base + i + 1]};
+        bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+        r[i] = h[0];
+        r[i + 1] = h[1];
+    }
+    return r;
+}
+
+// ---- global -> register -> LDS staging of a [64 x 64] bf16 tile (rows clamped to S-1) ------------------------
+__device__ __forceinline__ void tile_load(const bf16_t* base, int64_t row_stride, int row0, int S, u32x4_t (&r)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        int row = row0 + (c >> 3);
+        row = row < S ? row : S - 1;
+        r[j] = *reinterpret_cast<const u32x4_t*>(base + (int64_t)row * row_stride + (c & 7) * 8);
+    }
+}
+__device__ __forceinline__ void tile_store(bf16_t* lds, const u32x4_t (&r)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        *reinterpret_cast<u32x4_t*>(lds + (c >> 3) * PITCH + (c & 7) * 8) = r[j];
+    }
+}
+
+// A/B fragment whose contraction index runs along the row (d contiguous): lane (l&31, l>>5) reads 16 B.
+__device__ __forceinline__ bf16x8_t frag_row(const bf16_t* lds, int rowbase, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(lds + (rowbase + (lane & 31)) * PITCH + ks * 16 + (lane >> 5) * 8);
+}
+
+// A fragment whose contraction index runs ACROSS rows (transposed use of a row-major tile).
+// Element i of lane (m = l&31, hi = l>>5) is tile[rowbase + 4*hi + (i&3) + 8*(i>>2)][colbase + m]: exactly the row
+// order in which the previous product left its accumulator rows (row = (r&3) + 8*(r>>2) + 4*hi), so packed
+// accumulators can be used as the B operand unshuffled.  Two ds_read_b64_tr_b16: each 16-lane group reads a
+// [4 rows x 16 cols] block and receives it column-per-lane.
+__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* lds, int rowbase, int colbase, int lane) {
+    const int hi = lane >> 5;
+    const bf16_t* p = lds + (rowbase + 4 * hi + ((lane & 15) >> 2)) * PITCH + colbase + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr_t;
+    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr_t)(p));
+    bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr_t)(p + 8 * PITCH));
+    bf16x8_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = lo[i]; r[i + 4] = hi4[i]; }
+    return r;
+}
+
+// stationary-operand fragments straight from HBM: lane (row = l&31, hi) takes 8 contiguous d per k-step
+__device__ __forceinline__ void load_row_frags(const bf16_t* base, int64_t row_stride, int row, int S, int lane, bf16x8_t (&f)[4]) {
+    int r = row + (lane & 31);
+    r = r < S ? r : S - 1;
+    const bf16_t* p = base + (int64_t)r * row_stride + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(p + ks * 16);
+}
+
+// XCD-aware remap of the linear block id: consecutive virtual ids (same head) land on one XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+// row index inside a 32-row MFMA block of accumulator register r for this lane
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// =====================================================================================================
+// Forward:  O = softmax(scale * Q K^T) V ;  lse2 = log2 sum_k exp2(scale*log2e * q.k)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                         const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                         float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
+                                                         int S, int H, int n_qt, float c /* scale*log2(e) */) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // K[2], V[2]
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int q0 = qt * WG_ROWS + wave * 32;
+
+    const bf16_t* Qb = Q + b * sq.b + h * sq.h;
+    const bf16_t* Kb = K + b * sk.b + h * sk.h;
+    const bf16_t* Vb = V + b * sv.b + h * sv.h;
+
+    bf16x8_t qf[4];
+    load_row_frags(Qb, sq.s, q0, S, lane, qf);
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+
+    const int nt = (S + TILE - 1) / TILE;
+    u32x4_t kr[2], vr[2];
+    tile_load(Kb, sk.s, 0, S, kr);
+    tile_load(Vb, sv.s, 0, S, vr);
+    tile_store(lds, kr);
+    tile_store(lds + 2 * TILE_ELEMS, vr);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const bf16_t* kl = lds + (t & 1) * TILE_ELEMS;
+        const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
+        if (t + 1 < nt) {
+            tile_load(Kb, sk.s, (t + 1) * TILE, S, kr);
+            tile_load(Vb, sv.s, (t + 1) * TILE, S, vr);
+        }
+        // S^T[key, q] for the two 32-key blocks
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s[kb]);
+        }
+        if (t == nt - 1 && (S & (TILE - 1))) {
+            const int kbase = t * TILE;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + kb * 32 + acc_row(r, hi) >= S) s[kb][r] = -INFINITY;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, other_half(mx));
+        const float m_new = fmaxf(m, mx * c);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] * c - m_new);
+                s[kb][r] = p;
+                psum += p;
+            }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        // O^T[d, q] += V^T[d, key] P^T[key, q]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bf16x8_t pf = pack_frag(s[kb], 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o[db] = mfma32(frag_tr(vl, kb * 32 + 16 * cc, db * 32, lane), pf, o[db]);
+            }
+        if (t + 1 < nt) {
+            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
+            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, vr);
+        }
+        __syncthreads();
+    }
+
+    l += other_half(l);
+    const float inv = 1.f / l;
+    const int q = q0 + (lane & 31);
+    if (q < S) {
+        bf16_t* op = O + b * so.b + h * so.h + (int64_t)q * so.s;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t w;
+                w[0] = pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+                w[1] = pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+            }
+        if (hi == 0) LSE2[(int64_t)bh * S + q] = m + __builtin_amdgcn_logf(l);  // v_log_f32 is log2
+    }
+}
+
+// =====================================================================================================
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+// =====================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, TStride sdo,
+                                                           TStride so, int S, int H, int64_t total /* B*H*S */, float* __restrict__ delta) {
+    // 8 lanes per (b,h,q) row, 16 B each
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = gid >> 3;
+    const int c8 = (int)(gid & 7);
+    float acc = 0.f;
+    if (row < total) {
+        const int q = (int)(row % S);
+        const int64_t bh = row / S;
+        const int h = (int)(bh % H), b = (int)(bh / H);
+        float a[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(dO + b * sdo.b + h * sdo.h + (int64_t)q * sdo.s + c8 * 8), a);
+        unpack8(*reinterpret_cast<const u32x4_t*>(O + b * so.b + h * so.h + (int64_t)q * so.s + c8 * 8), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (row < total && c8 == 0) delta[row] = acc;
+}
+
+// =====================================================================================================
+// Backward, dQ:  dQ = scale * sum_k dS[q,k] K[k],  dS = P o (dP - delta),  P = exp2(c*s - lse2),  dP = dO V^T
+// =====================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                            const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                            bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo,
+                                                            TStride sdq, int S, int H, int n_qt, float c, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // K[2], V[2]
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int q0 = qt * WG_ROWS + wave * 32;
+
+    const bf16_t* Kb = K + b * sk.b + h * sk.h;
+    const bf16_t* Vb = V + b * sv.b + h * sv.h;
+    bf16x8_t qf[4], dof[4];
+    load_row_frags(Q + b * sq.b + h * sq.h, sq.s, q0, S, lane, qf);
+    load_row_frags(dO + b * sdo.b + h * sdo.h, sdo.s, q0, S, lane, dof);
+    int qc = q0 + (lane & 31);
+    qc = qc < S ? qc : S - 1;
+    const float lse = LSE2[(int64_t)bh * S + qc];
+    const float dlt = DELTA[(int64_t)bh * S + qc];
+
+    f32x16_t dq[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+
+    const int nt = (S + TILE - 1) / TILE;
+    u32x4_t kr[2], vr[2];
+    tile_load(Kb, sk.s, 0, S, kr);
+    tile_load(Vb, sv.s, 0, S, vr);
+    tile_store(lds, kr);
+    tile_store(lds + 2 * TILE_ELEMS, vr);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const bf16_t* kl = lds + (t & 1) * TILE_ELEMS;
+        const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
+        if (t + 1 < nt) {
+            tile_load(Kb, sk.s, (t + 1) * TILE, S, kr);
+            tile_load(Vb, sv.s, (t + 1) * TILE, S, vr);
+        }
+        const bool tail = (t == nt - 1) && (S & (TILE - 1));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s);      // S^T[key,q]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(vl, kb * 32, ks, lane), dof[ks], dp);   // dP^T[key,q]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[r] * c - lse);
+                if (tail && (t * TILE + kb * 32 + acc_row(r, hi) >= S)) p = 0.f;
+                s[r] = p * (dp[r] - dlt);                                                                // dS^T
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bf16x8_t dsf = pack_frag(s, 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_tr(kl, kb * 32 + 16 * cc, db * 32, lane), dsf, dq[db]);  // dQ^T[d,q]
+            }
+        }
+        if (t + 1 < nt) {
+            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
+            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, vr);
+        }
+        __syncthreads();
+    }
+    const int q = q0 + (lane & 31);
+    if (q < S) {
+        bf16_t* op = dQ + b * sdq.b + h * sdq.h + (int64_t)q * sdq.s;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t w;
+                w[0] = pack_bf16x2(dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale);
+                w[1] = pack_bf16x2(dq[db][4 * g + 2] * scale, dq[db][4 * g + 3] * scale);
+                *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
+}
+
+// =====================================================================================================
+// Backward, dK / dV:  dV = P^T dO ,  dK = scale * dS^T Q       (workgroup owns 128 keys, streams 64-query tiles)
+// =====================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                             const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                             const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                             bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, TStride sq, TStride sk,
+                                                             TStride sv, TStride sdo, TStride sdk, TStride sdv, int S, int H, int n_kt,
+                                                             float c, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // Q[2], dO[2]
+    __shared__ __attribute__((aligned(16))) float stat[2][2][TILE];      // [buf][lse|delta][q]
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / n_kt, kt = vid % n_kt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int k0 = kt * WG_ROWS + wave * 32;
+
+    const bf16_t* Qb = Q + b * sq.b + h * sq.h;
+    const bf16_t* dOb = dO + b * sdo.b + h * sdo.h;
+    const float* Lb = LSE2 + (int64_t)bh * S;
+    const float* Db = DELTA + (int64_t)bh * S;
+    bf16x8_t kf[4], vf[4];
+    load_row_frags(K + b * sk.b + h * sk.h, sk.s, k0, S, lane, kf);
+    load_row_frags(V + b * sv.b + h * sv.h, sv.s, k0, S, lane, vf);
+
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+    const int nt = (S + TILE - 1) / TILE;
+    u32x4_t qr[2], dor[2];
+    float st = 0.f;
+    auto stat_load = [&](int t) {
+        if (threadIdx.x < 2 * TILE) {
+            int q = t * TILE + (threadIdx.x & (TILE - 1));
+            q = q < S ? q : S - 1;
+            st = (threadIdx.x < TILE) ? Lb[q] : Db[q];
+        }
+    };
+    auto stat_store = [&](int buf) {
+        if (threadIdx.x < 2 * TILE) stat[buf][threadIdx.x >> 6][threadIdx.x & (TILE - 1)] = st;
+    };
+    tile_load(Qb, sq.s, 0, S, qr);
+    tile_load(dOb, sdo.s, 0, S, dor);
+    stat_load(0);
+    tile_store(lds, qr);
+    tile_store(lds + 2 * TILE_ELEMS, dor);
+    stat_store(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const bf16_t* ql = lds + (t & 1) * TILE_ELEMS;
+        const bf16_t* dol = lds + (2 + (t & 1)) * TILE_ELEMS;
+        const float* lse_l = stat[t & 1][0];
+        const float* dlt_l = stat[t & 1][1];
+        if (t + 1 < nt) {
+            tile_load(Qb, sq.s, (t + 1) * TILE, S, qr);
+            tile_load(dOb, sdo.s, (t + 1) * TILE, S, dor);
+            stat_load(t + 1);
+        }
+        const bool tail = (t == nt - 1) && (S & (TILE - 1));
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(ql, qb * 32, ks, lane), kf[ks], s);      // S[q,key]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key]
+            // per-row statistics: rows (r&3) + 8*(r>>2) + 4*hi -> four 16-byte LDS reads each
+            f32x4_t lv[4], dl[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lv[g] = *reinterpret_cast<const f32x4_t*>(lse_l + qb * 32 + 8 * g + 4 * hi);
+                dl[g] = *reinterpret_cast<const f32x4_t*>(dlt_l + qb * 32 + 8 * g + 4 * hi);
+            }
+            f32x16_t ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[r] * c - lv[r >> 2][r & 3]);
+                if (tail && (t * TILE + qb * 32 + acc_row(r, hi) >= S)) p = 0.f;
+                s[r] = p;
+                ds[r] = p * (dp[r] - dl[r >> 2][r & 3]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bf16x8_t pf = pack_frag(s, 8 * cc);
+                const bf16x8_t dsf = pack_frag(ds, 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = mfma32(frag_tr(dol, qb * 32 + 16 * cc, db * 32, lane), pf, dv[db]);   // dV^T[d,key] += dO^T P
+                    dk[db] = mfma32(frag_tr(ql, qb * 32 + 16 * cc, db * 32, lane), dsf, dk[db]);   // dK^T[d,key] += Q^T dS
+                }
+            }
+        }
+        if (t + 1 < nt) {
+            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, qr);
+            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, dor);
+            stat_store((t + 1) & 1);
+        }
+        __syncthreads();
+    }
+    const int k = k0 + (lane & 31);
+    if (k < S) {
+        bf16_t* kp = dK + b * sdk.b + h * sdk.h + (int64_t)k * sdk.s;
+        bf16_t* vp = dV + b * sdv.b + h * sdv.h + (int64_t)k * sdv.s;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t w;
+                w[0] = pack_bf16x2(dk[db][4 * g] * scale, dk[db][4 * g + 1] * scale);
+                w[1] = pack_bf16x2(dk[db][4 * g + 2] * scale, dk[db][4 * g + 3] * scale);
+                *reinterpret_cast<u32x2_t*>(kp + db * 32 + 8 * g + 4 * hi) = w;
+                w[0] = pack_bf16x2(dv[db][4 * g], dv[db][4 * g + 1]);
+                w[1] = pack_bf16x2(dv[db][4 * g + 2], dv[db][4 * g + 3]);
+                *reinterpret_cast<u32x2_t*>(vp + db * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
+}
+
+static inline bool stride_ok(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= HD && (st[0] % 8 == 0) && (st[1] % 8 == 0) && (st[2] % 8 == 0); }
+static inline TStride mk(const int64_t* st) { TStride t; t.b = st[0]; t.h = st[1]; t.s = st[2]; return t; }
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" {
+
+// All tensors are bf16 views [B, H, S, 64] given by element strides {batch, head, token} (last dim contiguous,
+// strides multiples of 8, base pointers 16-byte aligned).  lse2 / delta are fp32 [B, H, S] contiguous.
+int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
+                      const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
+                      int64_t head_dim, float scale, hipStream_t stream) {
+    if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
+    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(o_strides)) return VGPA_ERR_INVALID;
+    if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
+    const int n_qt = (int)((S + WG_ROWS - 1) / WG_ROWS);
+    const int64_t nblk = (int64_t)n_qt * B * H;
+    if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt,
+                       scale * 1.4426950408889634f);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// workspace: fp32 delta [B,H,S]  (vgpa_attn_bwd_workspace_bytes)
+size_t vgpa_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t S) { return (size_t)B * H * S * sizeof(float); }
+
+int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
+                      void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                      const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides, int64_t B,
+                      int64_t H, int64_t S, int64_t head_dim, float scale, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || !workspace || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24))
+        return VGPA_ERR_INVALID;
+    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(o_strides) || !stride_ok(do_strides) ||
+        !stride_ok(dq_strides) || !stride_ok(dk_strides) || !stride_ok(dv_strides))
+        return VGPA_ERR_INVALID;
+    if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || !al16(dq) || !al16(dk) || !al16(dv)) return VGPA_ERR_INVALID;
+    if (ws_bytes < vgpa_attn_bwd_workspace_bytes(B, H, S)) return VGPA_ERR_WORKSPACE;
+    float* delta = (float*)workspace;
+    const int64_t total = B * H * S;
+    const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
+    const int64_t nblk = (int64_t)n_t * B * H;
+    if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
+    const float c = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o,
+                       mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta);
+    VGPA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                       mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, c, scale);
+    VGPA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                       mk(dq_strides), (int)S, (int)H, n_t, c, scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// Shared device helpers for the videogpa_amd HIP kernels (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VGPA_OK 0
+#define VGPA_ERR_INVALID (-1)   // bad argument (null pointer, unsupported shape / dtype)
+#define VGPA_ERR_LAUNCH (-2)    // hipGetLastError() after a launch
+#define VGPA_ERR_WORKSPACE (-3) // caller-provided workspace too small
+
+#define VGPA_DTYPE_F32 0
+#define VGPA_DTYPE_BF16 1
+
+#define VGPA_CHECK_LAUNCH()                               \
+    do {                                                  \
+        if (hipGetLastError() != hipSuccess) return VGPA_ERR_LAUNCH; \
+    } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;  // 16-byte load/store
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round-to-nearest-even, NaN kept quiet (same result as torch's float -> bfloat16 cast)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf16lo_to_f32(v[i]);
+        f[2 * i + 1] = bf16hi_to_f32(v[i]);
+    }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in every thread
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 entries */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    T r = 0;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+    return r;
+}
+
+// load 8 consecutive elements as float from f32 or bf16 storage (16-byte aligned for bf16, 32 for f32)
+template <int DT>
+__device__ __forceinline__ void load8(const void* base, size_t idx, float* f) {
+    if (DT == VGPA_DTYPE_BF16) {
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(base) + idx);
+        unpack8(v, f);
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+        float4 a = p[0], b = p[1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+}
+template <int DT>
+__device__ __forceinline__ void store8(void* base, size_t idx, const float* f) {
+    if (DT == VGPA_DTYPE_BF16) {
+        *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(base) + idx) = pack8(f);
+    } else {
+        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx);
+        p[0] = make_float4(f[0], f[1], f[2], f[3]);
+        p[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+}
+template <int DT>
+__device__ __forceinline__ float load1(const void* base, size_t idx) {
+    if (DT == VGPA_DTYPE_BF16) return bf16_to_f32(reinterpret_cast<const bf16_t*>(base)[idx]);
+    return reinterpret_cast<const float*>(base)[idx];
+}
+template <int DT>
+__device__ __forceinline__ void store1(void* base, size_t idx, float f) {
+    if (DT == VGPA_DTYPE_BF16) reinterpret_cast<bf16_t*>(base)[idx] = f32_to_bf16(f);
+    else reinterpret_cast<float*>(base)[idx] = f;
+}

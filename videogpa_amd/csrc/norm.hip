@@ -1,0 +1,268 @@
+// AdaLN-Zero normalisation kernels for the mixed [text | video] token stream.
+// Replaces diffusers CogVideoXLayerNormZero / AdaLayerNorm / nn.LayerNorm as reached from
+// train/CogVideoX-5B/03_train.py:134-151 (transformer forward) -- see oracle/cogvideox.py::block_forward.
+//
+// Layout: one residual stream x[B,S,D] bf16, text tokens first (rows < text_len), video tokens after.  The
+// per-range modulation vectors (shift, 1+scale, gate) are tiny fp32 [B,D] arrays, so a row only has to pick
+// the pointer for its range: no torch.cat / split of the two streams is ever materialised.
+//
+// HBM-bound: one wave per token row, the whole row lives in registers (D <= 4096), 16-byte loads, exact
+// two-pass mean/variance, wave-level reductions only (no LDS, no barriers).
+#include "common.h"
+
+#define ROWS_PER_BLOCK 4
+
+template <int NV>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void ln_modulate_fwd_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ shift_v, const float* __restrict__ scale1p_v, const float* __restrict__ shift_t,
+    const float* __restrict__ scale1p_t, int64_t mod_stride, int text_len, int S, int D, int64_t rows, float eps,
+    bf16_t* __restrict__ out, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const bf16_t* xr = x + (size_t)row * D;
+    float v[NV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            unpack8(*reinterpret_cast<const u32x4_t*>(xr + i0), v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[c][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const bool is_text = s < text_len;
+    const float* sh = is_text ? shift_t : shift_v;
+    const float* sc = is_text ? scale1p_t : scale1p_v;
+    if (sh) { sh += (size_t)b * mod_stride; sc += (size_t)b * mod_stride; }
+    bf16_t* orow = out + (size_t)row * D;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = (v[c][j] - mean) * rstd * w[i0 + j] + bias[i0 + j];
+                if (sh) y = y * sc[i0 + j] + sh[i0 + j];
+                o[j] = y;
+            }
+            *reinterpret_cast<u32x4_t*>(orow + i0) = pack8(o);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * (1+scale) * w ;  optionally dx += dres
+template <int NV>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void ln_modulate_bwd_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ w, const float* __restrict__ scale1p_v,
+    const float* __restrict__ scale1p_t, int64_t mod_stride, int text_len, int S, int D, int64_t rows,
+    const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const float* sc = (s < text_len) ? scale1p_t : scale1p_v;
+    if (sc) sc += (size_t)b * mod_stride;
+    float g[NV][8], xh[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float a[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(dy + (size_t)row * D + i0), a);
+            unpack8(*reinterpret_cast<const u32x4_t*>(x + (size_t)row * D + i0), xh[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gg = a[j] * w[i0 + j];
+                if (sc) gg *= sc[i0 + j];
+                g[c][j] = gg;
+                xh[c][j] = (xh[c][j] - mean) * rstd;
+                s1 += gg;
+                s2 += gg * xh[c][j];
+            }
+        }
+    }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float o[8];
+            if (dres) unpack8(*reinterpret_cast<const u32x4_t*>(dres + (size_t)row * D + i0), o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = rstd * (g[c][j] - c1 - xh[c][j] * c2);
+                o[j] = dres ? o[j] + d : d;
+            }
+            *reinterpret_cast<u32x4_t*>(dx + (size_t)row * D + i0) = pack8(o);
+        }
+    }
+}
+
+// out = (x ? x : 0) + gate[range] * y   with bf16 rounding after the product (torch bf16 elementwise semantics)
+__global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                              const float* __restrict__ gate_v, const float* __restrict__ gate_t,
+                                                              int64_t mod_stride, int text_len, int S, int D, int64_t total8,
+                                                              bf16_t* __restrict__ out) {
+    const int d8 = D >> 3;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < total8; c += (int64_t)gridDim.x * 256) {
+        const int64_t row = c / d8;
+        const int i0 = (int)(c % d8) * 8;
+        const int b = (int)(row / S), s = (int)(row % S);
+        const float* gp = ((s < text_len) ? gate_t : gate_v) + (size_t)b * mod_stride + i0;
+        float yy[8], xx[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(y + (size_t)c * 8), yy);
+        if (x) unpack8(*reinterpret_cast<const u32x4_t*>(x + (size_t)c * 8), xx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = round_bf16(gp[j] * yy[j]);
+            xx[j] = x ? xx[j] + p : p;
+        }
+        *reinterpret_cast<u32x4_t*>(out + (size_t)c * 8) = pack8(xx);
+    }
+}
+
+__device__ __forceinline__ float tanh_fast(float z) {
+    // 1 - 2/(1+e^{2z}); saturates cleanly for |z| large
+    const float e = __expf(2.f * z);
+    return 1.f - 2.f / (1.f + e);
+}
+
+__global__ __launch_bounds__(256) void gelu_tanh_fwd_kernel(const bf16_t* __restrict__ u, int64_t total8, bf16_t* __restrict__ out) {
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < total8; c += (int64_t)gridDim.x * 256) {
+        float a[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(u + (size_t)c * 8), a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = a[j];
+            const float z = 0.7978845608028654f * (xv + 0.044715f * xv * xv * xv);
+            a[j] = 0.5f * xv * (1.f + tanh_fast(z));
+        }
+        *reinterpret_cast<u32x4_t*>(out + (size_t)c * 8) = pack8(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_tanh_bwd_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dy, int64_t total8,
+                                                              bf16_t* __restrict__ du) {
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < total8; c += (int64_t)gridDim.x * 256) {
+        float a[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(u + (size_t)c * 8), a);
+        unpack8(*reinterpret_cast<const u32x4_t*>(dy + (size_t)c * 8), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = a[j];
+            const float x2 = xv * xv;
+            const float z = 0.7978845608028654f * (xv + 0.044715f * xv * x2);
+            const float t = tanh_fast(z);
+            const float dz = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
+            a[j] = g[j] * (0.5f * (1.f + t) + 0.5f * xv * (1.f - t * t) * dz);
+        }
+        *reinterpret_cast<u32x4_t*>(du + (size_t)c * 8) = pack8(a);
+    }
+}
+
+static inline unsigned ew_grid(int64_t total8) {
+    int64_t nb = (total8 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+#define DISPATCH_NV(D, CALL)                       \
+    switch (((D) + 511) / 512) {                   \
+        case 1: { constexpr int NV = 1; CALL; } break; \
+        case 2: { constexpr int NV = 2; CALL; } break; \
+        case 3: { constexpr int NV = 3; CALL; } break; \
+        case 4: { constexpr int NV = 4; CALL; } break; \
+        case 5: { constexpr int NV = 5; CALL; } break; \
+        case 6: { constexpr int NV = 6; CALL; } break; \
+        case 7: { constexpr int NV = 7; CALL; } break; \
+        case 8: { constexpr int NV = 8; CALL; } break; \
+        default: return VGPA_ERR_INVALID;          \
+    }
+
+extern "C" {
+
+// y = LayerNorm(x; w, b, eps) [* scale1p + shift per token range].  Modulation pointers may all be NULL (plain LN).
+int32_t vgpa_ln_modulate_fwd(const void* x, const float* ln_w, const float* ln_b, const float* shift_v, const float* scale1p_v,
+                             const float* shift_t, const float* scale1p_t, int64_t mod_stride, int64_t B, int64_t S, int64_t D,
+                             int64_t text_len, float eps, void* out, float* mean, float* rstd, hipStream_t stream) {
+    if (!x || !ln_w || !ln_b || !out) return VGPA_ERR_INVALID;
+    if (B <= 0 || S <= 0 || D <= 0 || D % 8 != 0 || D > 4096 || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
+    const bool mod = shift_v != nullptr;
+    if (mod && (!scale1p_v || (text_len > 0 && (!shift_t || !scale1p_t)))) return VGPA_ERR_INVALID;
+    if ((mean == nullptr) != (rstd == nullptr)) return VGPA_ERR_INVALID;
+    const int64_t rows = B * S;
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    DISPATCH_NV(D, hipLaunchKernelGGL((ln_modulate_fwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)x, ln_w, ln_b,
+                                      shift_v, scale1p_v, shift_t, scale1p_t, mod_stride, (int)text_len, (int)S, (int)D, rows, eps,
+                                      (bf16_t*)out, mean, rstd));
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// dx = LN-backward(dy * scale1p * w) [+ dres].  No grads for w, b, shift, scale (frozen base / timestep-only path).
+int32_t vgpa_ln_modulate_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* ln_w,
+                             const float* scale1p_v, const float* scale1p_t, int64_t mod_stride, int64_t B, int64_t S, int64_t D,
+                             int64_t text_len, const void* dres, void* dx, hipStream_t stream) {
+    if (!dy || !x || !mean || !rstd || !ln_w || !dx) return VGPA_ERR_INVALID;
+    if (B <= 0 || S <= 0 || D <= 0 || D % 8 != 0 || D > 4096 || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
+    if (scale1p_v && text_len > 0 && !scale1p_t) return VGPA_ERR_INVALID;
+    const int64_t rows = B * S;
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    DISPATCH_NV(D, hipLaunchKernelGGL((ln_modulate_bwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)dy,
+                                      (const bf16_t*)x, mean, rstd, ln_w, scale1p_v, scale1p_t, mod_stride, (int)text_len, (int)S, (int)D, rows,
+                                      (const bf16_t*)dres, (bf16_t*)dx));
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// out = x + gate[range] * y   (x may be NULL: out = gate * y, which is also the backward dy = gate * dout)
+int32_t vgpa_gate_residual(const void* x, const void* y, const float* gate_v, const float* gate_t, int64_t mod_stride, int64_t B,
+                           int64_t S, int64_t D, int64_t text_len, void* out, hipStream_t stream) {
+    if (!y || !gate_v || !out) return VGPA_ERR_INVALID;
+    if (B <= 0 || S <= 0 || D <= 0 || D % 8 != 0 || text_len < 0 || text_len > S || (text_len > 0 && !gate_t)) return VGPA_ERR_INVALID;
+    const int64_t total8 = B * S * D / 8;
+    hipLaunchKernelGGL(gate_residual_kernel, dim3(ew_grid(total8)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)y, gate_v, gate_t,
+                       mod_stride, (int)text_len, (int)S, (int)D, total8, (bf16_t*)out);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+int32_t vgpa_gelu_tanh_fwd(const void* u, int64_t n, void* out, hipStream_t stream) {
+    if (!u || !out || n <= 0 || n % 8 != 0) return VGPA_ERR_INVALID;
+    hipLaunchKernelGGL(gelu_tanh_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16_t*)u, n / 8, (bf16_t*)out);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+int32_t vgpa_gelu_tanh_bwd(const void* u, const void* dy, int64_t n, void* du, hipStream_t stream) {
+    if (!u || !dy || !du || n <= 0 || n % 8 != 0) return VGPA_ERR_INVALID;
+    hipLaunchKernelGGL(gelu_tanh_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16_t*)u, (const bf16_t*)dy, n / 8, (bf16_t*)du);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+}  // extern "C"

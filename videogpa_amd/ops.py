@@ -1,0 +1,257 @@
+"""torch.autograd wrappers over the C-ABI HIP kernels.  PyTorch here is plumbing (device memory, streams,
+autograd graph); every op below runs a hand-written gfx950 kernel through `_lib.call` and raises if it cannot."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, dtype=None, contiguous=True):
+    if not t.is_cuda:
+        raise RuntimeError("videogpa_amd ops need GPU tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t
+
+
+def _i64x3(*v):
+    return (ctypes.c_int64 * 3)(*v)
+
+
+# --------------------------------------------------------------------------------------------- DPO loss
+class _DPOLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v_win, v_lose, v_win_ref, v_lose_ref, tgt_win, tgt_lose, beta, label_smoothing, loss_type, round_diff):
+        ts = [v_win, v_lose, v_win_ref, v_lose_ref, tgt_win, tgt_lose]
+        dt = v_win.dtype
+        if dt not in _DT:
+            raise RuntimeError(f"dpo_loss: unsupported dtype {dt}")
+        ts = [_req(t.contiguous() if not t.is_contiguous() else t, dt) for t in ts]
+        B = ts[0].shape[0]
+        N = ts[0].numel() // B
+        for t in ts:
+            if t.shape != ts[0].shape:
+                raise RuntimeError("dpo_loss: shape mismatch")
+        dev = v_win.device
+        out5 = torch.empty(5, dtype=torch.float32, device=dev)
+        dlogit = torch.empty(B, dtype=torch.float32, device=dev)
+        errs = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        ws_bytes = _lib.query("vgpa_dpo_loss_workspace_bytes", B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        flags = 1 if round_diff else 0
+        _lib.call("vgpa_dpo_loss_fwd", *ts, B, N, N, N, N, _DT[dt], float(beta), float(label_smoothing), int(loss_type), flags,
+                  out5, dlogit, errs, ws, ws_bytes, _stream())
+        ctx.save_for_backward(ts[0], ts[1], ts[4], ts[5], dlogit)
+        ctx.meta = (B, N, _DT[dt], float(beta), flags)
+        ctx.mark_non_differentiable(errs)
+        return out5[0], out5[1], out5[2], out5[3], out5[4], errs
+
+    @staticmethod
+    def backward(ctx, g_loss, g_margin, g_wr, g_lr, g_acc, g_errs):
+        v_win, v_lose, tgt_win, tgt_lose, dlogit = ctx.saved_tensors
+        B, N, dt, beta, flags = ctx.meta
+        gw = torch.empty_like(v_win)
+        gl = torch.empty_like(v_lose)
+        g = g_loss.to(torch.float32).contiguous()
+        _lib.call("vgpa_dpo_loss_bwd", v_win, v_lose, tgt_win, tgt_lose, B, N, N, N, N, dt, beta, flags, dlogit, g, gw, gl, _stream())
+        return gw, gl, None, None, None, None, None, None, None, None
+
+
+def dpo_loss(v_win, v_lose, v_win_ref, v_lose_ref, tgt_win, tgt_lose, beta=1.0, label_smoothing=0.0, loss_type="sigmoid",
+             round_diff=False):
+    """-> (loss, reward_margin, winner_reward, loser_reward, accuracy, errs[B,4]); only `loss` carries grad
+    (the reference's logged scalars are detached by use; train/loss.py:116-121)."""
+    lt = {"sigmoid": 0, "hinge": 1}.get(loss_type)
+    if lt is None:
+        raise ValueError(f"Unknown loss type: {loss_type}")
+    return _DPOLossFn.apply(v_win, v_lose, v_win_ref, v_lose_ref, tgt_win, tgt_lose, beta, label_smoothing, lt, round_diff)
+
+
+# --------------------------------------------------------------------------------------------- noise / velocity
+def noise_velocity_paired(x_pair, noise, t, sqrt_abar, sqrt_1m_abar):
+    """x_pair [B,2,...], noise [B,...] (shared by the pair), t [B] int64 -> (x_noisy_pair, v_target_pair)."""
+    dt = x_pair.dtype
+    _req(x_pair, dt), _req(noise, dt), _req(t, torch.int64), _req(sqrt_abar, torch.float32), _req(sqrt_1m_abar, torch.float32)
+    B = x_pair.shape[0]
+    if x_pair.shape[1] != 2 or x_pair.shape[2:] != noise.shape[1:] or noise.shape[0] != B:
+        raise RuntimeError("noise_velocity_paired: expected x_pair [B,2,...] and noise [B,...]")
+    N = noise.numel() // B
+    xt = torch.empty_like(x_pair)
+    v = torch.empty_like(x_pair)
+    _lib.call("vgpa_noise_velocity_paired", x_pair, noise, t, sqrt_abar, sqrt_1m_abar, B, N, sqrt_abar.numel(), _DT[dt], xt, v, _stream())
+    return xt, v
+
+
+# --------------------------------------------------------------------------------------------- AdaLN-Zero pieces
+class _LNModulateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, mod, text_len, eps):
+        # x [B,S,D] bf16; ln_w/ln_b fp32 [D]; mod fp32 [B,4,D] = (shift_v, 1+scale_v, shift_t, 1+scale_t) or None
+        _req(x, torch.bfloat16), _req(ln_w, torch.float32), _req(ln_b, torch.float32)
+        B, S, D = x.shape
+        out = torch.empty_like(x)
+        mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        if mod is not None:
+            _req(mod, torch.float32)
+            sv, s1v, st, s1t = mod[:, 0], mod[:, 1], mod[:, 2], mod[:, 3]
+            stride = mod.stride(0)
+        else:
+            sv = s1v = st = s1t = None
+            stride = 0
+        _lib.call("vgpa_ln_modulate_fwd", x, ln_w, ln_b, sv, s1v, st, s1t, stride, B, S, D, text_len, float(eps), out, mean, rstd, _stream())
+        ctx.save_for_backward(x, mean, rstd, ln_w, mod)
+        ctx.text_len = text_len
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, ln_w, mod = ctx.saved_tensors
+        B, S, D = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        if mod is not None:
+            s1v, s1t, stride = mod[:, 1], mod[:, 3], mod.stride(0)
+        else:
+            s1v = s1t = None
+            stride = 0
+        _lib.call("vgpa_ln_modulate_bwd", dy, x, mean, rstd, ln_w, s1v, s1t, stride, B, S, D, ctx.text_len, None, dx, _stream())
+        return dx, None, None, None, None, None
+
+
+def ln_modulate(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
+    return _LNModulateFn.apply(x, ln_w, ln_b, mod, text_len, eps)
+
+
+class _GateResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, gates, text_len):
+        # out = x + gate[range] * y ; gates fp32 [B,2,D] = (gate_v, gate_t)
+        _req(x, torch.bfloat16), _req(y, torch.bfloat16), _req(gates, torch.float32)
+        B, S, D = x.shape
+        out = torch.empty_like(x)
+        _lib.call("vgpa_gate_residual", x, y, gates[:, 0], gates[:, 1], gates.stride(0), B, S, D, text_len, out, _stream())
+        ctx.save_for_backward(gates)
+        ctx.text_len = text_len
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gates,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, S, D = dout.shape
+        dy = torch.empty_like(dout)
+        _lib.call("vgpa_gate_residual", None, dout, gates[:, 0], gates[:, 1], gates.stride(0), B, S, D, ctx.text_len, dy, _stream())
+        return dout, dy, None, None
+
+
+def gate_residual(x, y, gates, text_len):
+    return _GateResidualFn.apply(x, y, gates, text_len)
+
+
+class _GeluTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u):
+        _req(u, torch.bfloat16)
+        out = torch.empty_like(u)
+        _lib.call("vgpa_gelu_tanh_fwd", u, u.numel(), out, _stream())
+        ctx.save_for_backward(u)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        du = torch.empty_like(u)
+        _lib.call("vgpa_gelu_tanh_bwd", u, dy, u.numel(), du, _stream())
+        return du
+
+
+def gelu_tanh(u):
+    return _GeluTanhFn.apply(u)
+
+
+# --------------------------------------------------------------------------------------------- attention
+def _bhs_strides(t):
+    """element strides {batch, head, token} of a [B,H,S,64] view"""
+    assert t.stride(3) == 1
+    return _i64x3(t.stride(0), t.stride(1), t.stride(2))
+
+
+def attention_fwd_raw(q, k, v, scale=None):
+    """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32."""
+    B, H, S, Dh = q.shape
+    scale = Dh ** -0.5 if scale is None else scale
+    o = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
+    ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
+    _lib.call("vgpa_attn_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
+              float(scale), _stream())
+    return o, lse
+
+
+def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None):
+    """All [B,H,S,64] bf16 views; writes dq, dk, dv in place."""
+    B, H, S, Dh = q.shape
+    scale = Dh ** -0.5 if scale is None else scale
+    ws_bytes = _lib.query("vgpa_attn_bwd_workspace_bytes", B, H, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    _lib.call("vgpa_attn_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o),
+              _bhs_strides(do), _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), ws, ws_bytes, _stream())
+
+
+class _QKNormAttentionFn(torch.autograd.Function):
+    """qkv [B,S,3*H*64] (fused QKV GEMM output) -> attention output [B,S,H*64].
+    QK-norm (+ optional 3D RoPE on tokens >= text_len) -> flash attention; backward returns dqkv in the same layout."""
+
+    @staticmethod
+    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps):
+        _req(qkv, torch.bfloat16)
+        B, S, W = qkv.shape
+        Dh = W // (3 * H)
+        qkv5 = qkv.view(B, S, 3, H, Dh)
+        q_in, k_in, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,S,Dh] views
+        qn = torch.empty(B, H, S, Dh, dtype=torch.bfloat16, device=qkv.device)
+        kn = torch.empty_like(qn)
+        _lib.call("vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
+                  wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), _stream())
+        o, lse = attention_fwd_raw(qn, kn, v)
+        ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
+        ctx.meta = (text_len, H, eps)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin = ctx.saved_tensors
+        text_len, H, eps = ctx.meta
+        B, S, W = qkv.shape
+        Dh = W // (3 * H)
+        do = do.contiguous()
+        qkv5 = qkv.view(B, S, 3, H, Dh)
+        q_in, k_in, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(B, S, 3, H, Dh)
+        dq_in, dk_in, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        dqn = torch.empty_like(qn)
+        dkn = torch.empty_like(kn)
+        ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
+        dov = do.view(B, S, H, Dh).permute(0, 2, 1, 3)
+        attention_bwd_raw(qn, kn, v, ov, dov, lse, dqn, dkn, dv)
+        _lib.call("vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
+                  _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
+                  float(eps), _stream())
+        return dqkv, None, None, None, None, None, None, None, None, None
+
+
+def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6):
+    cos, sin = (None, None) if rope is None else rope
+    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps)
