@@ -1,0 +1,158 @@
+"""End-to-end: the MI355X CogVideoXTransformer3DModel / LoRA / DPO step vs the CPU oracle.  -m gpu only."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cogvideox as ocv
+from oracle import scheduler as osch
+
+
+def _setup(num_layers=2, heads=2, r=4, b_std=0.0, rope=True, seed=0):
+    from videogpa_amd.lora import LoraConfig, get_peft_model
+    from videogpa_amd.transformer import CogVideoXTransformer3DModel
+    kw = dict(num_attention_heads=heads, attention_head_dim=64, num_layers=num_layers, time_embed_dim=32, text_embed_dim=48,
+              sample_width=8, sample_height=8, sample_frames=9, max_text_seq_length=6)
+    cfg = ocv.CogVideoXConfig(**kw)
+    sd = {k: v.to(torch.bfloat16) for k, v in ocv.init_state_dict(cfg, seed=seed, std=0.05, mod_std=0.2).items()}
+    model = CogVideoXTransformer3DModel(use_rotary_positional_embeddings=True, **kw)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(device="cuda", dtype=torch.bfloat16)
+    pm = get_peft_model(model, LoraConfig(r=r, lora_alpha=2 * r, target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    lora = ocv.init_lora(cfg, r=r, seed=seed + 1, b_std=b_std)
+    own = pm.state_dict()
+    for k, v in lora.items():
+        own[k[:-len(".weight")] + ".default.weight"].copy_(v)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    # the product casts adapter weights to bf16 at use (PEFT autocast semantics): mirror that rounding in the oracle
+    lora64 = {k: v.to(torch.bfloat16).double() for k, v in lora.items()}
+    return cfg, sd64, lora64, pm
+
+
+def _inputs(cfg, B=1, F=3, H=8, W=8, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (0.7 * torch.randn(B, F, cfg.in_channels, H, W, generator=g)).to(torch.bfloat16)
+    txt = (0.5 * torch.randn(B, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g)).to(torch.bfloat16)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    return x, txt, t
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize("use_rope", [False, True])
+def test_forward_matches_oracle(use_rope):
+    cfg, sd64, lora64, pm = _setup(b_std=0.05)
+    x, txt, t = _inputs(cfg, B=2)
+    rope = ocv.rope_3d_tables(3, 4, 4, 64) if use_rope else None
+    with torch.no_grad():
+        y = pm(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda(),
+               image_rotary_emb=None if rope is None else (rope[0].cuda(), rope[1].cuda())).sample
+        with pm.disable_adapter():
+            y0 = pm(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda(),
+                    image_rotary_emb=None if rope is None else (rope[0].cuda(), rope[1].cuda())).sample
+    rope64 = None if rope is None else (rope[0].double(), rope[1].double())
+    yr = ocv.forward(sd64, cfg, x.double(), txt.double(), t, lora=lora64, lora_scale=2.0, image_rotary_emb=rope64)
+    yr0 = ocv.forward(sd64, cfg, x.double(), txt.double(), t, lora=None, image_rotary_emb=rope64)
+    assert y.shape == x.shape
+    sc = yr.abs().max().item()
+    e, e0 = (y.double().cpu() - yr).abs().max().item(), (y0.double().cpu() - yr0).abs().max().item()
+    # tolerance: bf16 activations (2^-8 relative per rounding) through 2 blocks; stated as 3% of the output range
+    assert e < 0.03 * sc and e0 < 0.03 * sc, (e, e0, sc)
+    assert (y - y0).abs().max().item() > 0   # the adapter does something
+
+
+def test_lora_grads_match_oracle():
+    cfg, sd64, lora64, pm = _setup(b_std=0.05)
+    x, txt, t = _inputs(cfg, B=1, seed=3)
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(x.shape, generator=g).to(torch.bfloat16)
+    y = pm(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
+    y.backward(dy.cuda())
+    lr = {k: v.clone().requires_grad_(True) for k, v in lora64.items()}
+    yr = ocv.forward(sd64, cfg, x.double(), txt.double(), t, lora=lr, lora_scale=2.0)
+    yr.backward(dy.double())
+    own = dict(pm.named_parameters())
+    checked = 0
+    for k, v in lr.items():
+        p = own[k[:-len(".weight")] + ".default.weight"]
+        assert p.grad is not None, k
+        ref = v.grad
+        err = (p.grad.double().cpu() - ref).abs().max().item()
+        assert err < 0.06 * ref.abs().max().item() + 1e-4, (k, err, ref.abs().max().item())
+        checked += 1
+    assert checked == 2 * 4 * cfg.num_layers
+    for n, p in pm.named_parameters():
+        if "lora_" not in n:
+            assert p.grad is None
+
+
+def test_dpo_pair_step_ln2_and_parity():
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    abar = osch.alphas_cumprod()
+    for b_std, check_ln2 in ((0.0, True), (0.05, False)):
+        cfg, sd64, lora64, pm = _setup(b_std=b_std)
+        tr = CogVideoXDPOTrainer({"beta": 1.0}, transformer=pm)
+        g = torch.Generator().manual_seed(21)
+        B = 2
+        xw = (0.7 * torch.randn(B, 16, 3, 8, 8, generator=g)).to(torch.bfloat16)
+        xl = (0.7 * torch.randn(B, 16, 3, 8, 8, generator=g)).to(torch.bfloat16)
+        txt = (0.5 * torch.randn(B, 6, cfg.text_embed_dim, generator=g)).to(torch.bfloat16)
+        t = torch.tensor([417, 80])
+        eps = torch.randn(B, 3, 16, 8, 8, generator=g).to(torch.bfloat16)
+        out = tr._shared_step({"x_win": xw.cuda(), "x_lose": xl.cuda(), "prompt_emb": txt.cuda()}, timesteps=t.cuda(), noise=eps.cuda())
+        if check_ln2:
+            assert abs(out.loss.item() - math.log(2.0)) < 1e-6          # policy == ref bit-for-bit when B = 0
+        ref = ocv.dpo_pair_step(sd64, cfg, lora64, abar, xw.double(), xl.double(), txt.double(), t, eps.double(), beta=1.0)
+        assert abs(out.loss.item() - ref["loss"].item()) < 1e-3, (out.loss.item(), ref["loss"].item())   # north_star tolerance
+        out.loss.backward()
+        grads = [p.grad for n, p in pm.named_parameters() if "lora_B" in n]
+        assert all(g_ is not None for g_ in grads) and any(float(g_.abs().max()) > 0 for g_ in grads)
+
+
+def test_optimizer_step_matches_torch_adamw():
+    from videogpa_amd.optim import FlatAdamW, FlatParams, cosine_schedule_with_warmup
+    g = torch.Generator().manual_seed(2)
+    ps = [torch.nn.Parameter(torch.randn(n, generator=g).cuda()) for n in (1000, 37, 4096)]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    flat = FlatParams(ps)
+    opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=2, total_steps=10)
+    ropt = torch.optim.AdamW(ref, lr=1e-2)
+    for step in range(4):
+        opt.zero_grad()
+        ropt.zero_grad()
+        for p, r in zip(ps, ref):
+            gr = torch.randn(p.shape, generator=g).cuda() * (3.0 if step % 2 else 0.01)
+            p.grad.add_(gr)
+            r.grad = gr.clone()
+        for grp in ropt.param_groups:
+            grp["lr"] = 1e-2 * cosine_schedule_with_warmup(step, 2, 10)
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+        opt.step()
+        for p, r in zip(ps, ref):
+            assert torch.allclose(p, r, rtol=1e-5, atol=1e-6), (step, (p - r).abs().max().item())
+
+
+def test_adapter_roundtrip_and_merge(tmp_path):
+    from videogpa_amd.lora import PeftModel
+    cfg, sd64, lora64, pm = _setup(b_std=0.05)
+    x, txt, t = _inputs(cfg, B=1, seed=5)
+    with torch.no_grad():
+        y = pm(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
+    pm.save_pretrained(str(tmp_path / "final_lora"))
+    cfg2, _, _, pm2 = _setup(b_std=0.0)
+    base = pm2.merge_and_unload()          # B = 0: plain base model
+    loaded = PeftModel.from_pretrained(base, str(tmp_path / "final_lora"))
+    with torch.no_grad():
+        y2 = loaded(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
+        merged = loaded.merge_and_unload()
+        y3 = merged(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
+    assert torch.equal(y, y2)
+    sc = y.float().abs().max().item()
+    assert (y3.float() - y.float()).abs().max().item() < 0.03 * sc     # merged weights are re-rounded to bf16

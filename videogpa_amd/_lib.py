@@ -24,6 +24,9 @@ SIGNATURES = {
     "vgpa_qknorm_rope_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
+    "vgpa_grad_norm_workspace_bytes": (SZ, []),
+    "vgpa_grad_norm": (I32, [P, I64, F32, P, P, SZ, P]),
+    "vgpa_adamw_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P, P]),
     "vgpa_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
 }
 

@@ -76,6 +76,70 @@ def dpo_loss(v_win, v_lose, v_win_ref, v_lose_ref, tgt_win, tgt_lose, beta=1.0, 
     return _DPOLossFn.apply(v_win, v_lose, v_win_ref, v_lose_ref, tgt_win, tgt_lose, beta, label_smoothing, lt, round_diff)
 
 
+class _DPOLossPairedFn(torch.autograd.Function):
+    """Paired layout: v_pair / vref_pair / tgt_pair are [B,2,...] (win, lose); no de-interleaving copies."""
+
+    @staticmethod
+    def forward(ctx, v_pair, vref_pair, tgt_pair, beta, label_smoothing, loss_type, round_diff):
+        dt = v_pair.dtype
+        if dt not in _DT:
+            raise RuntimeError(f"dpo_loss: unsupported dtype {dt}")
+        for t in (v_pair, vref_pair, tgt_pair):
+            _req(t, dt)
+            if t.shape != v_pair.shape or t.shape[1] != 2:
+                raise RuntimeError("dpo_loss_paired: expected [B,2,...] tensors of one shape")
+        B = v_pair.shape[0]
+        N = v_pair.numel() // (2 * B)
+        dev = v_pair.device
+        out5 = torch.empty(5, dtype=torch.float32, device=dev)
+        dlogit = torch.empty(B, dtype=torch.float32, device=dev)
+        errs = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        ws_bytes = _lib.query("vgpa_dpo_loss_workspace_bytes", B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        flags = 1 if round_diff else 0
+        _lib.call("vgpa_dpo_loss_fwd", v_pair[:, 0], v_pair[:, 1], vref_pair[:, 0], vref_pair[:, 1], tgt_pair[:, 0], tgt_pair[:, 1],
+                  B, N, 2 * N, 2 * N, 2 * N, _DT[dt], float(beta), float(label_smoothing), int(loss_type), flags, out5, dlogit, errs, ws,
+                  ws_bytes, _stream())
+        ctx.save_for_backward(v_pair, tgt_pair, dlogit)
+        ctx.meta = (B, N, _DT[dt], float(beta), flags)
+        ctx.mark_non_differentiable(errs)
+        return out5[0], out5[1], out5[2], out5[3], out5[4], errs
+
+    @staticmethod
+    def backward(ctx, g_loss, g_margin, g_wr, g_lr, g_acc, g_errs):
+        v_pair, tgt_pair, dlogit = ctx.saved_tensors
+        B, N, dt, beta, flags = ctx.meta
+        gp = torch.empty_like(v_pair)
+        g = g_loss.to(torch.float32).contiguous()
+        _lib.call("vgpa_dpo_loss_bwd", v_pair[:, 0], v_pair[:, 1], tgt_pair[:, 0], tgt_pair[:, 1], B, N, 2 * N, 2 * N, 2 * N, dt, beta, flags,
+                  dlogit, g, gp[:, 0], gp[:, 1], _stream())
+        return gp, None, None, None, None, None, None
+
+
+def dpo_loss_paired(v_pair, vref_pair, tgt_pair, beta=1.0, label_smoothing=0.0, loss_type="sigmoid", round_diff=False):
+    lt = {"sigmoid": 0, "hinge": 1}.get(loss_type)
+    if lt is None:
+        raise ValueError(f"Unknown loss type: {loss_type}")
+    return _DPOLossPairedFn.apply(v_pair, vref_pair, tgt_pair, beta, label_smoothing, lt, round_diff)
+
+
+# --------------------------------------------------------------------------------------------- optimizer
+def grad_norm(flat_grad, grad_scale=1.0, out=None):
+    _req(flat_grad, torch.float32)
+    out = torch.empty(1, dtype=torch.float32, device=flat_grad.device) if out is None else out
+    ws_bytes = _lib.query("vgpa_grad_norm_workspace_bytes")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=flat_grad.device)
+    _lib.call("vgpa_grad_norm", flat_grad, flat_grad.numel(), float(grad_scale), out, ws, ws_bytes, _stream())
+    return out
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_norm=0.0, total_norm=None):
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        _req(t, torch.float32)
+    _lib.call("vgpa_adamw_step", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2), float(eps),
+              float(weight_decay), int(step), float(grad_scale), float(max_norm), total_norm, _stream())
+
+
 # --------------------------------------------------------------------------------------------- noise / velocity
 def noise_velocity_paired(x_pair, noise, t, sqrt_abar, sqrt_1m_abar):
     """x_pair [B,2,...], noise [B,...] (shared by the pair), t [B] int64 -> (x_noisy_pair, v_target_pair)."""

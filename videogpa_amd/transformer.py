@@ -192,10 +192,6 @@ class Attention(nn.Module):
         D = n.shape[-1]
         W, b = self.fused_qkv()
         qkv = F.linear(n, W, b)
-        for i, m in enumerate((self.to_q, self.to_k, self.to_v)):
-            lora = _parts(m)[2]
-            if lora is not None:
-                _lora_add(qkv[..., i * D:(i + 1) * D], n, lora) if False else None
         # LoRA on q/k/v: one shared down-projection input, three rank-r updates into column slices
         loras = [_parts(m)[2] for m in (self.to_q, self.to_k, self.to_v)]
         if any(l is not None for l in loras):
