@@ -2,6 +2,12 @@
 or a call fails, this raises -- the product path never silently runs on something else."""
 import ctypes
 import os
+
+# torch first: its wheel bundles the HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  Loading our
+# library before torch would pull /opt/rocm's copy in as a SECOND runtime instance and launches on torch's streams
+# would fail; after torch, our NEEDED libamdhip64.so.7 resolves to the instance already loaded.
+import torch  # noqa: F401
+
 from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +33,9 @@ SIGNATURES = {
     "vgpa_grad_norm_workspace_bytes": (SZ, []),
     "vgpa_grad_norm": (I32, [P, I64, F32, P, P, SZ, P]),
     "vgpa_adamw_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P, P]),
+    "vgpa_attn_bwd_delta": (I32, [P, P, P, P, P, I64, I64, I64, I64, P]),
+    "vgpa_attn_bwd_dkv": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
+    "vgpa_attn_bwd_dq": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
 }
 

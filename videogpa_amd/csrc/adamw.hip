@@ -85,9 +85,9 @@ int32_t vgpa_grad_norm(const float* grad, int64_t n, float grad_scale, float* no
     if (!grad || !norm_out || !workspace || n <= 0 || ((uintptr_t)grad & 15)) return VGPA_ERR_INVALID;
     if (ws_bytes < vgpa_grad_norm_workspace_bytes()) return VGPA_ERR_WORKSPACE;
     const int nb = opt_blocks(n);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, stream, grad, n, (double*)workspace);
+    VGPA_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, stream, grad, n, (double*)workspace);
     VGPA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(OPT_THREADS), 0, stream, (const double*)workspace, nb, grad_scale, norm_out);
+    VGPA_LAUNCH(sumsq_finish_kernel, dim3(1), dim3(OPT_THREADS), 0, stream, (const double*)workspace, nb, grad_scale, norm_out);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -101,7 +101,7 @@ int32_t vgpa_adamw_step(float* param, const float* grad, float* exp_avg, float* 
     if (max_norm > 0.f && !total_norm) return VGPA_ERR_INVALID;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(opt_blocks(n)), dim3(OPT_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+    VGPA_LAUNCH(adamw_kernel, dim3(opt_blocks(n)), dim3(OPT_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
                        eps, weight_decay, bc1, bc2_sqrt, grad_scale, max_norm, total_norm);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;

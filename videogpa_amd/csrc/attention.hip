@@ -476,7 +476,7 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
     const int n_qt = (int)((S + WG_ROWS - 1) / WG_ROWS);
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+    VGPA_LAUNCH(attn_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt,
                        scale * 1.4426950408889634f);
     VGPA_CHECK_LAUNCH();
@@ -486,35 +486,71 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
 // workspace: fp32 delta [B,H,S]  (vgpa_attn_bwd_workspace_bytes)
 size_t vgpa_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t S) { return (size_t)B * H * S * sizeof(float); }
 
+static inline bool bwd_common_ok(int64_t B, int64_t H, int64_t S, int64_t head_dim) {
+    return head_dim == HD && B > 0 && H > 0 && S > 0 && S <= (1 << 24) && (int64_t)((S + WG_ROWS - 1) / WG_ROWS) * B * H <= 0x7fffffff;
+}
+
+// step 1 of the backward: delta[b,h,q] = sum_d dO * O
+int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_strides, const int64_t* do_strides, float* delta, int64_t B,
+                            int64_t H, int64_t S, int64_t head_dim, hipStream_t stream) {
+    if (!o || !d_o || !delta || !bwd_common_ok(B, H, S, head_dim) || !stride_ok(o_strides) || !stride_ok(do_strides) || !al16(o) || !al16(d_o))
+        return VGPA_ERR_INVALID;
+    const int64_t total = B * H * S;
+    VGPA_LAUNCH(attn_delta_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o,
+                       mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// step 2: dK, dV (workgroup per 128 keys)
+int32_t vgpa_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dk,
+                          void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                          const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
+                          hipStream_t stream) {
+    if (!q || !k || !v || !d_o || !lse2 || !delta || !dk || !dv || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
+    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(do_strides) || !stride_ok(dk_strides) ||
+        !stride_ok(dv_strides) || !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv))
+        return VGPA_ERR_INVALID;
+    const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
+    VGPA_LAUNCH(attn_bwd_dkv_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides),
+                       mk(do_strides), mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, scale * 1.4426950408889634f, scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// step 3: dQ (workgroup per 128 queries)
+int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dq,
+                         const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                         const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, hipStream_t stream) {
+    if (!q || !k || !v || !d_o || !lse2 || !delta || !dq || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
+    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(do_strides) || !stride_ok(dq_strides) ||
+        !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dq))
+        return VGPA_ERR_INVALID;
+    const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
+    VGPA_LAUNCH(attn_bwd_dq_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides),
+                       mk(do_strides), mk(dq_strides), (int)S, (int)H, n_t, scale * 1.4426950408889634f, scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// the whole backward (delta -> dK/dV -> dQ) with a caller-provided workspace for delta
 int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
                       void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
                       const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides, int64_t B,
                       int64_t H, int64_t S, int64_t head_dim, float scale, void* workspace, size_t ws_bytes, hipStream_t stream) {
-    if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || !workspace || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24))
-        return VGPA_ERR_INVALID;
-    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(o_strides) || !stride_ok(do_strides) ||
-        !stride_ok(dq_strides) || !stride_ok(dk_strides) || !stride_ok(dv_strides))
-        return VGPA_ERR_INVALID;
-    if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || !al16(dq) || !al16(dk) || !al16(dv)) return VGPA_ERR_INVALID;
+    if (!workspace) return VGPA_ERR_INVALID;
+    if (!bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
     if (ws_bytes < vgpa_attn_bwd_workspace_bytes(B, H, S)) return VGPA_ERR_WORKSPACE;
     float* delta = (float*)workspace;
-    const int64_t total = B * H * S;
-    const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
-    const int64_t nblk = (int64_t)n_t * B * H;
-    if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
-    const float c = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o,
-                       mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta);
-    VGPA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
-                       mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, c, scale);
-    VGPA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
-                       mk(dq_strides), (int)S, (int)H, n_t, c, scale);
-    VGPA_CHECK_LAUNCH();
-    return VGPA_OK;
+    int32_t rc = vgpa_attn_bwd_delta(o, d_o, o_strides, do_strides, delta, B, H, S, head_dim, stream);
+    if (rc) return rc;
+    rc = vgpa_attn_bwd_dkv(q, k, v, d_o, lse2, delta, dk, dv, q_strides, k_strides, v_strides, do_strides, dk_strides, dv_strides, B, H, S,
+                           head_dim, scale, stream);
+    if (rc) return rc;
+    return vgpa_attn_bwd_dq(q, k, v, d_o, lse2, delta, dq, q_strides, k_strides, v_strides, do_strides, dq_strides, B, H, S, head_dim, scale,
+                            stream);
 }
 
 }  // extern "C"

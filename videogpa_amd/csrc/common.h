@@ -11,6 +11,13 @@
 #define VGPA_DTYPE_F32 0
 #define VGPA_DTYPE_BF16 1
 
+// clear any stale (unrelated) runtime error first, so VGPA_CHECK_LAUNCH reports only this launch
+#define VGPA_LAUNCH(...)                 \
+    do {                                 \
+        (void)hipGetLastError();         \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 #define VGPA_CHECK_LAUNCH()                               \
     do {                                                  \
         if (hipGetLastError() != hipSuccess) return VGPA_ERR_LAUNCH; \

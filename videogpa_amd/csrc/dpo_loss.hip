@@ -167,13 +167,13 @@ int32_t vgpa_dpo_loss_fwd(const void* v_win, const void* v_lose, const void* v_w
     dim3 grid(nblk, (unsigned)B);
     double* partial = (double*)workspace;
     const bool rd = (flags & 1) != 0;
-#define LAUNCH(DT, RD) hipLaunchKernelGGL((dpo_err_partial_kernel<DT, RD>), grid, dim3(LOSS_THREADS), 0, stream, v_win, v_lose, v_win_ref, \
+#define LAUNCH(DT, RD) VGPA_LAUNCH((dpo_err_partial_kernel<DT, RD>), grid, dim3(LOSS_THREADS), 0, stream, v_win, v_lose, v_win_ref, \
                                           v_lose_ref, tgt_win, tgt_lose, N, stride_pred, stride_ref, stride_tgt, vec_ok, partial)
     if (dtype == VGPA_DTYPE_BF16) { if (rd) LAUNCH(VGPA_DTYPE_BF16, true); else LAUNCH(VGPA_DTYPE_BF16, false); }
     else { if (rd) LAUNCH(VGPA_DTYPE_F32, true); else LAUNCH(VGPA_DTYPE_F32, false); }
 #undef LAUNCH
     VGPA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dpo_finish_kernel, dim3(1), dim3(LOSS_THREADS), 0, stream, partial, nblk, (int)B, 1.0 / (double)N, beta,
+    VGPA_LAUNCH(dpo_finish_kernel, dim3(1), dim3(LOSS_THREADS), 0, stream, partial, nblk, (int)B, 1.0 / (double)N, beta,
                        label_smoothing, loss_type, out5, dlogit, errs);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
@@ -189,7 +189,7 @@ int32_t vgpa_dpo_loss_bwd(const void* v_win, const void* v_lose, const void* tgt
     dim3 grid(loss_blocks(N), (unsigned)B);
     const float two_over_n = (float)(2.0 / (double)N);
     const bool rd = (flags & 1) != 0;
-#define LAUNCH(DT, RD) hipLaunchKernelGGL((dpo_bwd_kernel<DT, RD>), grid, dim3(LOSS_THREADS), 0, stream, v_win, v_lose, tgt_win, tgt_lose, N, \
+#define LAUNCH(DT, RD) VGPA_LAUNCH((dpo_bwd_kernel<DT, RD>), grid, dim3(LOSS_THREADS), 0, stream, v_win, v_lose, tgt_win, tgt_lose, N, \
                                           stride_pred, stride_tgt, stride_grad, vec_ok, dlogit, grad_out, beta, two_over_n, grad_win, grad_lose)
     if (dtype == VGPA_DTYPE_BF16) { if (rd) LAUNCH(VGPA_DTYPE_BF16, true); else LAUNCH(VGPA_DTYPE_BF16, false); }
     else { if (rd) LAUNCH(VGPA_DTYPE_F32, true); else LAUNCH(VGPA_DTYPE_F32, false); }

@@ -58,10 +58,10 @@ extern "C" int32_t vgpa_noise_velocity_paired(const void* x_pair, const void* no
     if (nb > 2048) nb = 2048;
     dim3 grid((unsigned)nb, (unsigned)B);
     if (dtype == VGPA_DTYPE_BF16)
-        hipLaunchKernelGGL((noise_velocity_kernel<VGPA_DTYPE_BF16>), grid, dim3(256), 0, stream, x_pair, noise, t, sqrt_abar, sqrt_1m_abar, N,
+        VGPA_LAUNCH((noise_velocity_kernel<VGPA_DTYPE_BF16>), grid, dim3(256), 0, stream, x_pair, noise, t, sqrt_abar, sqrt_1m_abar, N,
                            num_train_timesteps, x_noisy_pair, v_target_pair);
     else if (dtype == VGPA_DTYPE_F32)
-        hipLaunchKernelGGL((noise_velocity_kernel<VGPA_DTYPE_F32>), grid, dim3(256), 0, stream, x_pair, noise, t, sqrt_abar, sqrt_1m_abar, N,
+        VGPA_LAUNCH((noise_velocity_kernel<VGPA_DTYPE_F32>), grid, dim3(256), 0, stream, x_pair, noise, t, sqrt_abar, sqrt_1m_abar, N,
                            num_train_timesteps, x_noisy_pair, v_target_pair);
     else
         return VGPA_ERR_INVALID;

@@ -216,7 +216,7 @@ int32_t vgpa_ln_modulate_fwd(const void* x, const float* ln_w, const float* ln_b
     if ((mean == nullptr) != (rstd == nullptr)) return VGPA_ERR_INVALID;
     const int64_t rows = B * S;
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    DISPATCH_NV(D, hipLaunchKernelGGL((ln_modulate_fwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)x, ln_w, ln_b,
+    DISPATCH_NV(D, VGPA_LAUNCH((ln_modulate_fwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)x, ln_w, ln_b,
                                       shift_v, scale1p_v, shift_t, scale1p_t, mod_stride, (int)text_len, (int)S, (int)D, rows, eps,
                                       (bf16_t*)out, mean, rstd));
     VGPA_CHECK_LAUNCH();
@@ -232,7 +232,7 @@ int32_t vgpa_ln_modulate_bwd(const void* dy, const void* x, const float* mean, c
     if (scale1p_v && text_len > 0 && !scale1p_t) return VGPA_ERR_INVALID;
     const int64_t rows = B * S;
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    DISPATCH_NV(D, hipLaunchKernelGGL((ln_modulate_bwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)dy,
+    DISPATCH_NV(D, VGPA_LAUNCH((ln_modulate_bwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)dy,
                                       (const bf16_t*)x, mean, rstd, ln_w, scale1p_v, scale1p_t, mod_stride, (int)text_len, (int)S, (int)D, rows,
                                       (const bf16_t*)dres, (bf16_t*)dx));
     VGPA_CHECK_LAUNCH();
@@ -245,7 +245,7 @@ int32_t vgpa_gate_residual(const void* x, const void* y, const float* gate_v, co
     if (!y || !gate_v || !out) return VGPA_ERR_INVALID;
     if (B <= 0 || S <= 0 || D <= 0 || D % 8 != 0 || text_len < 0 || text_len > S || (text_len > 0 && !gate_t)) return VGPA_ERR_INVALID;
     const int64_t total8 = B * S * D / 8;
-    hipLaunchKernelGGL(gate_residual_kernel, dim3(ew_grid(total8)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)y, gate_v, gate_t,
+    VGPA_LAUNCH(gate_residual_kernel, dim3(ew_grid(total8)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)y, gate_v, gate_t,
                        mod_stride, (int)text_len, (int)S, (int)D, total8, (bf16_t*)out);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
@@ -253,14 +253,14 @@ int32_t vgpa_gate_residual(const void* x, const void* y, const float* gate_v, co
 
 int32_t vgpa_gelu_tanh_fwd(const void* u, int64_t n, void* out, hipStream_t stream) {
     if (!u || !out || n <= 0 || n % 8 != 0) return VGPA_ERR_INVALID;
-    hipLaunchKernelGGL(gelu_tanh_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16_t*)u, n / 8, (bf16_t*)out);
+    VGPA_LAUNCH(gelu_tanh_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16_t*)u, n / 8, (bf16_t*)out);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
 
 int32_t vgpa_gelu_tanh_bwd(const void* u, const void* dy, int64_t n, void* du, hipStream_t stream) {
     if (!u || !dy || !du || n <= 0 || n % 8 != 0) return VGPA_ERR_INVALID;
-    hipLaunchKernelGGL(gelu_tanh_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16_t*)u, (const bf16_t*)dy, n / 8, (bf16_t*)du);
+    VGPA_LAUNCH(gelu_tanh_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16_t*)u, (const bf16_t*)dy, n / 8, (bf16_t*)du);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

@@ -137,7 +137,7 @@ int32_t vgpa_qknorm_rope_fwd(const void* q_in, const void* k_in, void* q_out, vo
     if (!qs_ok(qin_strides) || !qs_ok(kin_strides) || !qs_ok(qout_strides) || !qs_ok(kout_strides)) return VGPA_ERR_INVALID;
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
     const int64_t threads = 2 * B * S * H * 8;
-    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)q_in,
+    VGPA_LAUNCH(qknorm_rope_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)q_in,
                        (const bf16_t*)k_in, (bf16_t*)q_out, (bf16_t*)k_out, qmk(qin_strides), qmk(kin_strides), qmk(qout_strides),
                        qmk(kout_strides), wq, bq, wk, bk, rope_cos, rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps);
     VGPA_CHECK_LAUNCH();
@@ -155,7 +155,7 @@ int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void*
         return VGPA_ERR_INVALID;
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
     const int64_t threads = 2 * B * S * H * 8;
-    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dq_out,
+    VGPA_LAUNCH(qknorm_rope_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dq_out,
                        (const bf16_t*)dk_out, (const bf16_t*)q_in, (const bf16_t*)k_in, (bf16_t*)dq_in, (bf16_t*)dk_in, qmk(dqout_strides),
                        qmk(dkout_strides), qmk(qin_strides), qmk(kin_strides), qmk(dqin_strides), qmk(dkin_strides), wq, wk, rope_cos,
                        rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps);

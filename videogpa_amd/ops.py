@@ -251,6 +251,38 @@ def _bhs_strides(t):
     return _i64x3(t.stride(0), t.stride(1), t.stride(2))
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual kernel launches on the launch stream (bench.py's live roofline leg).
+    Disabled (None) by default: zero overhead in the product path."""
+
+    def __init__(self):
+        self.records = {}
+
+    def run(self, name, work, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.setdefault(name, []).append((a, b, work))
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "work_per_launch": recs[0][2]}
+        return out
+
+
+TIMER = None   # set to a KernelTimer() to time launches
+
+
+def _timed(name, work, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.run(name, work, fn)
+
+
 def attention_fwd_raw(q, k, v, scale=None):
     """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32."""
     B, H, S, Dh = q.shape
@@ -258,19 +290,27 @@ def attention_fwd_raw(q, k, v, scale=None):
     o = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=q.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
-    _lib.call("vgpa_attn_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
-              float(scale), _stream())
+    _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
+        "vgpa_attn_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
+        float(scale), _stream()))
     return o, lse
 
 
 def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None):
-    """All [B,H,S,64] bf16 views; writes dq, dk, dv in place."""
+    """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.
+    Algorithmic FLOPs (backward = 2 x forward): dK/dV kernel carries dV, dP, dK = 6 S^2 d; dQ kernel 2 S^2 d
+    (the S = QK^T recomputes in both kernels and the second dP are overhead, not counted)."""
     B, H, S, Dh = q.shape
     scale = Dh ** -0.5 if scale is None else scale
-    ws_bytes = _lib.query("vgpa_attn_bwd_workspace_bytes", B, H, S)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-    _lib.call("vgpa_attn_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o),
-              _bhs_strides(do), _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), ws, ws_bytes, _stream())
+    delta = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
+    st = _stream()
+    _lib.call("vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st)
+    _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
+        "vgpa_attn_bwd_dkv", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+        _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), st))
+    _timed("attn_bwd_dq_kernel", 2.0 * S * S * Dh * B * H, lambda: _lib.call(
+        "vgpa_attn_bwd_dq", q, k, v, do, lse, delta, dq, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+        _bhs_strides(dq), B, H, S, Dh, float(scale), st))
 
 
 class _QKNormAttentionFn(torch.autograd.Function):
