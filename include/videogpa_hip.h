@@ -1,0 +1,120 @@
+/* videogpa_hip.h -- C ABI of libvgpa_hip.so: the MI355X (gfx950) kernels behind the VideoGPA DPO hot path.
+ *
+ * Boundary contract: plain pointers and sizes, no torch types; the CALLER owns every buffer
+ * (outputs and workspaces); every call is asynchronous on `stream`, re-entrant, holds no global state; returns
+ * 0 on success or a negative VGPA_ERR_* code and never throws.  One process per GPU.
+ *
+ * The reference (Hongyang-Du/VideoGPA) is pure Python and reaches these computations through PyTorch / diffusers /
+ * PEFT objects; each entry point below cites the reference interface (file:line) it stands behind.  The Python
+ * host side that mirrors those object APIs is `videogpa_amd/` (ctypes binding: videogpa_amd/_lib.py; the binding a
+ * reference maintainer would add is shown in INTEGRATION.md).
+ *
+ * dtype codes: 0 = float32, 1 = bfloat16.  "BHS strides" = int64[3] element strides {batch, head, token} of a
+ * [B, H, S, 64] bf16 view whose last dimension is contiguous (multiples of 8; base pointers 16-byte aligned).
+ */
+#ifndef VIDEOGPA_HIP_H
+#define VIDEOGPA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vgpa_stream_t; /* == hipStream_t */
+
+#define VGPA_OK 0
+#define VGPA_ERR_INVALID (-1)
+#define VGPA_ERR_LAUNCH (-2)
+#define VGPA_ERR_WORKSPACE (-3)
+
+/* ---- Diffusion-DPO loss: train/loss.py:53-121 (DPOLoss.forward) + its autograd backward -------------------------
+ * Each input is [B, N] with its own per-sample stride (paired layout [B,2,N]: win = base, lose = base + N, stride 2N).
+ * out5 = {loss, reward_margin, winner_reward, loser_reward, accuracy}; dlogit[B] = dloss/dlogit_b (kept for bwd);
+ * errs[B,4] = {e_win, e_lose, e_win_ref, e_lose_ref} (may be NULL).  loss_type 0 = sigmoid (label_smoothing
+ * honoured), 1 = hinge.  flags bit0: round (v - tgt) to bf16 before squaring (what bf16 autocast does upstream). */
+size_t vgpa_dpo_loss_workspace_bytes(int64_t B);
+int32_t vgpa_dpo_loss_fwd(const void* v_win, const void* v_lose, const void* v_win_ref, const void* v_lose_ref,
+                          const void* tgt_win, const void* tgt_lose, int64_t B, int64_t N, int64_t stride_pred,
+                          int64_t stride_ref, int64_t stride_tgt, int32_t dtype, float beta, float label_smoothing,
+                          int32_t loss_type, int32_t flags, float* out5, float* dlogit, float* errs, void* workspace,
+                          size_t ws_bytes, vgpa_stream_t stream);
+int32_t vgpa_dpo_loss_bwd(const void* v_win, const void* v_lose, const void* tgt_win, const void* tgt_lose, int64_t B,
+                          int64_t N, int64_t stride_pred, int64_t stride_tgt, int64_t stride_grad, int32_t dtype, float beta,
+                          int32_t flags, const float* dlogit, const float* grad_out, void* grad_win, void* grad_lose,
+                          vgpa_stream_t stream);
+
+/* ---- noising + v-targets: scheduler.add_noise / get_velocity, train/CogVideoX-5B/03_train.py:129-130,154-155 ------
+ * x_pair [B,2,N], noise [B,N] shared by the pair, t [B]; tables = sqrt(abar), sqrt(1-abar) (fp32 [T]). */
+int32_t vgpa_noise_velocity_paired(const void* x_pair, const void* noise, const int64_t* t, const float* sqrt_abar,
+                                   const float* sqrt_1m_abar, int64_t B, int64_t N, int32_t num_train_timesteps,
+                                   int32_t dtype, void* x_noisy_pair, void* v_target_pair, vgpa_stream_t stream);
+
+/* ---- AdaLN-Zero pieces of CogVideoXBlock (diffusers CogVideoXLayerNormZero / AdaLayerNorm / LayerNorm), reached
+ * from train/CogVideoX-5B/03_train.py:134-151.  x, out, dy, dx: bf16 [B,S,D], text tokens first (rows < text_len).
+ * Per-range fp32 vectors [B,D] with a common batch stride; all four modulation pointers NULL = plain LayerNorm. */
+int32_t vgpa_ln_modulate_fwd(const void* x, const float* ln_w, const float* ln_b, const float* shift_v,
+                             const float* scale1p_v, const float* shift_t, const float* scale1p_t, int64_t mod_stride,
+                             int64_t B, int64_t S, int64_t D, int64_t text_len, float eps, void* out, float* mean,
+                             float* rstd, vgpa_stream_t stream);
+int32_t vgpa_ln_modulate_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* ln_w,
+                             const float* scale1p_v, const float* scale1p_t, int64_t mod_stride, int64_t B, int64_t S,
+                             int64_t D, int64_t text_len, const void* dres, void* dx, vgpa_stream_t stream);
+/* out = x + gate[range] * y (x NULL: out = gate * y, the backward of the y branch) */
+int32_t vgpa_gate_residual(const void* x, const void* y, const float* gate_v, const float* gate_t, int64_t mod_stride,
+                           int64_t B, int64_t S, int64_t D, int64_t text_len, void* out, vgpa_stream_t stream);
+/* FeedForward activation "gelu-approximate" (tanh), bf16, n elements */
+int32_t vgpa_gelu_tanh_fwd(const void* u, int64_t n, void* out, vgpa_stream_t stream);
+int32_t vgpa_gelu_tanh_bwd(const void* u, const void* dy, int64_t n, void* du, vgpa_stream_t stream);
+
+/* ---- QK-norm (LayerNorm over head_dim 64) + 3D RoPE (attn.norm_q/norm_k, apply_rotary_emb in
+ * CogVideoXAttnProcessor2_0; RoPE only when image_rotary_emb is given: generate/CogVideoX-5B.py:72-77).
+ * rope_cos/rope_sin: fp32 [S - text_len, 64] or NULL. */
+int32_t vgpa_qknorm_rope_fwd(const void* q_in, const void* k_in, void* q_out, void* k_out, const int64_t* qin_strides,
+                             const int64_t* kin_strides, const int64_t* qout_strides, const int64_t* kout_strides,
+                             const float* wq, const float* bq, const float* wk, const float* bk, const float* rope_cos,
+                             const float* rope_sin, int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim,
+                             float eps, vgpa_stream_t stream);
+int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void* q_in, const void* k_in, void* dq_in,
+                             void* dk_in, const int64_t* dqout_strides, const int64_t* dkout_strides,
+                             const int64_t* qin_strides, const int64_t* kin_strides, const int64_t* dqin_strides,
+                             const int64_t* dkin_strides, const float* wq, const float* wk, const float* rope_cos,
+                             const float* rope_sin, int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim,
+                             float eps, vgpa_stream_t stream);
+
+/* ---- 3D full attention, non-causal, head_dim 64 (F.scaled_dot_product_attention in the same processor) ----------
+ * lse2 = log2 sum_k exp2(scale*log2(e) * q.k), fp32 [B,H,S]; delta = rowsum(dO * O), fp32 [B,H,S]. */
+int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
+                      const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H,
+                      int64_t S, int64_t head_dim, float scale, vgpa_stream_t stream);
+size_t vgpa_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t S);
+int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_strides, const int64_t* do_strides, float* delta,
+                            int64_t B, int64_t H, int64_t S, int64_t head_dim, vgpa_stream_t stream);
+int32_t vgpa_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
+                          void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                          const int64_t* do_strides, const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H,
+                          int64_t S, int64_t head_dim, float scale, vgpa_stream_t stream);
+int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
+                         void* dq, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                         const int64_t* do_strides, const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,
+                         float scale, vgpa_stream_t stream);
+int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq,
+                      void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                      const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                      const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, void* workspace,
+                      size_t ws_bytes, vgpa_stream_t stream);
+
+/* ---- optimizer on one flat fp32 buffer of all LoRA parameters: gradient_clip_val=1.0 + torch.optim.AdamW,
+ * train/CogVideoX-5B/03_train.py:208-213,266.  norm_out[0] = grad_scale * ||grad||_2. */
+size_t vgpa_grad_norm_workspace_bytes(void);
+int32_t vgpa_grad_norm(const float* grad, int64_t n, float grad_scale, float* norm_out, void* workspace, size_t ws_bytes,
+                       vgpa_stream_t stream);
+int32_t vgpa_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int64_t step, float grad_scale, float max_norm,
+                        const float* total_norm, vgpa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDEOGPA_HIP_H */

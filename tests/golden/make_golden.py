@@ -181,7 +181,14 @@ def golden_scorer():
     print("scorer.pt written")
 
 
+def golden_adapter_config_keys():
+    """Key set PEFT wrote for the released adapters (checkpoints/VideoGPA-T2V-lora/adapter_config.json)."""
+    cfg = json.load(open(os.path.join(REF, "checkpoints/VideoGPA-T2V-lora/adapter_config.json")))
+    json.dump(sorted(cfg.keys()), open(os.path.join(HERE, "adapter_config_keys.json"), "w"))
+
+
 if __name__ == "__main__":
+    golden_adapter_config_keys()
     golden_dpo_loss()
     golden_dataset()
     golden_scorer()

@@ -1,0 +1,49 @@
+"""The C-ABI library loads on CPU and exports exactly what include/videogpa_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "videogpa_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(vgpa_[a-z0-9_]+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol():
+    from videogpa_amd import _lib, build
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in videogpa_hip.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (vgpa_[a-z0-9_]+)", out))
+    assert exported == declared, f"undeclared exports: {exported - declared}; missing: {declared - exported}"
+    assert set(_lib.SIGNATURES) == declared, f"ctypes table drift: {set(_lib.SIGNATURES) ^ declared}"
+
+
+def test_pure_host_queries():
+    from videogpa_amd import _lib
+    assert _lib.query("vgpa_dpo_loss_workspace_bytes", 3) == 3 * 256 * 4 * 8
+    assert _lib.query("vgpa_attn_bwd_workspace_bytes", 2, 48, 17776) == 2 * 48 * 17776 * 4
+    assert _lib.query("vgpa_grad_norm_workspace_bytes") == 1024 * 8
+
+
+def test_ops_fail_loudly_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from videogpa_amd import ops
+    from videogpa_amd.transformer import CogVideoXTransformer3DModel
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gelu_tanh(torch.zeros(8, dtype=torch.bfloat16))
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, num_layers=1, time_embed_dim=32, text_embed_dim=48,
+                                    use_rotary_positional_embeddings=True).to(torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 16, 4, 4, dtype=torch.bfloat16), torch.zeros(1, 2, 48, dtype=torch.bfloat16), torch.tensor([1]))

@@ -1,0 +1,145 @@
+"""Host-side logic of the product (runs on CPU): dataset / collate vs reference goldens, LR schedule, adapter file
+format, sharding, scheduler table."""
+import json
+import os
+
+import torch
+
+from videogpa_amd import dataset as vds
+from videogpa_amd.lora import LoraConfig, PeftModel, get_peft_model
+from videogpa_amd.optim import cosine_schedule_with_warmup
+from videogpa_amd.scheduler import CogVideoXDPMScheduler
+from videogpa_amd.transformer import CogVideoXTransformer3DModel
+
+
+def _materialise(gold, d):
+    for name in gold["existing_files"]:
+        p = os.path.join(d, name)
+        if name.startswith("lat_"):
+            gi, vi = name[4:-3].split("_")
+            torch.save(torch.full((16, 2, 4, 4), float(int(gi) * 10 + int(vi))).to(torch.bfloat16), p)
+        elif name.startswith("cond_"):
+            gi, vi = name[5:-3].split("_")
+            torch.save({"encoder_hidden_states": torch.full((6, 8), float(int(gi) * 10 + int(vi))).to(torch.bfloat16)}, p)
+        else:
+            json.dump(gold["meta"], open(p, "w"))
+
+
+def test_dataset_matches_reference(golden_dir, tmp_path):
+    gold = json.load(open(os.path.join(golden_dir, "dataset_pairs.json")))
+    _materialise(gold, tmp_path)
+    for r in gold["results"]:
+        ds = vds.DPODataset(str(tmp_path), os.path.join(tmp_path, "meta_data.json"), metric_name="consistency_score", **r["kwargs"])
+        got = [{"group_id": p["group_id"], "winner": p["winner"]["video_path"], "loser": p["loser"]["video_path"], "gap": p["metric_gap"]}
+               for p in ds.preference_pairs]
+        assert got == r["pairs"]
+        if r["batch"] is not None:
+            b = vds.collate_fn([ds[0], ds[1]])
+            g = r["batch"]
+            assert sorted(b.keys()) == g["keys"]
+            assert list(b["x_win"].shape) == g["x_win_shape"] and str(b["x_win"].dtype) == g["x_win_dtype"]
+            assert [float(b["x_win"][i].flatten()[0]) for i in range(2)] == g["x_win_vals"]
+            assert [float(b["x_lose"][i].flatten()[0]) for i in range(2)] == g["x_lose_vals"]
+            assert [float(b["prompt_emb"][i].flatten()[0]) for i in range(2)] == g["prompt_emb_vals"]   # winner's condition
+            assert b["prompt"] == g["prompt"] and b["m_win"].tolist() == g["m_win"] and b["m_lose"].tolist() == g["m_lose"]
+            p = vds.collate_paired([ds[0], ds[1]])
+            assert p["x_pair"].shape == (2, 2, 2, 16, 4, 4)
+            assert torch.equal(p["x_pair"][:, 0], b["x_win"].permute(0, 2, 1, 3, 4))
+            assert torch.equal(p["x_pair"][:, 1], b["x_lose"].permute(0, 2, 1, 3, 4))
+
+
+def test_missing_groups_key_raises(tmp_path):
+    import pytest
+    p = tmp_path / "m.json"
+    p.write_text("{}")
+    with pytest.raises(ValueError, match="missing 'groups'"):
+        vds.DPODataset(str(tmp_path), str(p))
+
+
+def test_lr_schedule_matches_transformers():
+    from transformers import get_cosine_schedule_with_warmup
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=5e-6)
+    sch = get_cosine_schedule_with_warmup(opt, num_warmup_steps=500, num_training_steps=10000)
+    for step in range(0, 10001):
+        if step in (0, 1, 250, 499, 500, 501, 5250, 9999, 10000):
+            assert abs(opt.param_groups[0]["lr"] - 5e-6 * cosine_schedule_with_warmup(step, 500, 10000)) < 1e-18
+        opt.step()
+        sch.step()
+    assert cosine_schedule_with_warmup(0, 500, 10000) == 0.0
+    assert abs(cosine_schedule_with_warmup(250, 500, 10000) - 0.5) < 1e-12
+    assert abs(cosine_schedule_with_warmup(5250, 500, 10000) - 0.5) < 1e-12
+
+
+def test_shard_indices_partition():
+    n, w = 23, 4
+    parts = [vds.shard_indices(n, r, w, epoch=3) for r in range(w)]
+    assert len({len(p) for p in parts}) == 1 and len(parts[0]) == 6
+    assert set(sum(parts, [])) == set(range(n))
+    assert parts == [vds.shard_indices(n, r, w, epoch=3) for r in range(w)]      # deterministic
+    assert parts != [vds.shard_indices(n, r, w, epoch=4) for r in range(w)]
+    dl = [vds.shard_indices(n, r, w, drop_last=True) for r in range(w)]
+    assert sorted(sum(dl, [])) == sorted(set(sum(dl, []))) and len(sum(dl, [])) == 20
+
+
+def _tiny():
+    return CogVideoXTransformer3DModel(num_attention_heads=2, num_layers=2, time_embed_dim=32, text_embed_dim=48,
+                                       use_rotary_positional_embeddings=True)
+
+
+def test_state_dict_contract():
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, num_layers=1, time_embed_dim=32, text_embed_dim=48,
+                                    use_rotary_positional_embeddings=True)
+    sd = m.state_dict()
+    D = 128
+    expect = {
+        "patch_embed.proj.weight": (D, 16, 2, 2), "patch_embed.text_proj.weight": (D, 48), "time_embedding.linear_1.weight": (32, D),
+        "time_embedding.linear_2.weight": (32, 32), "transformer_blocks.0.norm1.linear.weight": (6 * D, 32),
+        "transformer_blocks.0.norm1.norm.weight": (D,), "transformer_blocks.0.attn1.to_q.weight": (D, D),
+        "transformer_blocks.0.attn1.norm_q.weight": (64,), "transformer_blocks.0.attn1.norm_k.bias": (64,),
+        "transformer_blocks.0.attn1.to_out.0.weight": (D, D), "transformer_blocks.0.norm2.linear.bias": (6 * D,),
+        "transformer_blocks.0.ff.net.0.proj.weight": (4 * D, D), "transformer_blocks.0.ff.net.2.weight": (D, 4 * D),
+        "norm_final.weight": (D,), "norm_out.linear.weight": (2 * D, 32), "norm_out.norm.bias": (D,), "proj_out.weight": (64, D),
+    }
+    for k, shp in expect.items():
+        assert tuple(sd[k].shape) == shp, k
+    m.config.use_dynamic_positional_embedding = True   # attribute assignment, as train/CogVideoX1.5-5B/03_train.py:95 does
+    assert m.config["use_dynamic_positional_embedding"] is True
+
+
+def test_adapter_file_format_and_roundtrip(tmp_path):
+    from safetensors.torch import load_file
+    pm = get_peft_model(_tiny(), LoraConfig(r=4, lora_alpha=8, lora_dropout=0.0, target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    trainable = [n for n, p in pm.named_parameters() if p.requires_grad]
+    assert len(trainable) == 2 * 4 * 2 and all("lora_" in n for n in trainable)
+    with torch.no_grad():
+        for n, p in pm.named_parameters():
+            if "lora_B" in n:
+                p.normal_()
+    pm.save_pretrained(str(tmp_path / "final_lora"))
+    cfg = json.load(open(tmp_path / "final_lora" / "adapter_config.json"))
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "adapter_config_keys.json")))
+    assert set(ref) <= set(cfg), set(ref) - set(cfg)            # every key PEFT wrote for the released adapters
+    assert cfg["peft_type"] == "LORA" and cfg["r"] == 4 and cfg["lora_alpha"] == 8 and sorted(cfg["target_modules"]) == ["to_k", "to_out.0", "to_q", "to_v"]
+    sd = load_file(str(tmp_path / "final_lora" / "adapter_model.safetensors"))
+    assert "base_model.model.transformer_blocks.1.attn1.to_out.0.lora_B.weight" in sd
+    assert tuple(sd["base_model.model.transformer_blocks.0.attn1.to_q.lora_A.weight"].shape) == (4, 128)
+    assert tuple(sd["base_model.model.transformer_blocks.0.attn1.to_q.lora_B.weight"].shape) == (128, 4)
+    pm2 = PeftModel.from_pretrained(_tiny(), str(tmp_path / "final_lora"), adapter_name="other")
+    for k, v in sd.items():
+        assert torch.equal(pm2.state_dict()[k[:-7] + ".other.weight"], v)
+    layer = pm2.lora_layers()[0]
+    assert layer.scaling["other"] == 2.0 and layer.r["other"] == 4 and layer.lora_alpha["other"] == 8
+    layer.scaling["other"] = 0.2                                    # generate/CogVideoX1.5-5B.py:32-35 override
+    # merge: W' = W + scaling * B A
+    w0 = layer.base_layer.weight.detach().clone()
+    delta = layer.delta_weight("other")
+    base = pm2.merge_and_unload()
+    assert not any(hasattr(m, "base_layer") for m in base.modules())
+    assert torch.allclose(base.transformer_blocks[0].attn1.to_q.weight, w0 + delta, atol=1e-6)
+
+
+def test_scheduler_table_and_config():
+    s = CogVideoXDPMScheduler()
+    assert s.config.num_train_timesteps == 1000
+    a = s.alphas_cumprod
+    assert float(a[-1]) == 0.0 and abs(float(a[0]) - (1 - 0.00085)) < 1e-9 and bool((a[1:] <= a[:-1]).all())

@@ -8,6 +8,8 @@
 // bit-identical to the reference expression evaluated by PyTorch in that dtype.
 #include "common.h"
 
+#pragma clang fp contract(off)  // separate mul / add roundings, exactly like torch elementwise ops
+
 template <int DT>
 __device__ __forceinline__ float rnd(float v) { return DT == VGPA_DTYPE_BF16 ? round_bf16(v) : v; }
 

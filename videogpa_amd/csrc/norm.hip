@@ -10,113 +10,156 @@
 // two-pass mean/variance, wave-level reductions only (no LDS, no barriers).
 #include "common.h"
 
-#define ROWS_PER_BLOCK 4
+#define WAVES_PER_BLOCK 4
+#define ROWS_PER_WAVE 4
+#define ROWS_PER_BLOCK (WAVES_PER_BLOCK * ROWS_PER_WAVE)
+
+// A wave walks ROWS_PER_WAVE consecutive token rows and keeps the per-column affine of its lanes in registers:
+//   y = xhat * alpha + beta,  alpha = w * (1+scale),  beta = b * (1+scale) + shift
+// so the four fp32 parameter vectors are fetched once per wave (and again only if the rows cross the text/video
+// boundary or a batch boundary), not once per element.
+template <int NV>
+__device__ __forceinline__ void load_affine(const float* __restrict__ w, const float* __restrict__ bias, const float* sh,
+                                            const float* sc, int D, int lane, float (&alpha)[NV][8], float (&beta)[NV][8]) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + i0 + 4 * h);
+                const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + i0 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 sv = make_float4(1.f, 1.f, 1.f, 1.f), hv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sc) sv = *reinterpret_cast<const float4*>(sc + i0 + 4 * h);
+                if (sh) hv = *reinterpret_cast<const float4*>(sh + i0 + 4 * h);
+                alpha[c][4 * h + 0] = wv.x * sv.x; alpha[c][4 * h + 1] = wv.y * sv.y;
+                alpha[c][4 * h + 2] = wv.z * sv.z; alpha[c][4 * h + 3] = wv.w * sv.w;
+                beta[c][4 * h + 0] = bv.x * sv.x + hv.x; beta[c][4 * h + 1] = bv.y * sv.y + hv.y;
+                beta[c][4 * h + 2] = bv.z * sv.z + hv.z; beta[c][4 * h + 3] = bv.w * sv.w + hv.w;
+            }
+        }
+    }
+}
 
 template <int NV>
-__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void ln_modulate_fwd_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ln_modulate_fwd_kernel(
     const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ shift_v, const float* __restrict__ scale1p_v, const float* __restrict__ shift_t,
     const float* __restrict__ scale1p_t, int64_t mod_stride, int text_len, int S, int D, int64_t rows, float eps,
     bf16_t* __restrict__ out, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int b = (int)(row / S), s = (int)(row % S);
-    const bf16_t* xr = x + (size_t)row * D;
-    float v[NV][8];
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int i0 = (c * 64 + lane) * 8;
-        if (i0 < D) {
-            unpack8(*reinterpret_cast<const u32x4_t*>(xr + i0), v[c]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum += v[c][j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * ROWS_PER_WAVE;
+    float alpha[NV][8], beta[NV][8];
+    int cur_key = -1;
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= rows) return;
+        const int b = (int)(row / S), s = (int)(row % S);
+        const int key = b * 2 + (s < text_len ? 1 : 0);
+        if (key != cur_key) {
+            cur_key = key;
+            const float* sh = (s < text_len) ? shift_t : shift_v;
+            const float* sc = (s < text_len) ? scale1p_t : scale1p_v;
+            if (shift_v) { sh += (size_t)b * mod_stride; sc += (size_t)b * mod_stride; } else { sh = nullptr; sc = nullptr; }
+            load_affine<NV>(w, bias, sh, sc, D, lane, alpha, beta);
         }
-    }
-    const float mean = wave_sum(sum) / (float)D;
-    float sq = 0.f;
+        const bf16_t* xr = x + (size_t)row * D;
+        float v[NV][8];
+        float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int i0 = (c * 64 + lane) * 8;
-        if (i0 < D) {
+        for (int c = 0; c < NV; ++c) {
+            const int i0 = (c * 64 + lane) * 8;
+            if (i0 < D) {
+                unpack8(*reinterpret_cast<const u32x4_t*>(xr + i0), v[c]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; sq += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-    if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
-    const bool is_text = s < text_len;
-    const float* sh = is_text ? shift_t : shift_v;
-    const float* sc = is_text ? scale1p_t : scale1p_v;
-    if (sh) { sh += (size_t)b * mod_stride; sc += (size_t)b * mod_stride; }
-    bf16_t* orow = out + (size_t)row * D;
+                for (int j = 0; j < 8; ++j) sum += v[c][j];
+            } else {
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int i0 = (c * 64 + lane) * 8;
-        if (i0 < D) {
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float y = (v[c][j] - mean) * rstd * w[i0 + j] + bias[i0 + j];
-                if (sh) y = y * sc[i0 + j] + sh[i0 + j];
-                o[j] = y;
+                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
             }
-            *reinterpret_cast<u32x4_t*>(orow + i0) = pack8(o);
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int i0 = (c * 64 + lane) * 8;
+            if (i0 < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+        if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+        bf16_t* orow = out + (size_t)row * D;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int i0 = (c * 64 + lane) * 8;
+            if (i0 < D) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * alpha[c][j] + beta[c][j];
+                *reinterpret_cast<u32x4_t*>(orow + i0) = pack8(o);
+            }
         }
     }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * (1+scale) * w ;  optionally dx += dres
 template <int NV>
-__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void ln_modulate_bwd_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ln_modulate_bwd_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const float* __restrict__ scale1p_v,
     const float* __restrict__ scale1p_t, int64_t mod_stride, int text_len, int S, int D, int64_t rows,
     const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int b = (int)(row / S), s = (int)(row % S);
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const float* sc = (s < text_len) ? scale1p_t : scale1p_v;
-    if (sc) sc += (size_t)b * mod_stride;
-    float g[NV][8], xh[NV][8];
-    float s1 = 0.f, s2 = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * ROWS_PER_WAVE;
+    float alpha[NV][8], beta_unused[NV][8];
+    int cur_key = -1;
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= rows) return;
+        const int b = (int)(row / S), s = (int)(row % S);
+        const int key = b * 2 + (s < text_len ? 1 : 0);
+        if (key != cur_key) {
+            cur_key = key;
+            const float* sc = (s < text_len) ? scale1p_t : scale1p_v;
+            if (scale1p_v) sc += (size_t)b * mod_stride; else sc = nullptr;
+            load_affine<NV>(w, nullptr, nullptr, sc, D, lane, alpha, beta_unused);
+        }
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float g[NV][8], xh[NV][8];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int i0 = (c * 64 + lane) * 8;
-        if (i0 < D) {
-            float a[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(dy + (size_t)row * D + i0), a);
-            unpack8(*reinterpret_cast<const u32x4_t*>(x + (size_t)row * D + i0), xh[c]);
+        for (int c = 0; c < NV; ++c) {
+            const int i0 = (c * 64 + lane) * 8;
+            if (i0 < D) {
+                float a[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(dy + (size_t)row * D + i0), a);
+                unpack8(*reinterpret_cast<const u32x4_t*>(x + (size_t)row * D + i0), xh[c]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float gg = a[j] * w[i0 + j];
-                if (sc) gg *= sc[i0 + j];
-                g[c][j] = gg;
-                xh[c][j] = (xh[c][j] - mean) * rstd;
-                s1 += gg;
-                s2 += gg * xh[c][j];
+                for (int j = 0; j < 8; ++j) {
+                    const float gg = a[j] * alpha[c][j];
+                    g[c][j] = gg;
+                    xh[c][j] = (xh[c][j] - mean) * rstd;
+                    s1 += gg;
+                    s2 += gg * xh[c][j];
+                }
             }
         }
-    }
-    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int i0 = (c * 64 + lane) * 8;
-        if (i0 < D) {
-            float o[8];
-            if (dres) unpack8(*reinterpret_cast<const u32x4_t*>(dres + (size_t)row * D + i0), o);
+        for (int c = 0; c < NV; ++c) {
+            const int i0 = (c * 64 + lane) * 8;
+            if (i0 < D) {
+                float o[8];
+                if (dres) unpack8(*reinterpret_cast<const u32x4_t*>(dres + (size_t)row * D + i0), o);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = rstd * (g[c][j] - c1 - xh[c][j] * c2);
-                o[j] = dres ? o[j] + d : d;
+                for (int j = 0; j < 8; ++j) {
+                    const float d = rstd * (g[c][j] - c1 - xh[c][j] * c2);
+                    o[j] = dres ? o[j] + d : d;
+                }
+                *reinterpret_cast<u32x4_t*>(dx + (size_t)row * D + i0) = pack8(o);
             }
-            *reinterpret_cast<u32x4_t*>(dx + (size_t)row * D + i0) = pack8(o);
         }
     }
 }
@@ -216,7 +259,7 @@ int32_t vgpa_ln_modulate_fwd(const void* x, const float* ln_w, const float* ln_b
     if ((mean == nullptr) != (rstd == nullptr)) return VGPA_ERR_INVALID;
     const int64_t rows = B * S;
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    DISPATCH_NV(D, VGPA_LAUNCH((ln_modulate_fwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)x, ln_w, ln_b,
+    DISPATCH_NV(D, VGPA_LAUNCH((ln_modulate_fwd_kernel<NV>), grid, dim3(64 * WAVES_PER_BLOCK), 0, stream, (const bf16_t*)x, ln_w, ln_b,
                                       shift_v, scale1p_v, shift_t, scale1p_t, mod_stride, (int)text_len, (int)S, (int)D, rows, eps,
                                       (bf16_t*)out, mean, rstd));
     VGPA_CHECK_LAUNCH();
@@ -232,7 +275,7 @@ int32_t vgpa_ln_modulate_bwd(const void* dy, const void* x, const float* mean, c
     if (scale1p_v && text_len > 0 && !scale1p_t) return VGPA_ERR_INVALID;
     const int64_t rows = B * S;
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    DISPATCH_NV(D, VGPA_LAUNCH((ln_modulate_bwd_kernel<NV>), grid, dim3(64 * ROWS_PER_BLOCK), 0, stream, (const bf16_t*)dy,
+    DISPATCH_NV(D, VGPA_LAUNCH((ln_modulate_bwd_kernel<NV>), grid, dim3(64 * WAVES_PER_BLOCK), 0, stream, (const bf16_t*)dy,
                                       (const bf16_t*)x, mean, rstd, ln_w, scale1p_v, scale1p_t, mod_stride, (int)text_len, (int)S, (int)D, rows,
                                       (const bf16_t*)dres, (bf16_t*)dx));
     VGPA_CHECK_LAUNCH();

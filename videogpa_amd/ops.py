@@ -244,6 +244,76 @@ def gelu_tanh(u):
     return _GeluTanhFn.apply(u)
 
 
+# --------------------------------------------------------------------------------------------- linear (+ LoRA)
+class _LinearLoraFn(torch.autograd.Function):
+    """y = x W^T + b, and for every output slice i that carries an adapter:  y_i += s_i * (x A_i^T) B_i^T
+    (PEFT Linear.forward; adapters are fp32 parameters cast to the activation dtype at use).  W/b are frozen:
+    backward produces dx and the adapter gradients only.  One autograd node for the whole projection, so the
+    rank-r updates go straight into column slices of y / dx without autograd's CopySlices round trips."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, n_slices, scalings, *AB):
+        if W.requires_grad or (bias is not None and bias.requires_grad):
+            raise RuntimeError("videogpa_amd: base weights are frozen on this path (LoRA-only training, as in the reference)")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        y = torch.nn.functional.linear(x2, W, bias)
+        Dn = y.shape[1] // n_slices
+        saved, ts = [], []
+        for i in range(n_slices):
+            A, Bm = AB[2 * i], AB[2 * i + 1]
+            if A is None:
+                saved += [None, None]
+                ts.append(None)
+                continue
+            Ab, Bb = A.to(x.dtype), Bm.to(x.dtype)
+            t = x2 @ Ab.t()
+            y[:, i * Dn:(i + 1) * Dn].addmm_(t, Bb.t(), alpha=scalings[i])
+            saved += [Ab, Bb]
+            ts.append(t)
+        ctx.save_for_backward(x2, W, *saved, *ts)
+        ctx.meta = (n_slices, scalings, x.shape, [a is not None for a in AB[0::2]])
+        return y.view(*x.shape[:-1], y.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, scalings, xshape, has = ctx.meta
+        sv = ctx.saved_tensors
+        x2, W = sv[0], sv[1]
+        ABs, ts = sv[2:2 + 2 * n], sv[2 + 2 * n:]
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        Dn = dy2.shape[1] // n
+        dx = dy2 @ W
+        grads = []
+        for i in range(n):
+            if not has[i]:
+                grads += [None, None]
+                continue
+            Ab, Bb, t, s = ABs[2 * i], ABs[2 * i + 1], ts[i], scalings[i]
+            dyi = dy2[:, i * Dn:(i + 1) * Dn]
+            dt = (dyi @ Bb) * s                       # [M, r]
+            dB = (dyi.t() @ t) * s                    # [out, r]
+            dA = dt.t() @ x2                          # [r, in]
+            dx.addmm_(dt, Ab)
+            grads += [dA.float(), dB.float()]
+        return (dx.view(xshape), None, None, None, None, *grads)
+
+
+def linear_lora(x, W, bias, loras):
+    """loras: list (one per equal output slice) of None or (A [r,in] fp32, B [out_i,r] fp32, scaling)."""
+    if all(l is None for l in loras):
+        return torch.nn.functional.linear(x, W, bias)
+    flat, sc = [], []
+    for l in loras:
+        if l is None:
+            flat += [None, None]
+            sc.append(0.0)
+        else:
+            flat += [l[0], l[1]]
+            sc.append(float(l[2]))
+    return _LinearLoraFn.apply(x, W, bias, len(loras), tuple(sc), *flat)
+
+
 # --------------------------------------------------------------------------------------------- attention
 def _bhs_strides(t):
     """element strides {batch, head, token} of a [B,H,S,64] view"""

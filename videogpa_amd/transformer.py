@@ -153,17 +153,6 @@ def _parts(mod):
     return mod.weight, mod.bias, None
 
 
-def _lora_add(y, x, lora):
-    """y += scaling * (x A^T) B^T in place (PEFT Linear.forward semantics, adapter weights cast to x.dtype)."""
-    if lora is None:
-        return y
-    A, Bm, scaling = lora
-    t = F.linear(x, A.to(x.dtype))
-    y2 = y.view(-1, y.shape[-1])
-    y2.addmm_(t.view(-1, t.shape[-1]), Bm.to(x.dtype).t(), alpha=scaling)
-    return y
-
-
 class Attention(nn.Module):
     def __init__(self, dim, heads, head_dim, bias, qk_eps=1e-6):
         super().__init__()
@@ -189,25 +178,12 @@ class Attention(nn.Module):
         return self._fused[1], self._fused[2]
 
     def forward(self, n, text_len, rope):
-        D = n.shape[-1]
         W, b = self.fused_qkv()
-        qkv = F.linear(n, W, b)
-        # LoRA on q/k/v: one shared down-projection input, three rank-r updates into column slices
-        loras = [_parts(m)[2] for m in (self.to_q, self.to_k, self.to_v)]
-        if any(l is not None for l in loras):
-            q2 = qkv.view(-1, 3 * D)
-            x2 = n.view(-1, D)
-            for i, l in enumerate(loras):
-                if l is None:
-                    continue
-                A, Bm, scaling = l
-                t = F.linear(x2, A.to(n.dtype))
-                q2[:, i * D:(i + 1) * D].addmm_(t, Bm.to(n.dtype).t(), alpha=scaling)
+        qkv = ops.linear_lora(n, W, b, [_parts(m)[2] for m in (self.to_q, self.to_k, self.to_v)])
         a = ops.qknorm_attention(qkv, _f32(self.norm_q.weight), _f32(self.norm_q.bias), _f32(self.norm_k.weight), _f32(self.norm_k.bias),
                                  self.heads, text_len, rope, self.qk_eps)
         wo, bo, lo = _parts(self.to_out[0])
-        out = F.linear(a, wo, bo)
-        return _lora_add(out, a, lo)
+        return ops.linear_lora(a, wo, bo, [lo])
 
 
 class CogVideoXBlock(nn.Module):
