@@ -114,6 +114,26 @@ int32_t vgpa_adamw_step(float* param, const float* grad, float* exp_avg, float* 
                         float beta2, float eps, float weight_decay, int64_t step, float grad_scale, float max_norm,
                         const float* total_norm, vgpa_stream_t stream);
 
+/* ---- geometry-consistency scorer ---------------------------------------------------------------------------------
+ * project_points: utils/projection_utils.py:12-51 (+ :57-101 batch loop and [-1,1] output) with the confidence filter
+ * of utils/pointcloud_utils.py:47-73 as a per-point predicate.  pc/colors fp32 [N,3], conf fp32 [N] or NULL,
+ * K fp32 [T,3,3], E fp32 [T,e_rows,4] (e_rows 3 or 4).  canvas u8 [T,H,W,3] and/or out_f fp32 [T,3,H,W]. */
+size_t vgpa_project_points_workspace_bytes(int64_t T, int64_t H, int64_t W);
+int32_t vgpa_project_points(const float* pc, const float* colors, const float* conf, float conf_thr, const float* K,
+                            const float* E, int32_t e_rows, int64_t N, int64_t T, int64_t H, int64_t W, uint8_t* canvas,
+                            float* out_f, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* MSEMetric.compute, metrics/mse.py:14-54.  dtype 0 f32 / 2 u8; layout 0 [T,C,H,W] / 1 [T,H,W,C]; is_tensor selects
+ * the torch.Tensor vs numpy range heuristics. */
+size_t vgpa_frame_mse_workspace_bytes(void);
+int32_t vgpa_frame_mse(const void* gt, int32_t gt_dtype, int32_t gt_layout, int32_t gt_is_tensor, const void* rep,
+                       int32_t rep_dtype, int32_t rep_layout, int32_t rep_is_tensor, int64_t T, int64_t C, int64_t H,
+                       int64_t W, float* out, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* compute_motion_score_vectorized, metrics/consistency_score.py:8-40 */
+int32_t vgpa_motion_score(const float* E, int32_t e_rows, int64_t T, float* out, vgpa_stream_t stream);
+/* kornia find_fundamental (8-point) + sampson_epipolar_distance as used by metrics/epipolar.py:197-213 */
+int32_t vgpa_epipolar_sampson(const float* p1, const float* p2, const int64_t* offsets, int64_t n_pairs, float* err_out,
+                              float* F_out, vgpa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

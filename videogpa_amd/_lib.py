@@ -37,6 +37,12 @@ SIGNATURES = {
     "vgpa_attn_bwd_dkv": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd_dq": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
+    "vgpa_project_points_workspace_bytes": (SZ, [I64, I64, I64]),
+    "vgpa_project_points": (I32, [P, P, P, F32, P, P, I32, I64, I64, I64, I64, P, P, P, SZ, P]),
+    "vgpa_frame_mse_workspace_bytes": (SZ, []),
+    "vgpa_frame_mse": (I32, [P, I32, I32, I32, P, I32, I32, I32, I64, I64, I64, I64, P, P, SZ, P]),
+    "vgpa_motion_score": (I32, [P, I32, I64, P, P]),
+    "vgpa_epipolar_sampson": (I32, [P, P, P, I64, P, P, P]),
 }
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "workspace too small"}

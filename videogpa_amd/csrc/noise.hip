@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void noise_velocity_kernel(const void* __restr
             load8<DT>(x, ox + (size_t)p * N + i, a);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                o1[j] = rnd<DT>(__fadd_rn(rnd<DT>(__fmul_rn(sa, a[j])), rnd<DT>(__fmul_rn(sb, e[j]))));
-                o2[j] = rnd<DT>(__fsub_rn(rnd<DT>(__fmul_rn(sa, e[j])), rnd<DT>(__fmul_rn(sb, a[j]))));
+                o1[j] = rnd<DT>(rnd<DT>(sa * a[j]) + rnd<DT>(sb * e[j]));
+                o2[j] = rnd<DT>(rnd<DT>(sa * e[j]) - rnd<DT>(sb * a[j]));
             }
             store8<DT>(xt, ox + (size_t)p * N + i, o1);
             store8<DT>(v, ox + (size_t)p * N + i, o2);
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void noise_velocity_kernel(const void* __restr
         const float e = load1<DT>(noise, on + i);
         for (int p = 0; p < 2; ++p) {
             const float a = load1<DT>(x, ox + (size_t)p * N + i);
-            store1<DT>(xt, ox + (size_t)p * N + i, rnd<DT>(__fadd_rn(rnd<DT>(__fmul_rn(sa, a)), rnd<DT>(__fmul_rn(sb, e)))));
-            store1<DT>(v, ox + (size_t)p * N + i, rnd<DT>(__fsub_rn(rnd<DT>(__fmul_rn(sa, e)), rnd<DT>(__fmul_rn(sb, a)))));
+            store1<DT>(xt, ox + (size_t)p * N + i, rnd<DT>(rnd<DT>(sa * a) + rnd<DT>(sb * e)));
+            store1<DT>(v, ox + (size_t)p * N + i, rnd<DT>(rnd<DT>(sa * e) - rnd<DT>(sb * a)));
         }
     }
 }
