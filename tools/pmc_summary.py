@@ -1,0 +1,16 @@
+"""Aggregate a rocprofv3 --pmc counter_collection.csv per kernel: mean of each counter over dispatches."""
+import csv
+import sys
+from collections import defaultdict
+
+acc = defaultdict(lambda: defaultdict(list))
+for f in sys.argv[1:]:
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in acc.items():
+    if not k.startswith("attn") and "--all" not in sys.argv:
+        continue
+    print(k)
+    for c, v in sorted(cs.items()):
+        print(f"   {c:32s} {sum(v) / len(v):18.0f}  (n={len(v)})")

@@ -29,9 +29,10 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
-struct TStride {  // element strides of a [B, H, S, 64] view (last dim contiguous)
-    int64_t b, h, s;
+struct TStride {  // element strides of a [B, H, S, 64] view (last dim contiguous); every element offset < 2^31 (host-checked)
+    uint32_t b, h, s;
 };
+#define SOFTMAX_RESCALE_THR 6.0f  // running max is only raised when a tile exceeds it by > 2^THR (keeps P <= 2^THR)
 
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -53,13 +54,13 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int base) {
 }
 
 // ---- global -> register -> LDS staging of a [64 x 64] bf16 tile (rows clamped to S-1) ------------------------
-__device__ __forceinline__ void tile_load(const bf16_t* base, int64_t row_stride, int row0, int S, u32x4_t (&r)[2]) {
+__device__ __forceinline__ void tile_load(const bf16_t* base, uint32_t row_stride, int row0, int S, u32x4_t (&r)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = threadIdx.x + 256 * j;
         int row = row0 + (c >> 3);
         row = row < S ? row : S - 1;
-        r[j] = *reinterpret_cast<const u32x4_t*>(base + (int64_t)row * row_stride + (c & 7) * 8);
+        r[j] = *reinterpret_cast<const u32x4_t*>(base + ((uint32_t)row * row_stride + (uint32_t)((c & 7) * 8)));
     }
 }
 __device__ __forceinline__ void tile_store(bf16_t* lds, const u32x4_t (&r)[2]) {
@@ -93,10 +94,10 @@ __device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* lds, int rowbase, int 
 }
 
 // stationary-operand fragments straight from HBM: lane (row = l&31, hi) takes 8 contiguous d per k-step
-__device__ __forceinline__ void load_row_frags(const bf16_t* base, int64_t row_stride, int row, int S, int lane, bf16x8_t (&f)[4]) {
+__device__ __forceinline__ void load_row_frags(const bf16_t* base, uint32_t row_stride, int row, int S, int lane, bf16x8_t (&f)[4]) {
     int r = row + (lane & 31);
     r = r < S ? r : S - 1;
-    const bf16_t* p = base + (int64_t)r * row_stride + (lane >> 5) * 8;
+    const bf16_t* p = base + ((uint32_t)r * row_stride + (uint32_t)((lane >> 5) * 8));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(p + ks * 16);
 }
@@ -124,9 +125,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int q0 = qt * WG_ROWS + wave * 32;
 
-    const bf16_t* Qb = Q + b * sq.b + h * sq.h;
-    const bf16_t* Kb = K + b * sk.b + h * sk.h;
-    const bf16_t* Vb = V + b * sv.b + h * sv.h;
+    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
 
     bf16x8_t qf[4];
     load_row_frags(Qb, sq.s, q0, S, lane, qf);
@@ -173,22 +174,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, other_half(mx));
-        const float m_new = fmaxf(m, mx * c);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        m = m_new;
-        float psum = 0.f;
+        // lazy rescale: raise the running max (and rescale O, l) only when some row of this wave outgrows it by 2^THR.
+        // The decision is wave-uniform, so both half-lanes of a row always share one m.
+        if (__any(mx * c > m + SOFTMAX_RESCALE_THR)) {
+            mx = fmaxf(mx, other_half(mx));
+            const float m_new = fmaxf(m, mx * c);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
+        const f32x2_t c2 = {c, c}, nm2 = {-m, -m};
+        f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] * c - m_new);
-                s[kb][r] = p;
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t v = {s[kb][r], s[kb][r + 1]};
+                v = v * c2 + nm2;                                  // v_pk_fma_f32
+                f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                s[kb][r] = p[0];
+                s[kb][r + 1] = p[1];
+                ps2 += p;                                          // v_pk_add_f32
             }
-        l = l * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        l += ps2[0] + ps2[1];
         // O^T[d, q] += V^T[d, key] P^T[key, q]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const float inv = 1.f / l;
     const int q = q0 + (lane & 31);
     if (q < S) {
-        bf16_t* op = O + b * so.b + h * so.h + (int64_t)q * so.s;
+        bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -238,8 +248,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
         const int64_t bh = row / S;
         const int h = (int)(bh % H), b = (int)(bh / H);
         float a[8], o[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(dO + b * sdo.b + h * sdo.h + (int64_t)q * sdo.s + c8 * 8), a);
-        unpack8(*reinterpret_cast<const u32x4_t*>(O + b * so.b + h * so.h + (int64_t)q * so.s + c8 * 8), o);
+        unpack8(*reinterpret_cast<const u32x4_t*>(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h + (size_t)q * sdo.s + c8 * 8)), a);
+        unpack8(*reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c8 * 8)), o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
     }
@@ -264,11 +274,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int q0 = qt * WG_ROWS + wave * 32;
 
-    const bf16_t* Kb = K + b * sk.b + h * sk.h;
-    const bf16_t* Vb = V + b * sv.b + h * sv.h;
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
     bf16x8_t qf[4], dof[4];
-    load_row_frags(Q + b * sq.b + h * sq.h, sq.s, q0, S, lane, qf);
-    load_row_frags(dO + b * sdo.b + h * sdo.h, sdo.s, q0, S, lane, dof);
+    load_row_frags(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0, S, lane, qf);
+    load_row_frags(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0, S, lane, dof);
     int qc = q0 + (lane & 31);
     qc = qc < S ? qc : S - 1;
     const float lse = LSE2[(int64_t)bh * S + qc];
@@ -303,11 +313,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s);      // S^T[key,q]
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(vl, kb * 32, ks, lane), dof[ks], dp);   // dP^T[key,q]
+            const f32x2_t c2 = {c, c}, nl2 = {-lse, -lse}, nd2 = {-dlt, -dlt};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[r] * c - lse);
-                if (tail && (t * TILE + kb * 32 + acc_row(r, hi) >= S)) p = 0.f;
-                s[r] = p * (dp[r] - dlt);                                                                // dS^T
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t v = {s[r], s[r + 1]};
+                v = v * c2 + nl2;
+                f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                if (tail) {
+                    if (t * TILE + kb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
+                    if (t * TILE + kb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
+                }
+                f32x2_t d = {dp[r], dp[r + 1]};
+                d = (d + nd2) * p;                                                                       // dS^T
+                s[r] = d[0];
+                s[r + 1] = d[1];
             }
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     }
     const int q = q0 + (lane & 31);
     if (q < S) {
-        bf16_t* op = dQ + b * sdq.b + h * sdq.h + (int64_t)q * sdq.s;
+        bf16_t* op = dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -354,13 +373,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int k0 = kt * WG_ROWS + wave * 32;
 
-    const bf16_t* Qb = Q + b * sq.b + h * sq.h;
-    const bf16_t* dOb = dO + b * sdo.b + h * sdo.h;
+    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
+    const bf16_t* dOb = dO + ((size_t)b * sdo.b + (size_t)h * sdo.h);
     const float* Lb = LSE2 + (int64_t)bh * S;
     const float* Db = DELTA + (int64_t)bh * S;
     bf16x8_t kf[4], vf[4];
-    load_row_frags(K + b * sk.b + h * sk.h, sk.s, k0, S, lane, kf);
-    load_row_frags(V + b * sv.b + h * sv.h, sv.s, k0, S, lane, vf);
+    load_row_frags(K + ((size_t)b * sk.b + (size_t)h * sk.h), sk.s, k0, S, lane, kf);
+    load_row_frags(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, k0, S, lane, vf);
 
     f32x16_t dk[2], dv[2];
 #pragma unroll
@@ -415,12 +434,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 dl[g] = *reinterpret_cast<const f32x4_t*>(dlt_l + qb * 32 + 8 * g + 4 * hi);
             }
             f32x16_t ds;
+            const f32x2_t c2 = {c, c};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[r] * c - lv[r >> 2][r & 3]);
-                if (tail && (t * TILE + qb * 32 + acc_row(r, hi) >= S)) p = 0.f;
-                s[r] = p;
-                ds[r] = p * (dp[r] - dl[r >> 2][r & 3]);
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t v = {s[r], s[r + 1]};
+                const f32x2_t l2 = {lv[r >> 2][r & 3], lv[r >> 2][(r & 3) + 1]};
+                const f32x2_t dl2 = {dl[r >> 2][r & 3], dl[r >> 2][(r & 3) + 1]};
+                v = v * c2 - l2;
+                f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                if (tail) {
+                    if (t * TILE + qb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
+                    if (t * TILE + qb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
+                }
+                f32x2_t d = {dp[r], dp[r + 1]};
+                d = (d - dl2) * p;
+                s[r] = p[0];
+                s[r + 1] = p[1];
+                ds[r] = d[0];
+                ds[r + 1] = d[1];
             }
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
@@ -442,8 +473,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     }
     const int k = k0 + (lane & 31);
     if (k < S) {
-        bf16_t* kp = dK + b * sdk.b + h * sdk.h + (int64_t)k * sdk.s;
-        bf16_t* vp = dV + b * sdv.b + h * sdv.h + (int64_t)k * sdv.s;
+        bf16_t* kp = dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s);
+        bf16_t* vp = dV + ((size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)k * sdv.s);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -460,8 +491,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 }
 
 static inline bool stride_ok(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= HD && (st[0] % 8 == 0) && (st[1] % 8 == 0) && (st[2] % 8 == 0); }
-static inline TStride mk(const int64_t* st) { TStride t; t.b = st[0]; t.h = st[1]; t.s = st[2]; return t; }
+// every element offset reachable inside one (batch, head) slab and across the tensor must fit 31 bits
+static inline bool range_ok(const int64_t* st, int64_t B, int64_t H, int64_t S) {
+    return (B - 1) * st[0] + (H - 1) * st[1] + (S - 1) * st[2] + HD < ((int64_t)1 << 31);
+}
+static inline TStride mk(const int64_t* st) { TStride t; t.b = (uint32_t)st[0]; t.h = (uint32_t)st[1]; t.s = (uint32_t)st[2]; return t; }
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+#define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
 
 extern "C" {
 
@@ -471,7 +508,7 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
                       const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
                       int64_t head_dim, float scale, hipStream_t stream) {
     if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
-    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(o_strides)) return VGPA_ERR_INVALID;
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides)) return VGPA_ERR_INVALID;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
     const int n_qt = (int)((S + WG_ROWS - 1) / WG_ROWS);
     const int64_t nblk = (int64_t)n_qt * B * H;
@@ -493,7 +530,7 @@ static inline bool bwd_common_ok(int64_t B, int64_t H, int64_t S, int64_t head_d
 // step 1 of the backward: delta[b,h,q] = sum_d dO * O
 int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_strides, const int64_t* do_strides, float* delta, int64_t B,
                             int64_t H, int64_t S, int64_t head_dim, hipStream_t stream) {
-    if (!o || !d_o || !delta || !bwd_common_ok(B, H, S, head_dim) || !stride_ok(o_strides) || !stride_ok(do_strides) || !al16(o) || !al16(d_o))
+    if (!o || !d_o || !delta || !bwd_common_ok(B, H, S, head_dim) || !SOK(o_strides) || !SOK(do_strides) || !al16(o) || !al16(d_o))
         return VGPA_ERR_INVALID;
     const int64_t total = B * H * S;
     VGPA_LAUNCH(attn_delta_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o,
@@ -508,8 +545,8 @@ int32_t vgpa_attn_bwd_dkv(const void* q, const void* k, const void* v, const voi
                           const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
                           hipStream_t stream) {
     if (!q || !k || !v || !d_o || !lse2 || !delta || !dk || !dv || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
-    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(do_strides) || !stride_ok(dk_strides) ||
-        !stride_ok(dv_strides) || !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv))
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dk_strides) ||
+        !SOK(dv_strides) || !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv))
         return VGPA_ERR_INVALID;
     const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
     VGPA_LAUNCH(attn_bwd_dkv_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
@@ -524,7 +561,7 @@ int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void
                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
                          const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, hipStream_t stream) {
     if (!q || !k || !v || !d_o || !lse2 || !delta || !dq || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
-    if (!stride_ok(q_strides) || !stride_ok(k_strides) || !stride_ok(v_strides) || !stride_ok(do_strides) || !stride_ok(dq_strides) ||
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dq_strides) ||
         !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dq))
         return VGPA_ERR_INVALID;
     const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
