@@ -114,6 +114,9 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // =====================================================================================================
 // Forward:  O = softmax(scale * Q K^T) V ;  lse2 = log2 sum_k exp2(scale*log2e * q.k)
 // =====================================================================================================
+// QB = 32-row query blocks per wave.  QB = 2 halves the LDS reads, tile staging and loop overhead per MFMA (the
+// kernel is instruction-issue bound: ~9 VALU + 2 LDS instructions per MFMA at QB = 1), at 2 waves/SIMD.
+template <int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                          float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
@@ -123,19 +126,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int bh = vid / n_qt, qt = vid % n_qt;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int q0 = qt * WG_ROWS + wave * 32;
+    const int q0 = (qt * 4 + wave) * (32 * QB);
 
     const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
     const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
     const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
 
-    bf16x8_t qf[4];
-    load_row_frags(Qb, sq.s, q0, S, lane, qf);
-
-    f32x16_t o[2];
+    bf16x8_t qf[QB][4];
+    f32x16_t o[QB][2];
+    float m[QB], l[QB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < QB; ++j) {
+        load_row_frags(Qb, sq.s, q0 + 32 * j, S, lane, qf[j]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
+        m[j] = -INFINITY;
+        l[j] = 0.f;
+    }
 
     const int nt = (S + TILE - 1) / TILE;
     u32x4_t kr[2], vr[2];
@@ -152,61 +159,79 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             tile_load(Kb, sk.s, (t + 1) * TILE, S, kr);
             tile_load(Vb, sv.s, (t + 1) * TILE, S, vr);
         }
-        // S^T[key, q] for the two 32-key blocks
-        f32x16_t s[2];
+        // S^T[key, q] for the two 32-key blocks; each K fragment feeds all QB query blocks
+        f32x16_t s[QB][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+            for (int j = 0; j < QB; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s[kb]);
+                for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
+            }
         }
         if (t == nt - 1 && (S & (TILE - 1))) {
             const int kbase = t * TILE;
 #pragma unroll
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + kb * 32 + acc_row(r, hi) >= S) s[j][kb][r] = -INFINITY;
+        }
+        const f32x2_t c2 = {c, c};
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            float mx = s[j][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[j][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][1][r]);
+            // lazy rescale: raise the running max (and rescale O, l) only when some row of this wave outgrows it by
+            // 2^THR.  The decision is wave-uniform, so both half-lanes of a row always share one m.
+            if (__any(mx * c > m[j] + SOFTMAX_RESCALE_THR)) {
+                mx = fmaxf(mx, other_half(mx));
+                const float m_new = fmaxf(m[j], mx * c);
+                const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
+                m[j] = m_new;
+                l[j] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o[j][0][i] *= alpha; o[j][1][i] *= alpha; }
+            }
+            const f32x2_t nm2 = {-m[j], -m[j]};
+            f32x2_t ps2 = {0.f, 0.f};
+#pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kbase + kb * 32 + acc_row(r, hi) >= S) s[kb][r] = -INFINITY;
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t v = {s[j][kb][r], s[j][kb][r + 1]};
+                    v = v * c2 + nm2;                                  // v_pk_fma_f32
+                    f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                    s[j][kb][r] = p[0];
+                    s[j][kb][r + 1] = p[1];
+                    ps2 += p;                                          // v_pk_add_f32
+                }
+            l[j] += ps2[0] + ps2[1];
         }
-        float mx = s[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        // lazy rescale: raise the running max (and rescale O, l) only when some row of this wave outgrows it by 2^THR.
-        // The decision is wave-uniform, so both half-lanes of a row always share one m.
-        if (__any(mx * c > m + SOFTMAX_RESCALE_THR)) {
-            mx = fmaxf(mx, other_half(mx));
-            const float m_new = fmaxf(m, mx * c);
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            m = m_new;
-            l *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-        }
-        const f32x2_t c2 = {c, c}, nm2 = {-m, -m};
-        f32x2_t ps2 = {0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2_t v = {s[kb][r], s[kb][r + 1]};
-                v = v * c2 + nm2;                                  // v_pk_fma_f32
-                f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
-                s[kb][r] = p[0];
-                s[kb][r + 1] = p[1];
-                ps2 += p;                                          // v_pk_add_f32
-            }
-        l += ps2[0] + ps2[1];
-        // O^T[d, q] += V^T[d, key] P^T[key, q]
+        // O^T[d, q] += V^T[d, key] P^T[key, q]; each V fragment feeds all QB query blocks
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const bf16x8_t pf = pack_frag(s[kb], 8 * cc);
+                bf16x8_t pf[QB];
 #pragma unroll
-                for (int db = 0; db < 2; ++db) o[db] = mfma32(frag_tr(vl, kb * 32 + 16 * cc, db * 32, lane), pf, o[db]);
+                for (int j = 0; j < QB; ++j) pf[j] = pack_frag(s[j][kb], 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8_t vf = frag_tr(vl, kb * 32 + 16 * cc, db * 32, lane);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) o[j][db] = mfma32(vf, pf[j], o[j][db]);
+                }
             }
         if (t + 1 < nt) {
             tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
@@ -215,21 +240,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         __syncthreads();
     }
 
-    l += other_half(l);
-    const float inv = 1.f / l;
-    const int q = q0 + (lane & 31);
-    if (q < S) {
-        bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int j = 0; j < QB; ++j) {
+        const float lt = l[j] + other_half(l[j]);
+        const float inv = 1.f / lt;
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < S) {
+            bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2_t w;
-                w[0] = pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-                w[1] = pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-                *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
-            }
-        if (hi == 0) LSE2[(int64_t)bh * S + q] = m + __builtin_amdgcn_logf(l);  // v_log_f32 is log2
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t w;
+                    w[0] = pack_bf16x2(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv);
+                    w[1] = pack_bf16x2(o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+                }
+            if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
+        }
     }
 }
 
@@ -498,6 +526,7 @@ static inline bool range_ok(const int64_t* st, int64_t B, int64_t H, int64_t S) 
 static inline TStride mk(const int64_t* st) { TStride t; t.b = (uint32_t)st[0]; t.h = (uint32_t)st[1]; t.s = (uint32_t)st[2]; return t; }
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+#define FWD_QB 2   // query blocks (of 32 rows) per wave in the forward kernel
 #define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
 
 extern "C" {
@@ -510,12 +539,12 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
     if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides)) return VGPA_ERR_INVALID;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
-    const int n_qt = (int)((S + WG_ROWS - 1) / WG_ROWS);
+    const int n_qt = (int)((S + FWD_QB * WG_ROWS - 1) / (FWD_QB * WG_ROWS));
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
-    VGPA_LAUNCH(attn_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt,
-                       scale * 1.4426950408889634f);
+    VGPA_LAUNCH((attn_fwd_kernel<FWD_QB>), dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt,
+                scale * 1.4426950408889634f);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
