@@ -105,6 +105,18 @@ int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o
                       const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, void* workspace,
                       size_t ws_bytes, vgpa_stream_t stream);
 
+/* ---- LoRA A.B contractions (peft Linear.forward `lora_B(lora_A(x)) * scaling` and its backward for the adapters of
+ * train/CogVideoX-5B/03_train.py:102-106).  bf16 row-major operands with explicit row strides (elements).
+ *   down  : T[M,R]  = X[M,K] A[R,K]^T                     K % 64 == 0, R <= 256
+ *   up_add: Y[M,N]  = (accumulate ? Y : 0) + s * T[M,rp] Bw[N,rp]^T   rp in {16,32,48,64,96,128,192}, N % 32 == 0
+ *   grad  : G[P,Q] += s * U[M,P]^T V[M,Q]                 G fp32, caller-zeroed (fp32 atomics) */
+int32_t vgpa_lora_down(const void* X, int64_t ldx, const void* A, void* T, int64_t ldt, int64_t M, int64_t K, int64_t R,
+                       vgpa_stream_t stream);
+int32_t vgpa_lora_up_add(void* Y, int64_t ldy, const void* T, int64_t ldt, const void* Bw, int64_t ldb, float s, int64_t M,
+                         int64_t N, int64_t rp, int32_t accumulate, vgpa_stream_t stream);
+int32_t vgpa_lora_grad(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M,
+                       int64_t P, int64_t Q, vgpa_stream_t stream);
+
 /* ---- optimizer on one flat fp32 buffer of all LoRA parameters: gradient_clip_val=1.0 + torch.optim.AdamW,
  * train/CogVideoX-5B/03_train.py:208-213,266.  norm_out[0] = grad_scale * ||grad||_2. */
 size_t vgpa_grad_norm_workspace_bytes(void);

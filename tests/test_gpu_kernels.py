@@ -232,3 +232,72 @@ def test_qknorm_attention_fused(ops, use_rope):
     assert (o.double().cpu() - orf).abs().max().item() < 0.03
     e = (qd.grad.double().cpu() - x.grad).abs().max().item()
     assert e < 0.03 * x.grad.abs().max().item() + 2e-3, e
+
+
+# ------------------------------------------------------------------------------------------ LoRA MFMA kernels
+@pytest.mark.parametrize("M,K,r,n", [(200, 128, 4, 3), (333, 256, 64, 3), (1000, 3072, 64, 1), (130, 192, 8, 1)])
+def test_lora_kernels_raw(ops, M, K, r, n):
+    g = torch.Generator().manual_seed(M + r)
+    rp = ops._pad_rank(r)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    a_cat = torch.zeros(n * rp, K)
+    for j in range(n):
+        a_cat[j * rp:j * rp + r] = torch.randn(r, K, generator=g) / K ** 0.5
+    a_cat = a_cat.to(torch.bfloat16)
+    t = ops.lora_down(dev(x), dev(a_cat))
+    t_ref = x.double() @ a_cat.double().t()
+    assert (t.double().cpu() - t_ref).abs().max().item() < 0.02 * t_ref.abs().max().item() + 1e-3
+    # up_add into a column slice of a wider buffer
+    N = 96
+    y = torch.randn(M, n * N, generator=g).to(torch.bfloat16)
+    yd = dev(y).clone()
+    for j in range(n):
+        bw = torch.zeros(N, rp)
+        bw[:, :r] = torch.randn(N, r, generator=g)
+        bw = bw.to(torch.bfloat16)
+        ops.lora_up_add(yd[:, j * N:(j + 1) * N], t[:, j * rp:(j + 1) * rp], dev(bw), 2.0)
+        ref = y[:, j * N:(j + 1) * N].double() + 2.0 * (t[:, j * rp:(j + 1) * rp].double().cpu() @ bw.double().t())
+        err = (yd[:, j * N:(j + 1) * N].double().cpu() - ref).abs().max().item()
+        assert err < 0.02 * ref.abs().max().item() + 1e-3, err
+    # grad: fp32 U^T V over tokens
+    u = torch.randn(M, n * rp, generator=g).to(torch.bfloat16)
+    gr = ops.lora_grad(dev(u), dev(x), 0.5)
+    ref = 0.5 * (u.double().t() @ x.double())
+    assert gr.dtype == torch.float32 and tuple(gr.shape) == (n * rp, K)
+    assert (gr.double().cpu() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-4
+    gr2 = ops.lora_grad(dev(x)[:, :64], dev(u), 1.0)          # strided U (column slice)
+    ref2 = x[:, :64].double().t() @ u.double()
+    assert (gr2.double().cpu() - ref2).abs().max().item() < 2e-3 * ref2.abs().max().item() + 1e-4
+
+
+def test_linear_lora_function_vs_torch(ops):
+    g = torch.Generator().manual_seed(5)
+    Bt, S, K, Dn, r = 2, 77, 128, 128, 8
+    x = torch.randn(Bt, S, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(3 * Dn, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(3 * Dn, generator=g).to(torch.bfloat16)
+    As = [torch.randn(r, K, generator=g) / K ** 0.5 for _ in range(3)]
+    Bs = [torch.randn(Dn, r, generator=g) * 0.3 for _ in range(3)]
+    dy = torch.randn(Bt, S, 3 * Dn, generator=g).to(torch.bfloat16)
+    xd = dev(x).requires_grad_(True)
+    Ad = [dev(a).requires_grad_(True) for a in As]
+    Bd = [dev(b_).requires_grad_(True) for b_ in Bs]
+    loras = [(Ad[0], Bd[0], 2.0), None, (Ad[2], Bd[2], 2.0)]
+    y = ops.linear_lora(xd, dev(W), dev(b), loras)
+    y.backward(dev(dy))
+    xr = x.double().requires_grad_(True)
+    Ar = [a.to(torch.bfloat16).double().requires_grad_(True) for a in As]
+    Br = [b_.to(torch.bfloat16).double().requires_grad_(True) for b_ in Bs]
+    yr = F.linear(xr, W.double(), b.double())
+    parts = list(yr.split(Dn, dim=-1))
+    for i in (0, 2):
+        parts[i] = parts[i] + 2.0 * F.linear(F.linear(xr, Ar[i]), Br[i])
+    yr = torch.cat(parts, -1)
+    yr.backward(dy.double())
+    assert (y.double().cpu() - yr).abs().max().item() < 0.03 * yr.abs().max().item()
+    assert (xd.grad.double().cpu() - xr.grad).abs().max().item() < 0.03 * xr.grad.abs().max().item()
+    for i in (0, 2):
+        assert Ad[i].grad.dtype == torch.float32
+        assert (Ad[i].grad.double().cpu() - Ar[i].grad).abs().max().item() < 0.03 * Ar[i].grad.abs().max().item()
+        assert (Bd[i].grad.double().cpu() - Br[i].grad).abs().max().item() < 0.03 * Br[i].grad.abs().max().item()
+    assert Ad[1].grad is None and Bd[1].grad is None

@@ -1,0 +1,274 @@
+// LoRA A.B contractions on MFMA (SURVEY K5/K9 adapter part).  Replaces peft.tuners.lora.layer.Linear's
+// `lora_B(lora_A(x)) * scaling` and its autograd backward for the adapters the reference puts on
+// to_q / to_k / to_v / to_out.0 (train/CogVideoX-5B/03_train.py:102-106); oracle: oracle/cogvideox.py::_lora_linear.
+//
+// All three kernels are HBM-bound (rank r = 64 against 3072-wide activations: 2 r FLOP per activation byte), so
+// they are built to touch the big [M, 3072] operand exactly once with 16-byte row-contiguous accesses and to keep
+// the small operands in L2 / LDS:
+//   down   : T[M,R]  = X[M,K] A[R,K]^T                 (R = all adapters sharing the input, e.g. 3*64 for q,k,v)
+//   up_add : Y[M,N] (+)= s * T[M,r] Bw[N,r]^T           (in place on a column slice of the fused projection output)
+//   grad   : G[P,Q] += s * U[M,P]^T V[M,Q]   (fp32)    (dA = dT^T X, dB = s dY^T T; contraction over tokens, split
+//                                                       over M across workgroups, fp32 atomics into the small result)
+// Every product is taken transposed (D[n][m]) where that makes each lane's accumulator run along the contiguous
+// output dimension, so results leave as 8-byte row-contiguous pieces.
+#include "mfma_tiles.h"
+
+// ---- staging helpers with bounds (zero fill) -------------------------------------------------------------------
+// rows [row0, row0+64) x cols [col0, col0+64) of a row-major bf16 matrix; rows >= nrows or cols >= ncols read as 0
+__device__ __forceinline__ void tile_load_zfill(const bf16_t* base, int64_t ld, int64_t row0, int64_t nrows, int col0, int ncols,
+                                                u32x4_t (&r)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        const int64_t row = row0 + (c >> 3);
+        const int col = col0 + (c & 7) * 8;
+        u32x4_t z = {0u, 0u, 0u, 0u};
+        r[j] = (row < nrows && col < ncols) ? *reinterpret_cast<const u32x4_t*>(base + row * ld + col) : z;
+    }
+}
+
+// =====================================================================================================
+// down:  T = X A^T.   Workgroup = 64 rows of X, all RP = 32*NCB output columns; K streamed in chunks of 64.
+// =====================================================================================================
+template <int NCB>
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ A,
+                                                          bf16_t* __restrict__ T, int64_t ldt, int64_t M, int K, int R) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    constexpr int RP = 32 * NCB;
+    constexpr int NACC = (NCB + 1) / 2;
+    constexpr int BUF = (64 + RP) * PITCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int rb = wave & 1, cg = wave >> 1;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+
+    f32x16_t acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+    u32x4_t xr[2], ar[NCB];
+    auto load = [&](int k0) {
+        tile_load_zfill(X, ldx, row0, M, k0, K, xr);
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            const int row = c >> 3;
+            u32x4_t z = {0u, 0u, 0u, 0u};
+            ar[j] = (row < R) ? *reinterpret_cast<const u32x4_t*>(A + (int64_t)row * K + k0 + (c & 7) * 8) : z;
+        }
+    };
+    auto store = [&](int buf) {
+        bf16_t* xl = smem + buf * BUF;
+        bf16_t* al = xl + 64 * PITCH;
+        tile_store(xl, xr);
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            *reinterpret_cast<u32x4_t*>(al + (c >> 3) * PITCH + (c & 7) * 8) = ar[j];
+        }
+    };
+    const int nk = K / 64;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const bf16_t* xl = smem + (t & 1) * BUF;
+        const bf16_t* al = xl + 64 * PITCH;
+        if (t + 1 < nk) load((t + 1) * 64);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8_t xf = frag_row(xl, rb * 32, ks, lane);            // B operand: column = X row
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                const int cb = cg + 2 * a;
+                if (cb < NCB) acc[a] = mfma32(frag_row(al, cb * 32, ks, lane), xf, acc[a]);   // D[n = adapter col][m = X row]
+            }
+        }
+        if (t + 1 < nk) store((t + 1) & 1);
+        __syncthreads();
+    }
+    const int64_t m = row0 + rb * 32 + (lane & 31);
+    if (m < M) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const int cb = cg + 2 * a;
+            if (cb < NCB) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = cb * 32 + 8 * g + 4 * hi;
+                    if (n + 3 < R || n < R) {
+                        if (n + 3 < R) {
+                            u32x2_t w;
+                            w[0] = pack_bf16x2(acc[a][4 * g], acc[a][4 * g + 1]);
+                            w[1] = pack_bf16x2(acc[a][4 * g + 2], acc[a][4 * g + 3]);
+                            *reinterpret_cast<u32x2_t*>(T + m * ldt + n) = w;
+                        } else {
+                            for (int i = 0; i < 4; ++i)
+                                if (n + i < R) T[m * ldt + n + i] = f32_to_bf16(acc[a][4 * g + i]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// up_add:  Y (+)= s * T Bw^T.   No LDS: T / Bw fragments come straight from L2 (both are tiny), each wave owns a
+// 32-row x 128-column strip of Y and read-modify-writes it in 8-byte row-contiguous pieces.
+// =====================================================================================================
+template <int KS>
+__global__ __launch_bounds__(256) void lora_up_add_kernel(bf16_t* __restrict__ Y, int64_t ldy, const bf16_t* __restrict__ T, int64_t ldt,
+                                                            const bf16_t* __restrict__ Bw, int64_t ldb, float s, int64_t M, int N,
+                                                            int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * 64 + (wave & 1) * 32;
+    const int n0 = blockIdx.y * 256 + (wave >> 1) * 128;
+    if (m0 >= M || n0 >= N) return;
+    int64_t mr = m0 + (lane & 31);
+    const bool m_ok = mr < M;
+    mr = m_ok ? mr : M - 1;
+    bf16x8_t tf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) tf[ks] = *reinterpret_cast<const bf16x8_t*>(T + mr * ldt + ks * 16 + hi * 8);   // B operand: col = row m
+#pragma unroll
+    for (int cbi = 0; cbi < 4; ++cbi) {
+        const int nb = n0 + cbi * 32;
+        if (nb >= N) break;
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const bf16_t* bp = Bw + (int64_t)(nb + (lane & 31)) * ldb + hi * 8;                                         // A operand: row = out col n
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma32(*reinterpret_cast<const bf16x8_t*>(bp + ks * 16), tf[ks], acc);
+        if (m_ok) {
+            bf16_t* yp = Y + mr * ldy + nb + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t w;
+                float o[4] = {s * acc[4 * g], s * acc[4 * g + 1], s * acc[4 * g + 2], s * acc[4 * g + 3]};
+                if (accumulate) {
+                    w = *reinterpret_cast<const u32x2_t*>(yp + 8 * g);
+                    o[0] += bf16lo_to_f32(w[0]); o[1] += bf16hi_to_f32(w[0]);
+                    o[2] += bf16lo_to_f32(w[1]); o[3] += bf16hi_to_f32(w[1]);
+                }
+                w[0] = pack_bf16x2(o[0], o[1]);
+                w[1] = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<u32x2_t*>(yp + 8 * g) = w;
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// grad:  G[P,Q] += s * U^T V  over the token rows [blockIdx.y * rows_per_split, ...).  64x64 output tile per workgroup,
+// both operands are contracted over their ROW index -> hardware transpose reads of two row-major LDS tiles.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void lora_grad_kernel(const bf16_t* __restrict__ U, int64_t ldu, const bf16_t* __restrict__ V, int64_t ldv,
+                                                          float* __restrict__ G, int64_t ldg, float s, int64_t M, int P, int Q,
+                                                          int64_t rows_per_split, int n_qt) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];   // U[2], V[2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int pb = wave & 1, qb = wave >> 1;
+    const int p0 = (blockIdx.x / n_qt) * 64, q0 = (blockIdx.x % n_qt) * 64;
+    const int64_t mbeg = (int64_t)blockIdx.y * rows_per_split;
+    int64_t mend = mbeg + rows_per_split;
+    mend = mend < M ? mend : M;
+    if (mbeg >= mend) return;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    u32x4_t ur[2], vr[2];
+    const int nt = (int)((mend - mbeg + 63) / 64);
+    tile_load_zfill(U, ldu, mbeg, mend, p0, P, ur);
+    tile_load_zfill(V, ldv, mbeg, mend, q0, Q, vr);
+    tile_store(lds, ur);
+    tile_store(lds + 2 * TILE_ELEMS, vr);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const bf16_t* ul = lds + (t & 1) * TILE_ELEMS;
+        const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
+        if (t + 1 < nt) {
+            tile_load_zfill(U, ldu, mbeg + (int64_t)(t + 1) * 64, mend, p0, P, ur);
+            tile_load_zfill(V, ldv, mbeg + (int64_t)(t + 1) * 64, mend, q0, Q, vr);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc = mfma32(frag_tr(ul, 16 * kc, pb * 32, lane), frag_tr(vl, 16 * kc, qb * 32, lane), acc);
+        if (t + 1 < nt) {
+            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, ur);
+            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, vr);
+        }
+        __syncthreads();
+    }
+    const int q = q0 + qb * 32 + (lane & 31);
+    if (q < Q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + pb * 32 + acc_row(r, hi);
+            if (p < P) atomicAdd(&G[(int64_t)p * ldg + q], s * acc[r]);
+        }
+    }
+}
+
+static inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" {
+
+// T[M,R] = X[M,K] A[R,K]^T  (bf16; X row stride ldx, T row stride ldt; K % 64 == 0; R <= 256; ldx, ldt, K multiples of 8)
+int32_t vgpa_lora_down(const void* X, int64_t ldx, const void* A, void* T, int64_t ldt, int64_t M, int64_t K, int64_t R, hipStream_t stream) {
+    if (!X || !A || !T || M <= 0 || K <= 0 || K % 64 != 0 || R <= 0 || R > 256 || ldx % 8 || ldt % 8 || ldt < R || !a16(X) || !a16(A)) return VGPA_ERR_INVALID;
+    if (M > ((int64_t)1 << 31) * 32) return VGPA_ERR_INVALID;
+    const int ncb = (int)((R + 31) / 32);
+    const dim3 grid((unsigned)((M + 63) / 64));
+    const size_t shmem = (size_t)2 * (64 + 32 * ncb) * PITCH * sizeof(bf16_t);
+#define LD(N)                                                                                                                      \
+    if (hipFuncSetAttribute((const void*)lora_down_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) \
+        return VGPA_ERR_LAUNCH;                                                                                                    \
+    VGPA_LAUNCH((lora_down_kernel<N>), grid, dim3(256), shmem, stream, (const bf16_t*)X, ldx, (const bf16_t*)A, (bf16_t*)T, ldt, M, (int)K, (int)R)
+    switch (ncb) {
+        case 1: LD(1); break; case 2: LD(2); break; case 3: LD(3); break; case 4: LD(4); break;
+        case 5: LD(5); break; case 6: LD(6); break; case 7: LD(7); break; case 8: LD(8); break;
+        default: return VGPA_ERR_INVALID;
+    }
+#undef LD
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// Y[M,N] = (accumulate ? Y : 0) + s * T[M,rp] Bw[N,rp]^T   (bf16; rp in {16,32,48,64,96,128,192}; N % 32 == 0; 8-byte aligned rows of Y)
+int32_t vgpa_lora_up_add(void* Y, int64_t ldy, const void* T, int64_t ldt, const void* Bw, int64_t ldb, float s, int64_t M, int64_t N,
+                         int64_t rp, int32_t accumulate, hipStream_t stream) {
+    if (!Y || !T || !Bw || M <= 0 || N <= 0 || N % 32 != 0 || ldy % 4 || ldt % 8 || ldb % 8 || !a16(T) || !a16(Bw) || ((uintptr_t)Y & 7))
+        return VGPA_ERR_INVALID;
+    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 255) / 256));
+#define UP(KS) VGPA_LAUNCH((lora_up_add_kernel<KS>), grid, dim3(256), 0, stream, (bf16_t*)Y, ldy, (const bf16_t*)T, ldt, (const bf16_t*)Bw, ldb, s, M, (int)N, (int)accumulate)
+    switch (rp) {
+        case 16: UP(1); break; case 32: UP(2); break; case 48: UP(3); break; case 64: UP(4); break;
+        case 96: UP(6); break; case 128: UP(8); break; case 192: UP(12); break;
+        default: return VGPA_ERR_INVALID;
+    }
+#undef UP
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// G[P,Q] (fp32, row stride ldg, caller-zeroed) += s * U[M,P]^T V[M,Q]   (bf16 operands, P, Q multiples of 8)
+int32_t vgpa_lora_grad(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M, int64_t P, int64_t Q,
+                       hipStream_t stream) {
+    if (!U || !V || !G || M <= 0 || P <= 0 || Q <= 0 || P % 8 || Q % 8 || ldu % 8 || ldv % 8 || !a16(U) || !a16(V)) return VGPA_ERR_INVALID;
+    const int n_pt = (int)((P + 63) / 64), n_qt = (int)((Q + 63) / 64);
+    int64_t splits = 1024 / ((int64_t)n_pt * n_qt);
+    if (splits < 1) splits = 1;
+    const int64_t max_splits = (M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    int64_t rows = (M + splits - 1) / splits;
+    rows = (rows + 63) / 64 * 64;
+    splits = (M + rows - 1) / rows;
+    VGPA_LAUNCH(lora_grad_kernel, dim3((unsigned)(n_pt * n_qt), (unsigned)splits), dim3(256), 0, stream, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
+                G, ldg, s, M, (int)P, (int)Q, rows, n_qt);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+}  // extern "C"

@@ -245,11 +245,44 @@ def gelu_tanh(u):
 
 
 # --------------------------------------------------------------------------------------------- linear (+ LoRA)
+def _pad_rank(r):
+    rp = 16
+    while rp < r:
+        rp *= 2
+    return rp
+
+
+def lora_down(x2, a_cat, out=None):
+    """T[M,R] = x2[M,K] @ a_cat[R,K]^T on MFMA (x2 may be a column slice: row stride = x2.stride(0))."""
+    M, K = x2.shape
+    R = a_cat.shape[0]
+    t = torch.empty(M, R, dtype=torch.bfloat16, device=x2.device) if out is None else out
+    _timed("lora_down_kernel", 2.0 * M * K, lambda: _lib.call("vgpa_lora_down", x2, x2.stride(0), a_cat, t, t.stride(0), M, K, R, _stream()))
+    return t
+
+
+def lora_up_add(y2, t, bw, s, accumulate=True):
+    """y2[M,N] (+)= s * t[M,rp] @ bw[N,rp]^T in place (y2 / t may be column slices)."""
+    M, N = y2.shape
+    _timed("lora_up_add_kernel", 4.0 * M * N, lambda: _lib.call("vgpa_lora_up_add", y2, y2.stride(0), t, t.stride(0), bw, bw.stride(0), float(s),
+                                                                  M, N, t.shape[1], 1 if accumulate else 0, _stream()))
+
+
+def lora_grad(u, v, s=1.0):
+    """fp32 G[P,Q] = s * u[M,P]^T @ v[M,Q] (contraction over tokens)."""
+    M, P = u.shape
+    Q = v.shape[1]
+    g = torch.zeros(P, Q, dtype=torch.float32, device=u.device)
+    _timed("lora_grad_kernel", 2.0 * M * (P + Q), lambda: _lib.call("vgpa_lora_grad", u, u.stride(0), v, v.stride(0), g, Q, float(s), M, P, Q, _stream()))
+    return g
+
+
 class _LinearLoraFn(torch.autograd.Function):
     """y = x W^T + b, and for every output slice i that carries an adapter:  y_i += s_i * (x A_i^T) B_i^T
     (PEFT Linear.forward; adapters are fp32 parameters cast to the activation dtype at use).  W/b are frozen:
-    backward produces dx and the adapter gradients only.  One autograd node for the whole projection, so the
-    rank-r updates go straight into column slices of y / dx without autograd's CopySlices round trips."""
+    backward produces dx and the adapter gradients only.  The dense projection goes to hipBLASLt; every LoRA
+    contraction runs the hand-written MFMA kernels of csrc/lora.hip, in place on column slices of y / dx, with one
+    shared down-projection for all adapters that read the same input (q, k, v)."""
 
     @staticmethod
     def forward(ctx, x, W, bias, n_slices, scalings, *AB):
@@ -259,43 +292,49 @@ class _LinearLoraFn(torch.autograd.Function):
         x2 = x.reshape(-1, K)
         y = torch.nn.functional.linear(x2, W, bias)
         Dn = y.shape[1] // n_slices
-        saved, ts = [], []
-        for i in range(n_slices):
+        act = [i for i in range(n_slices) if AB[2 * i] is not None]
+        r = AB[2 * act[0]].shape[0]
+        rp = _pad_rank(r)
+        dt = x.dtype
+        a_cat = torch.zeros(len(act) * rp, K, dtype=dt, device=x.device)
+        bws = []
+        for j, i in enumerate(act):
             A, Bm = AB[2 * i], AB[2 * i + 1]
-            if A is None:
-                saved += [None, None]
-                ts.append(None)
-                continue
-            Ab, Bb = A.to(x.dtype), Bm.to(x.dtype)
-            t = x2 @ Ab.t()
-            y[:, i * Dn:(i + 1) * Dn].addmm_(t, Bb.t(), alpha=scalings[i])
-            saved += [Ab, Bb]
-            ts.append(t)
-        ctx.save_for_backward(x2, W, *saved, *ts)
-        ctx.meta = (n_slices, scalings, x.shape, [a is not None for a in AB[0::2]])
+            if A.shape[0] != r:
+                raise RuntimeError("adapters on one projection must share a rank")
+            a_cat[j * rp:j * rp + r] = A.to(dt)
+            bw = torch.zeros(Dn, rp, dtype=dt, device=x.device)
+            bw[:, :r] = Bm.to(dt)
+            bws.append(bw)
+        t = lora_down(x2, a_cat)
+        for j, i in enumerate(act):
+            lora_up_add(y[:, i * Dn:(i + 1) * Dn], t[:, j * rp:(j + 1) * rp], bws[j], scalings[i])
+        ctx.save_for_backward(x2, W, a_cat, t, *bws)
+        ctx.meta = (n_slices, scalings, x.shape, act, r, rp)
         return y.view(*x.shape[:-1], y.shape[1])
 
     @staticmethod
     def backward(ctx, dy):
-        n, scalings, xshape, has = ctx.meta
-        sv = ctx.saved_tensors
-        x2, W = sv[0], sv[1]
-        ABs, ts = sv[2:2 + 2 * n], sv[2 + 2 * n:]
+        n, scalings, xshape, act, r, rp = ctx.meta
+        x2, W, a_cat, t = ctx.saved_tensors[:4]
+        bws = ctx.saved_tensors[4:]
         dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
         Dn = dy2.shape[1] // n
         dx = dy2 @ W
-        grads = []
-        for i in range(n):
-            if not has[i]:
-                grads += [None, None]
-                continue
-            Ab, Bb, t, s = ABs[2 * i], ABs[2 * i + 1], ts[i], scalings[i]
+        M = dy2.shape[0]
+        dT = torch.empty(M, len(act) * rp, dtype=dy2.dtype, device=dy2.device)
+        grads = [None] * (2 * n)
+        for j, i in enumerate(act):
             dyi = dy2[:, i * Dn:(i + 1) * Dn]
-            dt = (dyi @ Bb) * s                       # [M, r]
-            dB = (dyi.t() @ t) * s                    # [out, r]
-            dA = dt.t() @ x2                          # [r, in]
-            dx.addmm_(dt, Ab)
-            grads += [dA.float(), dB.float()]
+            s = scalings[i]
+            lora_down(dyi, (bws[j] * s).t().contiguous(), out=dT[:, j * rp:(j + 1) * rp])       # dT_i = s * dy_i B_i
+            grads[2 * i + 1] = lora_grad(dyi, t[:, j * rp:(j + 1) * rp], s)[:, :r]               # dB_i = s * dy_i^T T_i
+        dA = lora_grad(dT, x2)                                                                     # dA = dT^T x (all adapters at once)
+        for j, i in enumerate(act):
+            grads[2 * i] = dA[j * rp:j * rp + r]
+        lora_up_add(dx, dT, a_cat.t().contiguous(), 1.0)                                           # dx += dT A
         return (dx.view(xshape), None, None, None, None, *grads)
 
 
