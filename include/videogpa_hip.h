@@ -108,7 +108,7 @@ int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o
 /* ---- LoRA A.B contractions (peft Linear.forward `lora_B(lora_A(x)) * scaling` and its backward for the adapters of
  * train/CogVideoX-5B/03_train.py:102-106).  bf16 row-major operands with explicit row strides (elements).
  *   down  : T[M,R]  = X[M,K] A[R,K]^T                     K % 64 == 0, R <= 256
- *   up_add: Y[M,N]  = (accumulate ? Y : 0) + s * T[M,rp] Bw[N,rp]^T   rp in {16,32,48,64,96,128,192}, N % 32 == 0
+ *   up_add: Y[M,N]  = (accumulate ? Y : 0) + s * T[M,rp] Bw[N,rp]^T   rp in {16,32,48,64,96,128,192}, N % 8 == 0
  *   grad  : G[P,Q] += s * U[M,P]^T V[M,Q]                 G fp32, caller-zeroed (fp32 atomics) */
 int32_t vgpa_lora_down(const void* X, int64_t ldx, const void* A, void* T, int64_t ldt, int64_t M, int64_t K, int64_t R,
                        vgpa_stream_t stream);

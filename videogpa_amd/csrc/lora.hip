@@ -115,48 +115,63 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
 }
 
 // =====================================================================================================
-// up_add:  Y (+)= s * T Bw^T.   No LDS: T / Bw fragments come straight from L2 (both are tiny), each wave owns a
-// 32-row x 128-column strip of Y and read-modify-writes it in 8-byte row-contiguous pieces.
+// up_add:  Y (+)= s * T Bw^T.   T / Bw fragments come straight from L2 (both are tiny).  A workgroup owns a
+// 64-row x 128-column block of Y: the four waves put their s*T*Bw^T sub-blocks into an fp32 LDS tile, then all 256
+// threads read-modify-write Y in 16-byte row-contiguous pieces (the 436 MB RMW of Y is the whole cost of this op).
 // =====================================================================================================
+#define UP_COLS 128
+#define UP_PITCH (UP_COLS + 4)   // fp32 words per LDS row (+4: conflict-free 16-byte writes down a column of rows)
 template <int KS>
 __global__ __launch_bounds__(256) void lora_up_add_kernel(bf16_t* __restrict__ Y, int64_t ldy, const bf16_t* __restrict__ T, int64_t ldt,
                                                             const bf16_t* __restrict__ Bw, int64_t ldb, float s, int64_t M, int N,
                                                             int accumulate) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * UP_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * 64 + (wave & 1) * 32;
-    const int n0 = blockIdx.y * 256 + (wave >> 1) * 128;
-    if (m0 >= M || n0 >= N) return;
-    int64_t mr = m0 + (lane & 31);
-    const bool m_ok = mr < M;
-    mr = m_ok ? mr : M - 1;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * UP_COLS;
+    const int rb = wave & 1, cg = wave >> 1;                       // wave: 32 rows x 64 cols of the block
+    int64_t mr = m0 + rb * 32 + (lane & 31);
+    mr = mr < M ? mr : M - 1;
     bf16x8_t tf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) tf[ks] = *reinterpret_cast<const bf16x8_t*>(T + mr * ldt + ks * 16 + hi * 8);   // B operand: col = row m
 #pragma unroll
-    for (int cbi = 0; cbi < 4; ++cbi) {
-        const int nb = n0 + cbi * 32;
-        if (nb >= N) break;
+    for (int cbi = 0; cbi < 2; ++cbi) {
+        const int nl = cg * 64 + cbi * 32;                          // local column of this 32x32 block
+        int nrow = n0 + nl + (lane & 31);
+        nrow = nrow < N ? nrow : N - 1;
         f32x16_t acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const bf16_t* bp = Bw + (int64_t)(nb + (lane & 31)) * ldb + hi * 8;                                         // A operand: row = out col n
+        const bf16_t* bp = Bw + (int64_t)nrow * ldb + hi * 8;                                                         // A operand: row = out col n
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = mfma32(*reinterpret_cast<const bf16x8_t*>(bp + ks * 16), tf[ks], acc);
-        if (m_ok) {
-            bf16_t* yp = Y + mr * ldy + nb + 4 * hi;
+        for (int ks = 0; ks < KS; ++ks) acc = mfma32(*reinterpret_cast<const bf16x8_t*>(bp + ks * 16), tf[ks], acc);  // D[n][m]
+        float* tp = tile + (rb * 32 + (lane & 31)) * UP_PITCH + nl + 4 * hi;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2_t w;
-                float o[4] = {s * acc[4 * g], s * acc[4 * g + 1], s * acc[4 * g + 2], s * acc[4 * g + 3]};
-                if (accumulate) {
-                    w = *reinterpret_cast<const u32x2_t*>(yp + 8 * g);
-                    o[0] += bf16lo_to_f32(w[0]); o[1] += bf16hi_to_f32(w[0]);
-                    o[2] += bf16lo_to_f32(w[1]); o[3] += bf16hi_to_f32(w[1]);
-                }
-                w[0] = pack_bf16x2(o[0], o[1]);
-                w[1] = pack_bf16x2(o[2], o[3]);
-                *reinterpret_cast<u32x2_t*>(yp + 8 * g) = w;
+        for (int g = 0; g < 4; ++g) {
+            f32x4_t v = {s * acc[4 * g], s * acc[4 * g + 1], s * acc[4 * g + 2], s * acc[4 * g + 3]};
+            *reinterpret_cast<f32x4_t*>(tp + 8 * g) = v;
+        }
+    }
+    __syncthreads();
+    // 64 rows x 16 chunks of 8 columns = 1024 chunks, 4 per thread; 16 consecutive lanes cover 256 contiguous bytes of a row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        const int row = c >> 4, col = (c & 15) * 8;
+        const int64_t m = m0 + row;
+        if (m < M && n0 + col < N) {
+            const float* tp = tile + row * UP_PITCH + col;
+            const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(tp), a1 = *reinterpret_cast<const f32x4_t*>(tp + 4);
+            float o[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            bf16_t* yp = Y + m * ldy + n0 + col;
+            if (accumulate) {
+                float y[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(yp), y);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += y[i];
             }
+            *reinterpret_cast<u32x4_t*>(yp) = pack8(o);
         }
     }
 }
@@ -236,12 +251,12 @@ int32_t vgpa_lora_down(const void* X, int64_t ldx, const void* A, void* T, int64
     return VGPA_OK;
 }
 
-// Y[M,N] = (accumulate ? Y : 0) + s * T[M,rp] Bw[N,rp]^T   (bf16; rp in {16,32,48,64,96,128,192}; N % 32 == 0; 8-byte aligned rows of Y)
+// Y[M,N] = (accumulate ? Y : 0) + s * T[M,rp] Bw[N,rp]^T   (bf16; rp in {16,32,48,64,96,128,192}; N % 8 == 0; 16-byte aligned rows of Y)
 int32_t vgpa_lora_up_add(void* Y, int64_t ldy, const void* T, int64_t ldt, const void* Bw, int64_t ldb, float s, int64_t M, int64_t N,
                          int64_t rp, int32_t accumulate, hipStream_t stream) {
-    if (!Y || !T || !Bw || M <= 0 || N <= 0 || N % 32 != 0 || ldy % 4 || ldt % 8 || ldb % 8 || !a16(T) || !a16(Bw) || ((uintptr_t)Y & 7))
+    if (!Y || !T || !Bw || M <= 0 || N <= 0 || N % 8 != 0 || ldy % 8 || ldt % 8 || ldb % 8 || !a16(T) || !a16(Bw) || !a16(Y))
         return VGPA_ERR_INVALID;
-    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 255) / 256));
+    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + UP_COLS - 1) / UP_COLS));
 #define UP(KS) VGPA_LAUNCH((lora_up_add_kernel<KS>), grid, dim3(256), 0, stream, (bf16_t*)Y, ldy, (const bf16_t*)T, ldt, (const bf16_t*)Bw, ldb, s, M, (int)N, (int)accumulate)
     switch (rp) {
         case 16: UP(1); break; case 32: UP(2); break; case 48: UP(3); break; case 64: UP(4); break;
