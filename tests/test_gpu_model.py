@@ -156,3 +156,61 @@ def test_adapter_roundtrip_and_merge(tmp_path):
     assert torch.equal(y, y2)
     sc = y.float().abs().max().item()
     assert (y3.float() - y.float()).abs().max().item() < 0.03 * sc     # merged weights are re-rounded to bf16
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs 3 / 4 geometry
+def _variant(kw_extra, B=1, F=4, C_in=16, seed=0):
+    from videogpa_amd.transformer import CogVideoXTransformer3DModel
+    kw = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=32, text_embed_dim=48, sample_width=8,
+              sample_height=8, sample_frames=13, max_text_seq_length=6, in_channels=C_in)
+    kw.update(kw_extra)
+    cfg = ocv.CogVideoXConfig(**kw)
+    sd = {k: v.to(torch.bfloat16) for k, v in ocv.init_state_dict(cfg, seed=seed, std=0.05, mod_std=0.2).items()}
+    model = CogVideoXTransformer3DModel(**dict(kw, use_rotary_positional_embeddings=True))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(device="cuda", dtype=torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(seed)
+    x = (0.7 * torch.randn(B, F, C_in, 8, 8, generator=g)).to(torch.bfloat16)
+    txt = (0.5 * torch.randn(B, 6, 48, generator=g)).to(torch.bfloat16)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        y = model(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
+    yr = ocv.forward({k: v.double() for k, v in sd.items()}, cfg, x.double(), txt.double(), t)
+    return y, yr
+
+
+def test_i2v_geometry_32ch_learned_positions():
+    """config 3: 16 noisy + 16 image-condition channels in, 16 out, learned positional table
+    (train/CogVideoX-I2V-5B/03_train.py:135-136)."""
+    y, yr = _variant(dict(use_learned_positional_embeddings=True), C_in=32)
+    assert tuple(y.shape) == (1, 4, 16, 8, 8)
+    assert (y.double().cpu() - yr).abs().max().item() < 0.03 * yr.abs().max().item()
+
+
+def test_cogvideox15_geometry_temporal_patch():
+    """config 4: patch_size_t = 2, linear patch embed without bias, (F/2) x h x w tokens
+    (train/CogVideoX1.5-5B/03_train.py:131-142 crops F to even first)."""
+    y, yr = _variant(dict(patch_size_t=2, patch_bias=False), F=4)
+    assert tuple(y.shape) == (1, 4, 16, 8, 8)
+    assert (y.double().cpu() - yr).abs().max().item() < 0.03 * yr.abs().max().item()
+
+
+def test_i2v_pair_step_with_condition_channels():
+    from videogpa_amd.lora import LoraConfig, get_peft_model
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    from videogpa_amd.transformer import CogVideoXTransformer3DModel
+    kw = dict(num_attention_heads=2, attention_head_dim=64, num_layers=1, time_embed_dim=32, text_embed_dim=48, sample_width=8,
+              sample_height=8, sample_frames=9, max_text_seq_length=6, in_channels=32, use_rotary_positional_embeddings=True,
+              use_learned_positional_embeddings=True)
+    model = CogVideoXTransformer3DModel(**kw).to(device="cuda", dtype=torch.bfloat16)
+    pm = get_peft_model(model, LoraConfig(r=4, lora_alpha=8, target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    tr = CogVideoXDPOTrainer({"beta": 1.0}, transformer=pm)
+    g = torch.Generator().manual_seed(0)
+    x_pair = (0.7 * torch.randn(2, 2, 3, 16, 8, 8, generator=g)).to(torch.bfloat16).cuda()
+    img = (0.7 * torch.randn(2, 1, 16, 8, 8, generator=g)).to(torch.bfloat16).cuda()
+    cond = torch.cat([img, torch.zeros(2, 2, 16, 8, 8, dtype=torch.bfloat16, device="cuda")], dim=1)   # zero-padded to F frames (:127-128)
+    cond_pair = torch.stack([cond, cond], dim=1)
+    txt = (0.5 * torch.randn(2, 6, 48, generator=g)).to(torch.bfloat16).cuda()
+    out = tr.shared_step_paired(x_pair, txt, cond_pair=cond_pair)
+    assert abs(out.loss.item() - math.log(2.0)) < 1e-6      # LoRA B = 0
+    out.loss.backward()

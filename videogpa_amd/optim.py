@@ -7,6 +7,7 @@ message keeps every xGMI link busy instead of 11 latency-bound 25 MB buckets), a
 fused HIP kernel (global-norm + clip + AdamW) with no host synchronisation.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -80,7 +81,7 @@ class FlatAdamW:
 
     def all_reduce_grads(self):
         """SUM all-reduce of the flat gradient on a side stream; the 1/world mean is folded into the step."""
-        if self.world() == 1:
+        if self.world() == 1 and os.environ.get("VGPA_FORCE_DIST") != "1":
             return None
         g = self.flat.grad
         if g.is_cuda:
