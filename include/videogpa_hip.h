@@ -70,12 +70,13 @@ int32_t vgpa_gelu_tanh_bwd(const void* u, const void* dy, int64_t n, void* du, v
 
 /* ---- QK-norm (LayerNorm over head_dim 64) + 3D RoPE (attn.norm_q/norm_k, apply_rotary_emb in
  * CogVideoXAttnProcessor2_0; RoPE only when image_rotary_emb is given: generate/CogVideoX-5B.py:72-77).
- * rope_cos/rope_sin: fp32 [S - text_len, 64] or NULL. */
+ * rope_cos/rope_sin: fp32 [S - text_len, 64] or NULL.  q_out is additionally multiplied by q_out_scale (the attention
+ * kernels take q pre-multiplied by scale*log2(e)); the backward returns d/d(q_in) for the UNscaled normalised query. */
 int32_t vgpa_qknorm_rope_fwd(const void* q_in, const void* k_in, void* q_out, void* k_out, const int64_t* qin_strides,
                              const int64_t* kin_strides, const int64_t* qout_strides, const int64_t* kout_strides,
                              const float* wq, const float* bq, const float* wk, const float* bk, const float* rope_cos,
                              const float* rope_sin, int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim,
-                             float eps, vgpa_stream_t stream);
+                             float eps, float q_out_scale, vgpa_stream_t stream);
 int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void* q_in, const void* k_in, void* dq_in,
                              void* dk_in, const int64_t* dqout_strides, const int64_t* dkout_strides,
                              const int64_t* qin_strides, const int64_t* kin_strides, const int64_t* dqin_strides,
@@ -84,7 +85,8 @@ int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void*
                              float eps, vgpa_stream_t stream);
 
 /* ---- 3D full attention, non-causal, head_dim 64 (F.scaled_dot_product_attention in the same processor) ----------
- * lse2 = log2 sum_k exp2(scale*log2(e) * q.k), fp32 [B,H,S]; delta = rowsum(dO * O), fp32 [B,H,S]. */
+ * CONTRACT: q is PRE-MULTIPLIED by scale*log2(e) in every entry point below; dq is the gradient w.r.t. the unscaled q.
+ * lse2 = log2 sum_k exp2(q.k), fp32 [B,H,S]; delta = rowsum(dO * O), fp32 [B,H,S]. */
 int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
                       const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H,
                       int64_t S, int64_t head_dim, float scale, vgpa_stream_t stream);

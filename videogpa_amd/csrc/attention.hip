@@ -31,13 +31,41 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // =====================================================================================================
 // Forward:  O = softmax(scale * Q K^T) V ;  lse2 = log2 sum_k exp2(scale*log2e * q.k)
 // =====================================================================================================
-// QB = 32-row query blocks per wave.  QB = 2 halves the LDS reads, tile staging and loop overhead per MFMA (the
-// kernel is instruction-issue bound: ~9 VALU + 2 LDS instructions per MFMA at QB = 1), at 2 waves/SIMD.
+// bf16x8 fragment <-> 8 floats
+__device__ __forceinline__ void frag_to_f32(const bf16x8_t& f, float* o) {
+    const u32x4_t u = __builtin_bit_cast(u32x4_t, f);
+    unpack8(u, o);
+}
+__device__ __forceinline__ bf16x8_t f32_to_frag(const float* o) { return __builtin_bit_cast(bf16x8_t, pack8(o)); }
+
+// The "-m" operand of the folded softmax shift: -m = a1 + a2 + a3 exactly enough (3 bf16 pieces = 24 mantissa bits),
+// living in k-slots 0..2 of an extra MFMA k-step whose K-side operand is (1,1,1,0,...): the QK^T accumulators then
+// come out as  c*q.k - m  and go straight into exp2.
+__device__ __forceinline__ bf16x8_t shift_frag(float m, int hi) {
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (hi == 0) {
+        const float t = -m;
+        const float a1 = round_bf16(t), a2 = round_bf16(t - a1), a3 = round_bf16((t - a1) - a2);
+        o[0] = a1; o[1] = a2; o[2] = a3;
+    }
+    return f32_to_frag(o);
+}
+
+#define PSUM_TRIGGER 1024.0f   // a half-lane tile sum above this (or inf/NaN) means some score outgrew the running max by > ~2^5
+
+// QB = 32-row query blocks per wave.
+// Softmax bookkeeping is kept off the VALU (the kernel is VALU-issue bound at head_dim 64):
+//  * Q arrives pre-scaled by scale*log2(e) (vgpa_qknorm_rope_fwd's q_out_scale; one rounding), and -m (running max)
+//    is folded into the QK^T MFMA chain by one extra k-step, so P = exp2(accumulator) with no per-score FMA;
+//  * the per-tile row max is NOT computed on the fast path: P is formed optimistically against the current m and the
+//    tile's partial sum is checked; only when a wave sees a sum above PSUM_TRIGGER (always on the first tile) does it
+//    take the slow path: recompute S, take the true max, raise m, rescale O and l (wave-uniform, so both half-lanes
+//    of a row always share one m).  P stays <= ~2^10, harmless in bf16 / fp32.
 template <int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                          float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
-                                                         int S, int H, int n_qt, float c /* scale*log2(e) */) {
+                                                         int S, int H, int n_qt) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // K[2], V[2]
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = vid / n_qt, qt = vid % n_qt;
@@ -49,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
     const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
 
-    bf16x8_t qf[QB][4];
+    bf16x8_t qf[QB][4], qx[QB];
     f32x16_t o[QB][2];
     float m[QB], l[QB];
 #pragma unroll
@@ -59,6 +87,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
         m[j] = -INFINITY;
         l[j] = 0.f;
+        qx[j] = shift_frag(0.f, hi);
+    }
+    bf16x8_t kx;   // K-side of the shift k-step: ones in k-slots 0..2 of the lower half-lanes
+    {
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
+        kx = f32_to_frag(o8);
     }
 
     const int nt = (S + TILE - 1) / TILE;
@@ -76,65 +111,99 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             tile_load(Kb, sk.s, (t + 1) * TILE, S, kr);
             tile_load(Vb, sv.s, (t + 1) * TILE, S, vr);
         }
-        // S^T[key, q] for the two 32-key blocks; each K fragment feeds all QB query blocks
+        const bool tail = (t == nt - 1) && (S & (TILE - 1));
         f32x16_t s[QB][2];
+        float psum[QB];
+        bool slow = (t == 0);
+        if (!slow) {
+            // fast path: accumulators = c*q.k - m  ->  P = exp2(.)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int j = 0; j < QB; ++j)
+                for (int j = 0; j < QB; ++j) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
+                    for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
+                    s[j][kb] = mfma32(kx, qx[j], s[j][kb]);
+                }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
 #pragma unroll
-                for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
+                    for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
+                }
             }
-        }
-        if (t == nt - 1 && (S & (TILE - 1))) {
-            const int kbase = t * TILE;
 #pragma unroll
-            for (int j = 0; j < QB; ++j)
+            for (int j = 0; j < QB; ++j) {
+                f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kbase + kb * 32 + acc_row(r, hi) >= S) s[j][kb][r] = -INFINITY;
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2_t p = {__builtin_amdgcn_exp2f(s[j][kb][r]), __builtin_amdgcn_exp2f(s[j][kb][r + 1])};
+                        if (tail) {
+                            if (t * TILE + kb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
+                            if (t * TILE + kb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
+                        }
+                        s[j][kb][r] = p[0];
+                        s[j][kb][r + 1] = p[1];
+                        ps2 += p;
+                    }
+                psum[j] = ps2[0] + ps2[1];
+                slow = slow || !(psum[j] <= PSUM_TRIGGER);
+            }
+            slow = __any(slow);
         }
-        const f32x2_t c2 = {c, c};
+        if (slow) {
+            // slow path (first tile, or a row outgrew its running max): exact max, raise m, rescale
 #pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            float mx = s[j][0][0];
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[j][0][r]);
+                for (int j = 0; j < QB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][1][r]);
-            // lazy rescale: raise the running max (and rescale O, l) only when some row of this wave outgrows it by
-            // 2^THR.  The decision is wave-uniform, so both half-lanes of a row always share one m.
-            if (__any(mx * c > m[j] + SOFTMAX_RESCALE_THR)) {
+                    for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                if (tail) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (t * TILE + kb * 32 + acc_row(r, hi) >= S) s[j][kb][r] = -INFINITY;
+                }
+                float mx = s[j][0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[j][0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][1][r]);
                 mx = fmaxf(mx, other_half(mx));
-                const float m_new = fmaxf(m[j], mx * c);
+                const float m_new = fmaxf(m[j], mx);
                 const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
                 m[j] = m_new;
+                qx[j] = shift_frag(m_new, hi);
                 l[j] *= alpha;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { o[j][0][i] *= alpha; o[j][1][i] *= alpha; }
+                float ps = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(s[j][kb][r] - m_new);
+                        s[j][kb][r] = p;
+                        ps += p;
+                    }
+                psum[j] = ps;
             }
-            const f32x2_t nm2 = {-m[j], -m[j]};
-            f32x2_t ps2 = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2_t v = {s[j][kb][r], s[j][kb][r + 1]};
-                    v = v * c2 + nm2;                                  // v_pk_fma_f32
-                    f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
-                    s[j][kb][r] = p[0];
-                    s[j][kb][r + 1] = p[1];
-                    ps2 += p;                                          // v_pk_add_f32
-                }
-            l[j] += ps2[0] + ps2[1];
         }
+#pragma unroll
+        for (int j = 0; j < QB; ++j) l[j] += psum[j];
         // O^T[d, q] += V^T[d, key] P^T[key, q]; each V fragment feeds all QB query blocks
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -211,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                             const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                             const float* __restrict__ LSE2, const float* __restrict__ DELTA,
                                                             bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo,
-                                                            TStride sdq, int S, int H, int n_qt, float c, float scale) {
+                                                            TStride sdq, int S, int H, int n_qt, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // K[2], V[2]
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = vid / n_qt, qt = vid % n_qt;
@@ -226,8 +295,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     load_row_frags(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0, S, lane, dof);
     int qc = q0 + (lane & 31);
     qc = qc < S ? qc : S - 1;
-    const float lse = LSE2[(int64_t)bh * S + qc];
     const float dlt = DELTA[(int64_t)bh * S + qc];
+    const bf16x8_t qx = shift_frag(LSE2[(int64_t)bh * S + qc], hi);   // -lse folded into the QK^T chain (see forward)
+    bf16x8_t kx;
+    {
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
+        kx = f32_to_frag(o8);
+    }
 
     f32x16_t dq[2];
 #pragma unroll
@@ -254,16 +329,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             f32x16_t s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            s = mfma32(kx, qx, s);                                                                       // - lse2[q]
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s);      // S^T[key,q]
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s);      // S^T[key,q] - lse2
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(vl, kb * 32, ks, lane), dof[ks], dp);   // dP^T[key,q]
-            const f32x2_t c2 = {c, c}, nl2 = {-lse, -lse}, nd2 = {-dlt, -dlt};
+            const f32x2_t nd2 = {-dlt, -dlt};
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                f32x2_t v = {s[r], s[r + 1]};
-                v = v * c2 + nl2;
-                f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
                 if (tail) {
                     if (t * TILE + kb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
                     if (t * TILE + kb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
@@ -309,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                              const float* __restrict__ LSE2, const float* __restrict__ DELTA,
                                                              bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, TStride sq, TStride sk,
                                                              TStride sv, TStride sdo, TStride sdk, TStride sdv, int S, int H, int n_kt,
-                                                             float c, float scale) {
+                                                             float kscale /* scale / (scale*log2e) = ln 2: Q is pre-scaled */) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // Q[2], dO[2]
     __shared__ __attribute__((aligned(16))) float stat[2][2][TILE];      // [buf][lse|delta][q]
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
@@ -379,13 +453,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 dl[g] = *reinterpret_cast<const f32x4_t*>(dlt_l + qb * 32 + 8 * g + 4 * hi);
             }
             f32x16_t ds;
-            const f32x2_t c2 = {c, c};
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32x2_t v = {s[r], s[r + 1]};
                 const f32x2_t l2 = {lv[r >> 2][r & 3], lv[r >> 2][(r & 3) + 1]};
                 const f32x2_t dl2 = {dl[r >> 2][r & 3], dl[r >> 2][(r & 3) + 1]};
-                v = v * c2 - l2;
+                v = v - l2;
                 f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
                 if (tail) {
                     if (t * TILE + qb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
@@ -425,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2_t w;
-                w[0] = pack_bf16x2(dk[db][4 * g] * scale, dk[db][4 * g + 1] * scale);
-                w[1] = pack_bf16x2(dk[db][4 * g + 2] * scale, dk[db][4 * g + 3] * scale);
+                w[0] = pack_bf16x2(dk[db][4 * g] * kscale, dk[db][4 * g + 1] * kscale);
+                w[1] = pack_bf16x2(dk[db][4 * g + 2] * kscale, dk[db][4 * g + 3] * kscale);
                 *reinterpret_cast<u32x2_t*>(kp + db * 32 + 8 * g + 4 * hi) = w;
                 w[0] = pack_bf16x2(dv[db][4 * g], dv[db][4 * g + 1]);
                 w[1] = pack_bf16x2(dv[db][4 * g + 2], dv[db][4 * g + 3]);
@@ -443,13 +516,18 @@ static inline bool range_ok(const int64_t* st, int64_t B, int64_t H, int64_t S) 
 static inline TStride mk(const int64_t* st) { TStride t; t.b = (uint32_t)st[0]; t.h = (uint32_t)st[1]; t.s = (uint32_t)st[2]; return t; }
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+#ifndef FWD_QB
 #define FWD_QB 2   // query blocks (of 32 rows) per wave in the forward kernel
+#endif
 #define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
 
 extern "C" {
 
 // All tensors are bf16 views [B, H, S, 64] given by element strides {batch, head, token} (last dim contiguous,
 // strides multiples of 8, base pointers 16-byte aligned).  lse2 / delta are fp32 [B, H, S] contiguous.
+// CONTRACT: q holds the queries PRE-MULTIPLIED by scale*log2(e) (vgpa_qknorm_rope_fwd writes them that way through
+// q_out_scale), in all four entry points; `scale` is still the softmax scale (used for the dQ / dK multipliers).
+// dq is the gradient w.r.t. the UNscaled query.
 int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
                       const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
                       int64_t head_dim, float scale, hipStream_t stream) {
@@ -460,8 +538,7 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
     VGPA_LAUNCH((attn_fwd_kernel<FWD_QB>), dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt,
-                scale * 1.4426950408889634f);
+                (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -497,7 +574,7 @@ int32_t vgpa_attn_bwd_dkv(const void* q, const void* k, const void* v, const voi
     const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
     VGPA_LAUNCH(attn_bwd_dkv_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides),
-                       mk(do_strides), mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, scale * 1.4426950408889634f, scale);
+                       mk(do_strides), mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, 0.6931471805599453f);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -513,7 +590,7 @@ int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void
     const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
     VGPA_LAUNCH(attn_bwd_dq_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides),
-                       mk(do_strides), mk(dq_strides), (int)S, (int)H, n_t, scale * 1.4426950408889634f, scale);
+                       mk(do_strides), mk(dq_strides), (int)S, (int)H, n_t, scale);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
                                                                 const float* __restrict__ bq, const float* __restrict__ wk,
                                                                 const float* __restrict__ bk, const float* __restrict__ rope_cos,
                                                                 const float* __restrict__ rope_sin, int text_len, int B, int H, int S,
-                                                                float eps) {
+                                                                float eps, float q_out_scale) {
     const int64_t nvec = (int64_t)B * S * H;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t vid = gid >> 3;
@@ -61,6 +61,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
             y[j] = a * cp[j] - bq2 * sp[j];
             y[j + 1] = bq2 * cp[j + 1] + a * sp[j + 1];
         }
+    }
+    if (!which) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] *= q_out_scale;   // attention wants q * scale * log2(e): fold it here, one rounding
     }
     *reinterpret_cast<u32x4_t*>(op + c8 * 8) = pack8(y);
 }
@@ -127,19 +131,20 @@ static inline QStride qmk(const int64_t* st) { QStride t; t.b = st[0]; t.h = st[
 
 extern "C" {
 
-// q_out/k_out = RoPE(LayerNorm_64(q_in/k_in)); every tensor is a bf16 [B,H,S,64] view given by element strides
+// q_out = q_out_scale * RoPE(LayerNorm_64(q_in)), k_out = RoPE(LayerNorm_64(k_in)); every tensor is a bf16 [B,H,S,64] view given by element strides
 // {batch, head, token}.  rope_cos/rope_sin: fp32 [S - text_len, 64] (pair-repeated, SURVEY A-2) or NULL.
 int32_t vgpa_qknorm_rope_fwd(const void* q_in, const void* k_in, void* q_out, void* k_out, const int64_t* qin_strides,
                              const int64_t* kin_strides, const int64_t* qout_strides, const int64_t* kout_strides, const float* wq,
                              const float* bq, const float* wk, const float* bk, const float* rope_cos, const float* rope_sin,
-                             int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim, float eps, hipStream_t stream) {
+                             int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim, float eps, float q_out_scale,
+                             hipStream_t stream) {
     if (!q_in || !k_in || !q_out || !k_out || !wq || !bq || !wk || !bk || head_dim != 64 || B <= 0 || H <= 0 || S <= 0) return VGPA_ERR_INVALID;
     if (!qs_ok(qin_strides) || !qs_ok(kin_strides) || !qs_ok(qout_strides) || !qs_ok(kout_strides)) return VGPA_ERR_INVALID;
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
     const int64_t threads = 2 * B * S * H * 8;
     VGPA_LAUNCH(qknorm_rope_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)q_in,
                        (const bf16_t*)k_in, (bf16_t*)q_out, (bf16_t*)k_out, qmk(qin_strides), qmk(kin_strides), qmk(qout_strides),
-                       qmk(kout_strides), wq, bq, wk, bk, rope_cos, rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps);
+                       qmk(kout_strides), wq, bq, wk, bk, rope_cos, rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps, q_out_scale);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

@@ -392,10 +392,22 @@ def _timed(name, work, fn):
         TIMER.run(name, work, fn)
 
 
-def attention_fwd_raw(q, k, v, scale=None):
+LOG2E = 1.4426950408889634
+
+
+def prescale_q(q, scale=None):
+    """The attention kernels take q * scale * log2(e) (one bf16 rounding).  The fused path gets it from the QK-norm
+    kernel; this helper is for callers holding a plain q."""
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    return (q.float() * (scale * LOG2E)).to(q.dtype)
+
+
+def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False):
     """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32."""
     B, H, S, Dh = q.shape
     scale = Dh ** -0.5 if scale is None else scale
+    if not q_prescaled:
+        q = prescale_q(q, scale)
     o = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=q.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
@@ -405,12 +417,14 @@ def attention_fwd_raw(q, k, v, scale=None):
     return o, lse
 
 
-def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None):
+def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False):
     """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.
     Algorithmic FLOPs (backward = 2 x forward): dK/dV kernel carries dV, dP, dK = 6 S^2 d; dQ kernel 2 S^2 d
     (the S = QK^T recomputes in both kernels and the second dP are overhead, not counted)."""
     B, H, S, Dh = q.shape
     scale = Dh ** -0.5 if scale is None else scale
+    if not q_prescaled:
+        q = prescale_q(q, scale)
     delta = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     st = _stream()
     _lib.call("vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st)
@@ -436,8 +450,8 @@ class _QKNormAttentionFn(torch.autograd.Function):
         qn = torch.empty(B, H, S, Dh, dtype=torch.bfloat16, device=qkv.device)
         kn = torch.empty_like(qn)
         _lib.call("vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
-                  wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), _stream())
-        o, lse = attention_fwd_raw(qn, kn, v)
+                  wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), _stream())
+        o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True)
         ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
         ctx.meta = (text_len, H, eps)
         return o
@@ -458,7 +472,7 @@ class _QKNormAttentionFn(torch.autograd.Function):
         dkn = torch.empty_like(kn)
         ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
         dov = do.view(B, S, H, Dh).permute(0, 2, 1, 3)
-        attention_bwd_raw(qn, kn, v, ov, dov, lse, dqn, dkn, dv)
+        attention_bwd_raw(qn, kn, v, ov, dov, lse, dqn, dkn, dv, q_prescaled=True)
         _lib.call("vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
                   _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
                   float(eps), _stream())
