@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     load_row_frags(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0, S, lane, dof);
     int qc = q0 + (lane & 31);
     qc = qc < S ? qc : S - 1;
-    const float dlt = DELTA[(int64_t)bh * S + qc];
     const bf16x8_t qx = shift_frag(LSE2[(int64_t)bh * S + qc], hi);   // -lse folded into the QK^T chain (see forward)
+    const bf16x8_t dx = shift_frag(DELTA[(int64_t)bh * S + qc], hi);  // -delta folded into the dP chain
     bf16x8_t kx;
     {
         float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -332,9 +332,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             s = mfma32(kx, qx, s);                                                                       // - lse2[q]
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s);      // S^T[key,q] - lse2
+            dp = mfma32(kx, dx, dp);                                                                     // - delta[q]
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(vl, kb * 32, ks, lane), dof[ks], dp);   // dP^T[key,q]
-            const f32x2_t nd2 = {-dlt, -dlt};
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(vl, kb * 32, ks, lane), dof[ks], dp);   // dP^T[key,q] - delta
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                     if (t * TILE + kb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
                 }
                 f32x2_t d = {dp[r], dp[r + 1]};
-                d = (d + nd2) * p;                                                                       // dS^T
+                d = d * p;                                                                               // dS^T
                 s[r] = d[0];
                 s[r + 1] = d[1];
             }
@@ -384,8 +384,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                              bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, TStride sq, TStride sk,
                                                              TStride sv, TStride sdo, TStride sdk, TStride sdv, int S, int H, int n_kt,
                                                              float kscale /* scale / (scale*log2e) = ln 2: Q is pre-scaled */) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // Q[2], dO[2]
-    __shared__ __attribute__((aligned(16))) float stat[2][2][TILE];      // [buf][lse|delta][q]
+    // Q[2], dO[2] tiles.  The 8 padding columns (64..71) of every row carry the row's softmax statistics as three bf16
+    // pieces (-lse in the Q tile, -delta in the dO tile); one extra MFMA k-step against a (1,1,1,0,...) operand folds
+    // them into the S and dP accumulators, so P = exp2(acc) and dS = P * acc with no per-score subtract.
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS + 16];
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = vid / n_kt, kt = vid % n_kt;
     const int b = bh / H, h = bh % H;
@@ -399,6 +401,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     bf16x8_t kf[4], vf[4];
     load_row_frags(K + ((size_t)b * sk.b + (size_t)h * sk.h), sk.s, k0, S, lane, kf);
     load_row_frags(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, k0, S, lane, vf);
+    bf16x8_t ones;   // B operand of the statistics k-step (the upper half-lanes read the next row's data: times 0)
+    {
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
+        ones = f32_to_frag(o8);
+    }
+    // everything the statistics k-step can touch must be finite: clear the whole LDS array once
+    for (int i = threadIdx.x; i < (4 * TILE_ELEMS + 16) / 8; i += 256) {
+        u32x4_t z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4_t*>(lds + i * 8) = z;
+    }
+    __syncthreads();
 
     f32x16_t dk[2], dv[2];
 #pragma unroll
@@ -414,8 +428,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             st = (threadIdx.x < TILE) ? Lb[q] : Db[q];
         }
     };
-    auto stat_store = [&](int buf) {
-        if (threadIdx.x < 2 * TILE) stat[buf][threadIdx.x >> 6][threadIdx.x & (TILE - 1)] = st;
+    auto stat_store = [&](int buf) {   // threads 0..63: -lse pieces into the Q tile, 64..127: -delta pieces into the dO tile
+        if (threadIdx.x < 2 * TILE) {
+            const float t0 = -st;
+            const float a1 = round_bf16(t0), a2 = round_bf16(t0 - a1), a3 = round_bf16((t0 - a1) - a2);
+            u32x4_t w = {pack_bf16x2(a1, a2), pack_bf16x2(a3, 0.f), 0u, 0u};
+            bf16_t* tile = lds + ((threadIdx.x < TILE ? 0 : 2) + buf) * TILE_ELEMS;
+            *reinterpret_cast<u32x4_t*>(tile + (threadIdx.x & (TILE - 1)) * PITCH + 64) = w;
+        }
     };
     tile_load(Qb, sq.s, 0, S, qr);
     tile_load(dOb, sdo.s, 0, S, dor);
@@ -428,8 +448,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     for (int t = 0; t < nt; ++t) {
         const bf16_t* ql = lds + (t & 1) * TILE_ELEMS;
         const bf16_t* dol = lds + (2 + (t & 1)) * TILE_ELEMS;
-        const float* lse_l = stat[t & 1][0];
-        const float* dlt_l = stat[t & 1][1];
         if (t + 1 < nt) {
             tile_load(Qb, sq.s, (t + 1) * TILE, S, qr);
             tile_load(dOb, sdo.s, (t + 1) * TILE, S, dor);
@@ -441,31 +459,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             f32x16_t s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            s = mfma32(frag_row(ql, qb * 32, 4, lane), ones, s);                                         // - lse2[q]
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(ql, qb * 32, ks, lane), kf[ks], s);      // S[q,key]
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(ql, qb * 32, ks, lane), kf[ks], s);      // S[q,key] - lse2
+            dp = mfma32(frag_row(dol, qb * 32, 4, lane), ones, dp);                                      // - delta[q]
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key]
-            // per-row statistics: rows (r&3) + 8*(r>>2) + 4*hi -> four 16-byte LDS reads each
-            f32x4_t lv[4], dl[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                lv[g] = *reinterpret_cast<const f32x4_t*>(lse_l + qb * 32 + 8 * g + 4 * hi);
-                dl[g] = *reinterpret_cast<const f32x4_t*>(dlt_l + qb * 32 + 8 * g + 4 * hi);
-            }
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key] - delta
             f32x16_t ds;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                f32x2_t v = {s[r], s[r + 1]};
-                const f32x2_t l2 = {lv[r >> 2][r & 3], lv[r >> 2][(r & 3) + 1]};
-                const f32x2_t dl2 = {dl[r >> 2][r & 3], dl[r >> 2][(r & 3) + 1]};
-                v = v - l2;
-                f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
                 if (tail) {
                     if (t * TILE + qb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
                     if (t * TILE + qb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
                 }
                 f32x2_t d = {dp[r], dp[r + 1]};
-                d = (d - dl2) * p;
+                d = d * p;
                 s[r] = p[0];
                 s[r + 1] = p[1];
                 ds[r] = d[0];
