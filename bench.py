@@ -111,6 +111,7 @@ def main():
     from videogpa_amd.transformer import COGVIDEOX_5B
 
     cfg_kw = dict(COGVIDEOX_5B, num_layers=args.layers)
+    torch.manual_seed(0)                           # identical adapter init (PEFT kaiming-uniform A) on every rank
     model = build_model(cfg_kw, dev, seed=0)       # identical base weights on every rank
     trainer = CogVideoXDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2 * args.rank_r, "beta": 1.0, "accumulate_grad_batches": 1},
                                   transformer=model)

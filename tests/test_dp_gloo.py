@@ -41,8 +41,10 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    params = _make_params()
+    params = _make_params(seed=rank)               # ranks start from DIFFERENT values ...
     flat = FlatParams(params)
+    dist.broadcast(flat.flat, src=0)               # ... and take rank 0's, as DPOEngine does at construction
+    assert all(torch.equal(p.detach(), q.detach()) for p, q in zip(params, _make_params(seed=0)))
     opt = FlatAdamW(flat, lr=1e-3, max_grad_norm=1.0, warmup_steps=0, total_steps=10)
     data = _data()
     idx = shard_indices(len(data), rank, world, shuffle=False)

@@ -268,3 +268,29 @@ def test_loss_curve_matches_oracle_training_loop(beta, tol):
     # the adapters themselves stay together too
     worst = max((own[k[:-len('.weight')] + '.default.weight'].detach().double().cpu() - v.detach()).abs().max().item() for k, v in ref_params.items())
     assert worst < 5e-3, worst
+
+
+def test_fit_end_to_end_from_disk(tmp_path):
+    """dataset on disk (.pt latents / conditions + meta_data.json) -> prefetching loader -> engine -> final_lora."""
+    import json
+    from videogpa_amd.fit import fit
+    from videogpa_amd.lora import PeftModel
+    cfg, sd64, lora64, pm = _setup(b_std=0.0, r=4)
+    g = torch.Generator().manual_seed(3)
+    groups = []
+    for gi in range(6):
+        vids = []
+        for vi in range(2):
+            torch.save((0.7 * torch.randn(16, 3, 8, 8, generator=g)).to(torch.bfloat16), tmp_path / f"lat_{gi}_{vi}.pt")
+            torch.save({"encoder_hidden_states": (0.5 * torch.randn(6, cfg.text_embed_dim, generator=g)).to(torch.bfloat16)}, tmp_path / f"cond_{gi}_{vi}.pt")
+            vids.append({"video_path": f"v{gi}_{vi}.mp4", "consistency_score": 0.2 + 0.5 * vi, "motion_norm": 1.0,
+                         "latent_path": f"lat_{gi}_{vi}.pt", "condition_path": f"cond_{gi}_{vi}.pt"})
+        groups.append({"group_id": f"g{gi}", "prompt": "p", "videos": vids})
+    (tmp_path / "meta_data.json").write_text(json.dumps({"groups": groups}))
+    logs = []
+    tr = fit({"base_path": str(tmp_path), "metadata_path": str(tmp_path / "meta_data.json"), "max_steps": 3, "accumulate_grad_batches": 2,
+              "batch_size": 1, "num_workers": 0, "learning_rate": 1e-3, "warmup_steps": 1, "log_every_n_steps": 1,
+              "output_dir": str(tmp_path / "out")}, transformer=pm, log=logs.append)
+    assert tr.global_step == 3 and len(logs) >= 3
+    assert (tmp_path / "out" / "final_lora" / "adapter_model.safetensors").exists()
+    assert any(float(p.abs().max()) > 0 for n, p in pm.named_parameters() if "lora_B" in n)   # B left zero -> trained

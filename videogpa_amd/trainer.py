@@ -134,6 +134,10 @@ class DPOEngine:
         self.opt = trainer.configure_optimizers(process_group)
         self.accum = int(trainer.config.get("accumulate_grad_batches", 1))
         self.micro = 0
+        # every rank must start from rank 0's adapter values (DDP does this broadcast at construction)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            dist.broadcast(self.opt.flat.flat, src=0, group=process_group)
         self.opt.zero_grad()
 
     def micro_step(self, batch) -> Dict[str, Any]:
