@@ -101,6 +101,13 @@ int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void
                          void* dq, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                          const int64_t* do_strides, const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,
                          float scale, vgpa_stream_t stream);
+/* fused alternative to bwd_dkv + bwd_dq (5 instead of 7 matrix products per score block): dK, dV as above, dQ added with
+ * fp32 atomics into dq_f32 = fp32 [B,H,S,64] contiguous, which the CALLER MUST ZERO first. */
+int32_t vgpa_attn_bwd_fused(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
+                            float* dq_f32, void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides,
+                            const int64_t* v_strides, const int64_t* do_strides, const int64_t* dk_strides,
+                            const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
+                            vgpa_stream_t stream);
 int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq,
                       void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                       const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,

@@ -302,3 +302,24 @@ def test_linear_lora_function_vs_torch(ops):
         assert (Ad[i].grad.double().cpu() - Ar[i].grad).abs().max().item() < 0.03 * Ar[i].grad.abs().max().item()
         assert (Bd[i].grad.double().cpu() - Br[i].grad).abs().max().item() < 0.03 * Br[i].grad.abs().max().item()
     assert Ad[1].grad is None and Bd[1].grad is None
+
+
+def test_attention_bwd_fused_variant_matches_split(ops):
+    """The optional one-kernel backward (dQ through fp32 atomics) against the default split kernels."""
+    g = torch.Generator().manual_seed(123)
+    B, H, S = 1, 2, 700
+    q, k, v, do = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16).cuda() for _ in range(4))
+    o, lse = ops.attention_fwd_raw(q, k, v)
+    ov = o.view(B, S, H, 64).permute(0, 2, 1, 3)
+    res = {}
+    old = ops.ATTN_BWD_FUSED
+    try:
+        for fused in (False, True):
+            ops.ATTN_BWD_FUSED = fused
+            dq, dk, dv = (torch.empty(B, H, S, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+            ops.attention_bwd_raw(q, k, v, ov, do, lse, dq, dk, dv)
+            res[fused] = (dq.float(), dk.float(), dv.float())
+    finally:
+        ops.ATTN_BWD_FUSED = old
+    for a, b, name in zip(res[False], res[True], ("dq", "dk", "dv")):
+        assert (a - b).abs().max().item() <= 0.02 * a.abs().max().item() + 1e-3, name

@@ -38,7 +38,7 @@ for _ in range(a.iters):
         ops.attention_bwd_raw(q, k, v, ov, dov, lse, dq, dk, dv)
 torch.cuda.synchronize()
 unit = 2.0 * S * S * 64 * B * H
-hw_units = {"attn_fwd_kernel": 2, "attn_bwd_dkv_kernel": 4, "attn_bwd_dq_kernel": 3}
+hw_units = {"attn_fwd_kernel": 2, "attn_bwd_dkv_kernel": 4, "attn_bwd_dq_kernel": 3, "attn_bwd_fused_kernel": 5}
 for name, s in ops.TIMER.summary().items():
     print(f"{name:22s} avg {s['avg_ms']:8.3f} ms  algorithmic {s['work_per_launch'] / s['avg_ms'] / 1e9:7.1f} TF/s  "
           f"executed-MFMA {hw_units[name] * unit / s['avg_ms'] / 1e9:7.1f} TF/s")

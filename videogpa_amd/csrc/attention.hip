@@ -517,6 +517,218 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     }
 }
 
+// =====================================================================================================
+// Backward, fused:  dK, dV AND dQ in one sweep (5 matrix products per score block instead of the 7 of the split
+// dK/dV + dQ pair).  Workgroup = 8 waves = 256 keys; wave w keeps dK^T, dV^T of its 32 keys in registers exactly as
+// attn_bwd_dkv_kernel does.  For dQ the per-tile dS (bf16, [256 keys][64 q]) is handed through LDS: after one
+// barrier, wave w owns the (q-block, d-block) = (w&1, (w>>1)&1) 32x32 piece of dQ for key half w>>2, contracts its
+// 128 keys against K^T fragments it holds in registers for the whole kernel (hardware transpose reads of the dS
+// tile), and adds the result to a caller-zeroed fp32 dQ[B,H,S,64] with row-contiguous fp32 atomics (128 B per
+// half-wave).  Workgroups of one head start their q sweep at different tiles so they do not hit the same dQ rows at
+// the same time.  fp32 atomics make dQ run-to-run reproducible only to rounding (like every atomic-based attention
+// backward); dK/dV stay deterministic.
+// =====================================================================================================
+#define FUSED_KEYS 256
+__device__ __forceinline__ void tile_load1(const bf16_t* base, uint32_t row_stride, int row0, int S, u32x4_t& r) {
+    const int c = threadIdx.x;   // 512 threads: one 16-byte chunk each
+    int row = row0 + (c >> 3);
+    row = row < S ? row : S - 1;
+    r = *reinterpret_cast<const u32x4_t*>(base + ((uint32_t)row * row_stride + (uint32_t)((c & 7) * 8)));
+}
+__device__ __forceinline__ void tile_store1(bf16_t* lds, const u32x4_t& r) {
+    const int c = threadIdx.x;
+    *reinterpret_cast<u32x4_t*>(lds + (c >> 3) * PITCH + (c & 7) * 8) = r;
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                               const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                               float* __restrict__ dQ32, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
+                                                               TStride sq, TStride sk, TStride sv, TStride sdo, TStride sdk, TStride sdv,
+                                                               int S, int H, int n_kt, float scale, float kscale) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS + 16];        // Q[2], dO[2] (+ stats in the padding columns)
+    __shared__ __attribute__((aligned(16))) bf16_t dsl[FUSED_KEYS * PITCH];         // K staging at start, then dS[key][q] per tile
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / n_kt, kt = vid % n_kt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int k0 = kt * FUSED_KEYS + wave * 32;
+    const int qblk = wave & 1, dblk = (wave >> 1) & 1, half = wave >> 2;
+
+    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* dOb = dO + ((size_t)b * sdo.b + (size_t)h * sdo.h);
+    const float* Lb = LSE2 + (int64_t)bh * S;
+    const float* Db = DELTA + (int64_t)bh * S;
+    float* dQb = dQ32 + (int64_t)bh * S * HD;
+    bf16x8_t kf[4], vf[4];
+    load_row_frags(Kb, sk.s, k0, S, lane, kf);
+    load_row_frags(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, k0, S, lane, vf);
+    bf16x8_t ones;
+    {
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
+        ones = f32_to_frag(o8);
+    }
+    for (int i = threadIdx.x; i < (4 * TILE_ELEMS + 16) / 8; i += 512) {
+        u32x4_t z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4_t*>(lds + i * 8) = z;
+    }
+    // stage this workgroup's 256 K rows once, take the K^T fragments this wave needs for dQ, then reuse the buffer for dS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = threadIdx.x + 512 * j;
+        int row = kt * FUSED_KEYS + (c >> 3);
+        row = row < S ? row : S - 1;
+        *reinterpret_cast<u32x4_t*>(dsl + (c >> 3) * PITCH + (c & 7) * 8) =
+            *reinterpret_cast<const u32x4_t*>(Kb + ((uint32_t)row * sk.s + (uint32_t)((c & 7) * 8)));
+    }
+    __syncthreads();
+    bf16x8_t ktf[8];   // B operand of dQ[q,d] += dS[q,key] K[key,d]: n = d, k-slots = the 128 keys of this wave's half
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) ktf[ks] = frag_tr(dsl, 128 * half + 16 * ks, dblk * 32, lane);
+    __syncthreads();
+
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+    const int nt = (S + TILE - 1) / TILE;
+    const int start = (int)(((int64_t)kt * 37) % nt);     // stagger the q sweep across the workgroups of a head
+    auto tile_of = [&](int i) { int x = i + start; return x >= nt ? x - nt : x; };
+    const bool key_tail = (kt * FUSED_KEYS + FUSED_KEYS > S);
+    const bool key_ok = (k0 + (lane & 31)) < S;
+    u32x4_t qr, dor;
+    float st = 0.f;
+    auto stat_load = [&](int tq) {
+        if (threadIdx.x < 2 * TILE) {
+            int q = tq * TILE + (threadIdx.x & (TILE - 1));
+            q = q < S ? q : S - 1;
+            st = (threadIdx.x < TILE) ? Lb[q] : Db[q];
+        }
+    };
+    auto stat_store = [&](int buf) {
+        if (threadIdx.x < 2 * TILE) {
+            const float t0 = -st;
+            const float a1 = round_bf16(t0), a2 = round_bf16(t0 - a1), a3 = round_bf16((t0 - a1) - a2);
+            u32x4_t w = {pack_bf16x2(a1, a2), pack_bf16x2(a3, 0.f), 0u, 0u};
+            bf16_t* tile = lds + ((threadIdx.x < TILE ? 0 : 2) + buf) * TILE_ELEMS;
+            *reinterpret_cast<u32x4_t*>(tile + (threadIdx.x & (TILE - 1)) * PITCH + 64) = w;
+        }
+    };
+    tile_load1(Qb, sq.s, tile_of(0) * TILE, S, qr);
+    tile_load1(dOb, sdo.s, tile_of(0) * TILE, S, dor);
+    stat_load(tile_of(0));
+    tile_store1(lds, qr);
+    tile_store1(lds + 2 * TILE_ELEMS, dor);
+    stat_store(0);
+    __syncthreads();
+
+    for (int i = 0; i < nt; ++i) {
+        const int tq = tile_of(i);
+        const bf16_t* ql = lds + (i & 1) * TILE_ELEMS;
+        const bf16_t* dol = lds + (2 + (i & 1)) * TILE_ELEMS;
+        if (i + 1 < nt) {
+            const int tn = tile_of(i + 1);
+            tile_load1(Qb, sq.s, tn * TILE, S, qr);
+            tile_load1(dOb, sdo.s, tn * TILE, S, dor);
+            stat_load(tn);
+        }
+        const bool tail = (tq == nt - 1) && (S & (TILE - 1));
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            s = mfma32(frag_row(ql, qb * 32, 4, lane), ones, s);                                         // - lse2[q]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(ql, qb * 32, ks, lane), kf[ks], s);      // S[q,key] - lse2
+            dp = mfma32(frag_row(dol, qb * 32, 4, lane), ones, dp);                                      // - delta[q]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key] - delta
+            f32x16_t ds;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
+                if (tail) {
+                    if (tq * TILE + qb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
+                    if (tq * TILE + qb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
+                }
+                f32x2_t d = {dp[r], dp[r + 1]};
+                d = d * p;
+                s[r] = p[0];
+                s[r + 1] = p[1];
+                ds[r] = d[0];
+                ds[r + 1] = d[1];
+            }
+            if (key_tail && !key_ok) {   // keys past the end must not reach dQ (their dK/dV columns are never stored)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = 0.f;
+            }
+            // dS[key = this lane][q = qb*32 + rows] -> LDS, 4 consecutive q (8 bytes) per store
+            bf16_t* dsp = dsl + (wave * 32 + (lane & 31)) * PITCH + qb * 32 + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t w;
+                w[0] = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
+                w[1] = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
+                *reinterpret_cast<u32x2_t*>(dsp + 8 * g) = w;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bf16x8_t pf = pack_frag(s, 8 * cc);
+                const bf16x8_t dsf = pack_frag(ds, 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = mfma32(frag_tr(dol, qb * 32 + 16 * cc, db * 32, lane), pf, dv[db]);   // dV^T[d,key] += dO^T P
+                    dk[db] = mfma32(frag_tr(ql, qb * 32 + 16 * cc, db * 32, lane), dsf, dk[db]);   // dK^T[d,key] += Q^T dS
+                }
+            }
+        }
+        __syncthreads();   // dS tile complete
+        {
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mfma32(frag_tr(dsl, 128 * half + 16 * ks, qblk * 32, lane), ktf[ks], acc);   // dQ[q,d]
+            float* dqp = dQb + (int64_t)(tq * TILE + qblk * 32) * HD + dblk * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = acc_row(r, hi);
+#ifdef FUSED_NO_ATOMIC
+                asm volatile("" ::"v"(acc[r]));
+#else
+                if (tq * TILE + qblk * 32 + qrow < S) atomicAdd(dqp + qrow * HD, acc[r] * scale);
+#endif
+            }
+        }
+        if (i + 1 < nt) {
+            tile_store1(lds + ((i + 1) & 1) * TILE_ELEMS, qr);
+            tile_store1(lds + (2 + ((i + 1) & 1)) * TILE_ELEMS, dor);
+            stat_store((i + 1) & 1);
+        }
+        __syncthreads();   // next tiles staged; dS tile free again
+    }
+    const int k = k0 + (lane & 31);
+    if (k < S) {
+        bf16_t* kp = dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s);
+        bf16_t* vp = dV + ((size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)k * sdv.s);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t w;
+                w[0] = pack_bf16x2(dk[db][4 * g] * kscale, dk[db][4 * g + 1] * kscale);
+                w[1] = pack_bf16x2(dk[db][4 * g + 2] * kscale, dk[db][4 * g + 3] * kscale);
+                *reinterpret_cast<u32x2_t*>(kp + db * 32 + 8 * g + 4 * hi) = w;
+                w[0] = pack_bf16x2(dv[db][4 * g], dv[db][4 * g + 1]);
+                w[1] = pack_bf16x2(dv[db][4 * g + 2], dv[db][4 * g + 3]);
+                *reinterpret_cast<u32x2_t*>(vp + db * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
+}
+
 static inline bool stride_ok(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= HD && (st[0] % 8 == 0) && (st[1] % 8 == 0) && (st[2] % 8 == 0); }
 // every element offset reachable inside one (batch, head) slab and across the tensor must fit 31 bits
 static inline bool range_ok(const int64_t* st, int64_t B, int64_t H, int64_t S) {
@@ -600,6 +812,23 @@ int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void
     VGPA_LAUNCH(attn_bwd_dq_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides),
                        mk(do_strides), mk(dq_strides), (int)S, (int)H, n_t, scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// fused backward: dK, dV (bf16 views) and dQ accumulated into dq_f32 -- fp32 [B,H,S,64] contiguous, ZEROED BY THE CALLER.
+int32_t vgpa_attn_bwd_fused(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
+                            float* dq_f32, void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides,
+                            const int64_t* v_strides, const int64_t* do_strides, const int64_t* dk_strides, const int64_t* dv_strides,
+                            int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, hipStream_t stream) {
+    if (!q || !k || !v || !d_o || !lse2 || !delta || !dq_f32 || !dk || !dv || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dk_strides) || !SOK(dv_strides) || !al16(q) ||
+        !al16(k) || !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv))
+        return VGPA_ERR_INVALID;
+    const int n_t = (int)((S + FUSED_KEYS - 1) / FUSED_KEYS);
+    VGPA_LAUNCH(attn_bwd_fused_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(512), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, dq_f32, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides),
+                mk(v_strides), mk(do_strides), mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, scale, 0.6931471805599453f);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

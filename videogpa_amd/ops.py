@@ -393,6 +393,12 @@ def _timed(name, work, fn):
 
 
 LOG2E = 1.4426950408889634
+# backward attention: "split" (default) = deterministic dK/dV kernel + dQ kernel (7 matrix products per score block);
+# "fused" = one kernel with dQ by fp32 atomics (5 products).  Measured on MI355X at the headline shape the fused form
+# is SLOWER (46.6 ms vs 26.5 ms per layer): its 60 GB of dQ atomics per launch run at ~2.6 TB/s (23.9 ms without them).
+# It stays selectable (VGPA_ATTN_BWD=fused) and parity-tested.
+import os as _os
+ATTN_BWD_FUSED = _os.environ.get("VGPA_ATTN_BWD", "split") == "fused"
 
 
 def prescale_q(q, scale=None):
@@ -428,6 +434,13 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
     delta = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     st = _stream()
     _lib.call("vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st)
+    if ATTN_BWD_FUSED:
+        dq32 = torch.zeros(B, H, S, Dh, dtype=torch.float32, device=q.device)
+        _timed("attn_bwd_fused_kernel", 8.0 * S * S * Dh * B * H, lambda: _lib.call(
+            "vgpa_attn_bwd_fused", q, k, v, do, lse, delta, dq32, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+            _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), st))
+        dq.copy_(dq32)
+        return
     _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
         "vgpa_attn_bwd_dkv", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
         _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), st))
