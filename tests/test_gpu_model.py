@@ -294,3 +294,49 @@ def test_fit_end_to_end_from_disk(tmp_path):
     assert tr.global_step == 3 and len(logs) >= 3
     assert (tmp_path / "out" / "final_lora" / "adapter_model.safetensors").exists()
     assert any(float(p.abs().max()) > 0 for n, p in pm.named_parameters() if "lora_B" in n)   # B left zero -> trained
+
+
+def test_generate_denoise_loop_matches_cpu_restatement():
+    """generate path: CFG + RoPE + merged adapter + DPM scheduler, 6 steps, injected noise, vs the same
+    loop run in fp64 on the CPU through oracle.cogvideox.forward."""
+    from videogpa_amd.generate import denoise, rope_3d_tables
+    from videogpa_amd.scheduler import CogVideoXDPMScheduler
+    cfg, sd64, lora64, pm = _setup(b_std=0.05)
+    steps, B, Fr, Hh, Ww = 6, 1, 3, 8, 8
+    merged = pm.merge_and_unload()
+    # oracle gets the same merged (bf16-rounded) weights
+    sdm = {k: v.detach().double().cpu() for k, v in merged.state_dict().items()}
+    g = torch.Generator().manual_seed(77)
+    pos = (0.5 * torch.randn(B, 6, cfg.text_embed_dim, generator=g)).to(torch.bfloat16)
+    neg = torch.zeros_like(pos)
+    lat0 = torch.randn(B, Fr, 16, Hh, Ww, generator=g).to(torch.bfloat16)
+    noise = torch.randn(steps, 2, B, Fr, 16, Hh, Ww, generator=g).to(torch.bfloat16)
+    sch = CogVideoXDPMScheduler(timestep_spacing="trailing")
+    out = denoise(merged, sch, pos.cuda(), neg.cuda(), latent_frames=Fr, height=Hh, width=Ww, num_inference_steps=steps,
+                  guidance_scale=6.0, latents=lat0.cuda(), step_noise=noise.cuda())
+    # CPU fp64 loop
+    ref_s = CogVideoXDPMScheduler(timestep_spacing="trailing")
+    ref_s.set_timesteps(steps)
+    assert ref_s.timesteps.tolist() == [999, 832, 666, 499, 332, 166]
+    cos, sin = ocv.rope_3d_tables(Fr, Hh // 2, Ww // 2, 64)
+    c2, s2 = rope_3d_tables(Fr, Hh // 2, Ww // 2, 64, device="cpu")
+    assert torch.equal(cos, c2) and torch.equal(sin, s2)
+    lat = lat0.double()
+    old = None
+    emb = torch.cat([neg, pos]).double()
+    for i, t in enumerate(ref_s.timesteps):
+        v = ocv.forward(sdm, cfg, torch.cat([lat, lat]), emb, t.expand(2), image_rotary_emb=(cos.double(), sin.double()))
+        v = v[:1] + 6.0 * (v[1:] - v[:1])
+        lat, old = ref_s.step(v, old, t, ref_s.timesteps[i - 1] if i > 0 else None, lat, noise=noise[i].double())
+        lat = lat.to(torch.bfloat16).double()     # the pipeline casts latents back to the prompt dtype every step
+    err = (out.double().cpu() - lat).abs().max().item()
+    assert err < 0.06 * lat.abs().max().item(), (err, lat.abs().max().item())
+    # a perfect denoiser is a fixed point of the last step: prev_sample == predicted x0
+    sch.set_timesteps(50)
+    assert sch.timesteps[0].item() == 999 and sch.timesteps[-1].item() == 19     # "trailing" spacing, 50 steps
+    x0 = torch.randn(1, 2, 4, 4, 4, generator=g, dtype=torch.float64)
+    e = torch.randn(1, 2, 4, 4, 4, generator=g, dtype=torch.float64)
+    a = sch.alphas_cumprod[19]
+    xt, vv = a.sqrt() * x0 + (1 - a).sqrt() * e, a.sqrt() * e - (1 - a).sqrt() * x0
+    prev, px0 = sch.step(vv, None, 19, 39, xt, noise=torch.ones(2, *xt.shape, dtype=torch.float64))   # final step: alpha_prev = 1
+    assert torch.allclose(px0, x0, atol=1e-9) and torch.allclose(prev, x0, atol=1e-9)

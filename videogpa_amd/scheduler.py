@@ -28,6 +28,10 @@ class CogVideoXDPMScheduler:
             s = (s - sT) * (s0 / (s0 - sT))
             abar = s ** 2
         self.alphas_cumprod = abar
+        self.final_alpha_cumprod = torch.tensor(1.0, dtype=torch.float64)   # set_alpha_to_one (CogVideoX scheduler_config)
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+        self.num_inference_steps = None
         self._tabs = {}
 
     @classmethod
@@ -37,6 +41,63 @@ class CogVideoXDPMScheduler:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         cfg.update(kw)
         return cls(**cfg)
+
+    # ------------------------------------------------------------------ sampling side (generate/CogVideoX-5B.py:18,70-77)
+    # PARITY UNPINNED: restated from diffusers' scheduling_dpm_cogvideox.py (SDE-DPM-Solver++ 2M on v-prediction).
+    @classmethod
+    def from_config(cls, config, **kw):
+        cfg = {k: v for k, v in dict(config).items() if not k.startswith("_")}
+        cfg.update(kw)
+        return cls(**cfg)
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        spacing = self.config.get("timestep_spacing", "trailing")
+        if spacing == "trailing":
+            ts = torch.round(torch.arange(T, 0, -T / num_inference_steps, dtype=torch.float64)) - 1
+        elif spacing == "leading":
+            ts = (torch.arange(0, num_inference_steps, dtype=torch.float64) * (T // num_inference_steps)).round().flip(0)
+        else:
+            ts = torch.linspace(0, T - 1, num_inference_steps, dtype=torch.float64).round().flip(0)
+        self.timesteps = ts.to(torch.int64).to(device) if device is not None else ts.to(torch.int64)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    @staticmethod
+    def _lambda(a):
+        return 0.5 * torch.log(a / (1 - a))
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, eta=0.0, generator=None, noise=None,
+             return_dict=False):
+        """-> (prev_sample, pred_original_sample).  `noise` (two draws, [2, *sample.shape]) may be injected for parity tests."""
+        T = self.config.num_train_timesteps
+        t = int(timestep)
+        prev_t = t - T // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        a_back = self.alphas_cumprod[int(timestep_back)] if timestep_back is not None else None
+        x = sample.to(torch.float64)
+        v = model_output.to(torch.float64)
+        pred_x0 = a_t.sqrt() * x - (1 - a_t).sqrt() * v                      # v-prediction
+        lamb, lamb_next = self._lambda(a_t), self._lambda(a_prev)
+        h = lamb_next - lamb
+        m1 = ((1 - a_prev) / (1 - a_t)).sqrt() * torch.exp(-h)
+        m2 = torch.expm1(-2 * h) * a_prev.sqrt()
+        m_noise = (1 - a_prev).sqrt() * (1 - torch.exp(-2 * h)).sqrt()
+
+        def draw(i):
+            if noise is not None:
+                return noise[i].to(torch.float64)
+            return torch.randn(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype).to(torch.float64)
+
+        prev = m1 * x - m2 * pred_x0 + m_noise * draw(0)
+        if old_pred_original_sample is not None and prev_t >= 0:
+            r = (lamb - self._lambda(a_back)) / h
+            d = (1 + 1 / (2 * r)) * pred_x0 - (1 / (2 * r)) * old_pred_original_sample.to(torch.float64)
+            prev = m1 * x - m2 * d + m_noise * draw(1)
+        return prev.to(sample.dtype), pred_x0.to(sample.dtype)
 
     def tables(self, dtype, device):
         """fp32 device tables of sqrt(abar), sqrt(1-abar) with the table first cast to the sample dtype (as upstream)."""
