@@ -164,26 +164,31 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ln_modulate_bwd_kernel(
     }
 }
 
-// out = (x ? x : 0) + gate[range] * y   with bf16 rounding after the product (torch bf16 elementwise semantics)
+// out = (x ? x : 0) + gate[range] * y   with bf16 rounding after the product (torch bf16 elementwise semantics).
+// One workgroup walks whole token rows (no per-element index division); the gate vector of the row's range is read
+// as float4 and stays L1/L2 resident.
 __global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
                                                               const float* __restrict__ gate_v, const float* __restrict__ gate_t,
-                                                              int64_t mod_stride, int text_len, int S, int D, int64_t total8,
+                                                              int64_t mod_stride, int text_len, int S, int D, int64_t rows,
                                                               bf16_t* __restrict__ out) {
     const int d8 = D >> 3;
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < total8; c += (int64_t)gridDim.x * 256) {
-        const int64_t row = c / d8;
-        const int i0 = (int)(c % d8) * 8;
-        const int b = (int)(row / S), s = (int)(row % S);
-        const float* gp = ((s < text_len) ? gate_t : gate_v) + (size_t)b * mod_stride + i0;
-        float yy[8], xx[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(y + (size_t)c * 8), yy);
-        if (x) unpack8(*reinterpret_cast<const u32x4_t*>(x + (size_t)c * 8), xx);
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = (int)(row / S), s = (int)(row - (int64_t)b * S);
+        const float* gp = ((s < text_len) ? gate_t : gate_v) + (size_t)b * mod_stride;
+        const size_t base = (size_t)row * D;
+        for (int c = threadIdx.x; c < d8; c += 256) {
+            float yy[8], xx[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(y + base + (size_t)c * 8), yy);
+            if (x) unpack8(*reinterpret_cast<const u32x4_t*>(x + base + (size_t)c * 8), xx);
+            const float4 g0 = *reinterpret_cast<const float4*>(gp + c * 8), g1 = *reinterpret_cast<const float4*>(gp + c * 8 + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float p = round_bf16(gp[j] * yy[j]);
-            xx[j] = x ? xx[j] + p : p;
+            for (int j = 0; j < 8; ++j) {
+                const float p = round_bf16(g[j] * yy[j]);
+                xx[j] = x ? xx[j] + p : p;
+            }
+            *reinterpret_cast<u32x4_t*>(out + base + (size_t)c * 8) = pack8(xx);
         }
-        *reinterpret_cast<u32x4_t*>(out + (size_t)c * 8) = pack8(xx);
     }
 }
 
@@ -287,9 +292,10 @@ int32_t vgpa_gate_residual(const void* x, const void* y, const float* gate_v, co
                            int64_t S, int64_t D, int64_t text_len, void* out, hipStream_t stream) {
     if (!y || !gate_v || !out) return VGPA_ERR_INVALID;
     if (B <= 0 || S <= 0 || D <= 0 || D % 8 != 0 || text_len < 0 || text_len > S || (text_len > 0 && !gate_t)) return VGPA_ERR_INVALID;
-    const int64_t total8 = B * S * D / 8;
-    VGPA_LAUNCH(gate_residual_kernel, dim3(ew_grid(total8)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)y, gate_v, gate_t,
-                       mod_stride, (int)text_len, (int)S, (int)D, total8, (bf16_t*)out);
+    const int64_t rows = B * S;
+    const unsigned nb = (unsigned)(rows < 16384 ? rows : 16384);
+    VGPA_LAUNCH(gate_residual_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)y, gate_v, gate_t,
+                       mod_stride, (int)text_len, (int)S, (int)D, rows, (bf16_t*)out);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
