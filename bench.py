@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--height", type=int, default=60)
     ap.add_argument("--width", type=int, default=90)
     ap.add_argument("--rank-r", type=int, default=64)
+    ap.add_argument("--checkpoint", action="store_true", help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -113,8 +114,8 @@ def main():
     cfg_kw = dict(COGVIDEOX_5B, num_layers=args.layers)
     torch.manual_seed(0)                           # identical adapter init (PEFT kaiming-uniform A) on every rank
     model = build_model(cfg_kw, dev, seed=0)       # identical base weights on every rank
-    trainer = CogVideoXDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2 * args.rank_r, "beta": 1.0, "accumulate_grad_batches": 1},
-                                  transformer=model)
+    trainer = CogVideoXDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2 * args.rank_r, "beta": 1.0, "accumulate_grad_batches": 1,
+                                   "enable_gradient_checkpointing": args.checkpoint}, transformer=model)
     # LoRA B ~ N(0, 1e-3) so the step is beyond the trivial B=0 point
     gB = torch.Generator(device=dev).manual_seed(1)
     with torch.no_grad():

@@ -323,3 +323,64 @@ def test_attention_bwd_fused_variant_matches_split(ops):
         ops.ATTN_BWD_FUSED = old
     for a, b, name in zip(res[False], res[True], ("dq", "dk", "dv")):
         assert (a - b).abs().max().item() <= 0.02 * a.abs().max().item() + 1e-3, name
+
+
+# ------------------------------------------------------------------------------------------ edge cases / error codes
+@pytest.mark.parametrize("S", [1, 7, 63, 64, 65, 129])
+def test_attention_tiny_and_boundary_lengths(ops, S):
+    g = torch.Generator().manual_seed(S)
+    B, H = 2, 1
+    q, k, v, do = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16) for _ in range(4))
+    o, lse = ops.attention_fwd_raw(dev(q), dev(k), dev(v))
+    o_ref, dq_ref, dk_ref, dv_ref = _attn_ref(q, k, v, do)
+    assert (o.view(B, S, H, 64).permute(0, 2, 1, 3).double().cpu() - o_ref).abs().max().item() < 0.02
+    dq, dk, dv = (torch.empty(B, H, S, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    ops.attention_bwd_raw(dev(q), dev(k), dev(v), o.view(B, S, H, 64).permute(0, 2, 1, 3), dev(do), lse, dq, dk, dv)
+    for a, r in ((dq, dq_ref), (dk, dk_ref), (dv, dv_ref)):
+        assert (a.double().cpu() - r).abs().max().item() < 0.03 * r.abs().max().item() + 2e-3
+    assert torch.isfinite(o).all() and torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all()
+
+
+def test_attention_outlier_scores_late_rescale_many_tiles(ops):
+    """Spikes far above the running max in several late tiles, in both half-lanes, must go through the slow path."""
+    g = torch.Generator().manual_seed(4)
+    B, H, S = 1, 1, 1000
+    q, k, v = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16) for _ in range(3))
+    for key, row, gain in ((300, 5, 3.0), (700, 40, 6.0), (905, 5, 9.0), (999, 77, 12.0)):
+        k[0, 0, key] = (q[0, 0, row].float() * gain / 8).to(torch.bfloat16)
+    o, lse = ops.attention_fwd_raw(dev(q), dev(k), dev(v))
+    o_ref = _attn_ref(q, k, v)
+    assert (o.view(B, S, H, 64).permute(0, 2, 1, 3).double().cpu() - o_ref).abs().max().item() < 0.03
+    assert torch.isfinite(lse).all()
+
+
+def test_cabi_rejects_bad_arguments(ops):
+    from videogpa_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    assert lib.vgpa_gelu_tanh_fwd(None, 64, x.data_ptr(), st) == -1                    # null pointer
+    assert lib.vgpa_gelu_tanh_fwd(x.data_ptr(), 60, x.data_ptr(), st) == -1            # n % 8 != 0
+    import ctypes
+    s3 = (ctypes.c_int64 * 3)(64, 64, 64)
+    f = torch.zeros(8, dtype=torch.float32, device="cuda")
+    assert lib.vgpa_attn_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), f.data_ptr(), s3, s3, s3, s3, 1, 1, 1, 128, 0.1, st) == -1   # head_dim
+    bad = (ctypes.c_int64 * 3)(64, 64, 60)
+    assert lib.vgpa_attn_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), f.data_ptr(), bad, s3, s3, s3, 1, 1, 1, 64, 0.1, st) == -1   # stride
+    ws = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    assert lib.vgpa_dpo_loss_fwd(*([x.data_ptr()] * 6), 1, 64, 64, 64, 64, 1, 1.0, 0.0, 0, 0, f.data_ptr(), f.data_ptr(), None, ws.data_ptr(), 16, st) == -3
+    with pytest.raises(ValueError, match="Unknown loss type"):
+        ops.dpo_loss(x.view(1, 64), x.view(1, 64), x.view(1, 64), x.view(1, 64), x.view(1, 64), x.view(1, 64), loss_type="nope")
+
+
+def test_ln_modulate_max_width_and_batch_boundaries(ops):
+    g = torch.Generator().manual_seed(8)
+    B, S, D, Lt = 3, 5, 4096, 2          # rows-per-wave groups straddle batch and text/video boundaries
+    x = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    mod = 0.3 * torch.randn(B, 4, D, generator=g)
+    y = ops.ln_modulate(dev(x), dev(w), dev(b), dev(mod), Lt, 1e-5)
+    n = F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5)
+    sc = torch.cat([mod[:, 3:4].expand(B, Lt, D), mod[:, 1:2].expand(B, S - Lt, D)], 1).double()
+    sh = torch.cat([mod[:, 2:3].expand(B, Lt, D), mod[:, 0:1].expand(B, S - Lt, D)], 1).double()
+    assert (y.double().cpu() - (n * sc + sh)).abs().max().item() < 0.04

@@ -340,3 +340,24 @@ def test_generate_denoise_loop_matches_cpu_restatement():
     xt, vv = a.sqrt() * x0 + (1 - a).sqrt() * e, a.sqrt() * e - (1 - a).sqrt() * x0
     prev, px0 = sch.step(vv, None, 19, 39, xt, noise=torch.ones(2, *xt.shape, dtype=torch.float64))   # final step: alpha_prev = 1
     assert torch.allclose(px0, x0, atol=1e-9) and torch.allclose(prev, x0, atol=1e-9)
+
+
+def test_gradient_checkpointing_gives_same_grads():
+    """enable_gradient_checkpointing() (train/CogVideoX-5B/03_train.py:107-108): per-block recompute, identical adapter grads."""
+    cfg, sd64, lora64, pm = _setup(b_std=0.05)
+    x, txt, t = _inputs(cfg, B=2, seed=11)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(x.shape, generator=g).to(torch.bfloat16).cuda()
+    pm.train()
+    grads = []
+    for ckpt in (False, True):
+        if ckpt:
+            pm.enable_gradient_checkpointing()
+        for p in pm.parameters():
+            p.grad = None
+        y = pm(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
+        y.backward(dy)
+        grads.append({n: p.grad.clone() for n, p in pm.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) == 2 * 4 * cfg.num_layers
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n     # same kernels, same order -> bit-identical

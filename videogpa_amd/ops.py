@@ -316,8 +316,9 @@ class _LinearLoraFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         n, scalings, xshape, act, r, rp = ctx.meta
-        x2, W, a_cat, t = ctx.saved_tensors[:4]
-        bws = ctx.saved_tensors[4:]
+        sv = ctx.saved_tensors            # read once: activation checkpointing unpacks saved tensors a single time
+        x2, W, a_cat, t = sv[:4]
+        bws = sv[4:]
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.stride(1) != 1:
             dy2 = dy2.contiguous()
