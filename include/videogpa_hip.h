@@ -61,6 +61,18 @@ int32_t vgpa_ln_modulate_fwd(const void* x, const float* ln_w, const float* ln_b
 int32_t vgpa_ln_modulate_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* ln_w,
                              const float* scale1p_v, const float* scale1p_t, int64_t mod_stride, int64_t B, int64_t S,
                              int64_t D, int64_t text_len, const void* dres, void* dx, vgpa_stream_t stream);
+/* fused gated residual + following LN-modulate (the pair diffusers runs as `hidden += gate * out` then `norm(hidden)`):
+ *   fwd: x_new = x + gate[range]*y ; n = LN(x_new) * (w (1+scale)) + (b (1+scale) + shift)      (y NULL: n = LN-mod(x) only)
+ *   bwd: dx = dres + LN'(dn) ; dy = gate[range]*dx                                               (dres / dy may be NULL) */
+int32_t vgpa_residual_ln_fwd(const void* x, const void* y, const float* gate_v, const float* gate_t, int64_t gate_stride,
+                             const float* ln_w, const float* ln_b, const float* shift_v, const float* scale1p_v,
+                             const float* shift_t, const float* scale1p_t, int64_t mod_stride, int64_t B, int64_t S, int64_t D,
+                             int64_t text_len, float eps, void* x_new, void* n_out, float* mean, float* rstd,
+                             vgpa_stream_t stream);
+int32_t vgpa_residual_ln_bwd(const void* dn, const void* x_new, const float* mean, const float* rstd, const float* ln_w,
+                             const float* scale1p_v, const float* scale1p_t, int64_t mod_stride, const float* gate_v,
+                             const float* gate_t, int64_t gate_stride, const void* dres, int64_t B, int64_t S, int64_t D,
+                             int64_t text_len, void* dx, void* dy, vgpa_stream_t stream);
 /* out = x + gate[range] * y (x NULL: out = gate * y, the backward of the y branch) */
 int32_t vgpa_gate_residual(const void* x, const void* y, const float* gate_v, const float* gate_t, int64_t mod_stride,
                            int64_t B, int64_t S, int64_t D, int64_t text_len, void* out, vgpa_stream_t stream);

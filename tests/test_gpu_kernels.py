@@ -96,8 +96,9 @@ def test_noise_velocity_bit_exact(ops, dtype):
 
 
 # ------------------------------------------------------------------------------------------ AdaLN pieces
+@pytest.mark.parametrize("impl", ["fused", "v1"])
 @pytest.mark.parametrize("D,text_len", [(128, 6), (3072, 5), (512, 0)])
-def test_ln_modulate_fwd_bwd(ops, D, text_len):
+def test_ln_modulate_fwd_bwd(ops, D, text_len, impl):
     g = torch.Generator().manual_seed(D)
     B, S = 2, 37
     x = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
@@ -107,8 +108,9 @@ def test_ln_modulate_fwd_bwd(ops, D, text_len):
     mod[:, 1] += 1
     mod[:, 3] += 1
     dy = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    lnm = ops.ln_modulate if impl == "fused" else ops.ln_modulate_v1
     xd = dev(x).requires_grad_(True)
-    y = ops.ln_modulate(xd, dev(w), dev(b), dev(mod), text_len, 1e-5)
+    y = lnm(xd, dev(w), dev(b), dev(mod), text_len, 1e-5)
     y.backward(dev(dy))
     xr = x.double().requires_grad_(True)
     n = F.layer_norm(xr, (D,), w.double(), b.double(), 1e-5)
@@ -121,7 +123,7 @@ def test_ln_modulate_fwd_bwd(ops, D, text_len):
     gerr = (xd.grad.double().cpu() - xr.grad).abs().max().item()
     assert gerr < 0.02 * xr.grad.abs().max().item() + 1e-3
     # plain LN (no modulation)
-    y2 = ops.ln_modulate(dev(x), dev(w), dev(b), None, 0, 1e-5)
+    y2 = lnm(dev(x), dev(w), dev(b), None, 0, 1e-5)
     assert (y2.double().cpu() - n.detach()).abs().max().item() < 0.03
 
 
@@ -384,3 +386,35 @@ def test_ln_modulate_max_width_and_batch_boundaries(ops):
     sc = torch.cat([mod[:, 3:4].expand(B, Lt, D), mod[:, 1:2].expand(B, S - Lt, D)], 1).double()
     sh = torch.cat([mod[:, 2:3].expand(B, Lt, D), mod[:, 0:1].expand(B, S - Lt, D)], 1).double()
     assert (y.double().cpu() - (n * sc + sh)).abs().max().item() < 0.04
+
+
+@pytest.mark.parametrize("B,S,D,Lt", [(2, 37, 128, 6), (1, 300, 3072, 226), (3, 21, 512, 0), (2, 33, 256, 33)])
+def test_residual_ln_fused_equals_composition(ops, B, S, D, Lt):
+    """x' = x + gate*y ; n = LN-mod(x')  fused in one pass, against gate_residual + ln_modulate_v1 run separately, forward
+    and backward (with a gradient arriving on BOTH outputs)."""
+    g = torch.Generator().manual_seed(S * D)
+    x = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    y = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    gates = torch.randn(B, 2, D, generator=g).to(torch.bfloat16).float()
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    mod = 0.3 * torch.randn(B, 4, D, generator=g)
+    mod[:, 1] += 1
+    mod[:, 3] += 1
+    dxn = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    dn = torch.randn(B, S, D, generator=g).to(torch.bfloat16)
+    outs = []
+    for fused in (True, False):
+        xd, yd = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+        if fused:
+            xn, n = ops.residual_ln(xd, yd, dev(gates), dev(w), dev(b), dev(mod), Lt, 1e-5)
+        else:
+            xn = ops.gate_residual(xd, yd, dev(gates), Lt)
+            n = ops.ln_modulate_v1(xn, dev(w), dev(b), dev(mod), Lt, 1e-5)
+        torch.autograd.backward([xn, n], [dev(dxn), dev(dn)])
+        outs.append((xn.detach(), n.detach(), xd.grad, yd.grad))
+    f, u = outs
+    assert torch.equal(f[0], u[0])                                        # residual stream: same bf16 rounding order
+    assert (f[1].float() - u[1].float()).abs().max().item() <= 0.032      # LN output: <= 1 bf16 ulp of O(4) values
+    for i in (2, 3):
+        sc = u[i].float().abs().max().item()
+        assert (f[i].float() - u[i].float()).abs().max().item() <= 0.02 * sc, i

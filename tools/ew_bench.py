@@ -1,0 +1,46 @@
+"""Micro-benchmark of the HBM-bound transformer kernels at the headline shape (2 sequences x 17776 tokens x 3072)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videogpa_amd import ops  # noqa: E402
+
+B, S, D, Lt = 2, 17776, 3072, 226
+x = torch.randn(B, S, D, device="cuda").bfloat16()
+y = torch.randn(B, S, D, device="cuda").bfloat16()
+g = torch.randn(B, 2, D, device="cuda")
+mod = torch.randn(B, 4, D, device="cuda")
+w, bb = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
+u = torch.randn(B, S, 4 * D, device="cuda").bfloat16()
+unit = B * S * D * 2 / 1e9   # GB per pass over one [B,S,D] bf16 tensor
+
+
+def t(f, n=20):
+    f()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def show(name, us, passes):
+    print(f"{name:34s} {us:8.1f} us   {passes * unit / us * 1e6 / 1e3:6.2f} TB/s ({passes} passes)")
+
+
+show("gate_residual fwd", t(lambda: ops.gate_residual(x, y, g, Lt)), 3)
+show("ln_modulate v1 fwd", t(lambda: ops.ln_modulate_v1(x, w, bb, mod, Lt, 1e-5)), 2)
+show("ln_modulate (fused kernel, no y)", t(lambda: ops.ln_modulate(x, w, bb, mod, Lt, 1e-5)), 2)
+show("residual_ln fwd", t(lambda: ops.residual_ln(x, y, g, w, bb, mod, Lt, 1e-5)), 4)
+xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+xn, n = ops.residual_ln(xr, yr, g, w, bb, mod, Lt, 1e-5)
+show("residual_ln bwd", t(lambda: torch.autograd.grad([xn, n], [xr, yr], [x, y], retain_graph=True)), 5)
+xr2 = x.clone().requires_grad_(True)
+n1 = ops.ln_modulate_v1(xr2, w, bb, mod, Lt, 1e-5)
+show("ln_modulate v1 bwd", t(lambda: torch.autograd.grad(n1, xr2, y, retain_graph=True)), 3)
+show("gelu fwd", t(lambda: ops.gelu_tanh(u)), 8)

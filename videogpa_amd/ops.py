@@ -193,7 +193,69 @@ class _LNModulateFn(torch.autograd.Function):
 
 
 def ln_modulate(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
+    return _ResidualLNFn.apply(x, None, None, ln_w, ln_b, mod, text_len, eps)[1]
+
+
+def ln_modulate_v1(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
+    """First-generation LN-modulate kernels (kept for A/B and as a second implementation under test)."""
     return _LNModulateFn.apply(x, ln_w, ln_b, mod, text_len, eps)
+
+
+def _mod_ptrs(mod):
+    if mod is None:
+        return None, None, None, None, 0
+    return mod[:, 0], mod[:, 1], mod[:, 2], mod[:, 3], mod.stride(0)
+
+
+class _ResidualLNFn(torch.autograd.Function):
+    """(x, y) -> (x_new = x + gate*y, n = LN(x_new)*alpha + beta) in one pass; backward fuses the residual-path add, the
+    LN backward and the gate multiply.  y / gates may be None: plain LN-modulate of x (x_new is then x itself)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gates, ln_w, ln_b, mod, text_len, eps):
+        _req(x, torch.bfloat16), _req(ln_w, torch.float32), _req(ln_b, torch.float32)
+        B, S, D = x.shape
+        n = torch.empty_like(x)
+        mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        sv, s1v, st, s1t, mstride = _mod_ptrs(mod)
+        if y is not None:
+            _req(y, torch.bfloat16), _req(gates, torch.float32)
+            x_new = torch.empty_like(x)
+            gv, gt, gstride = gates[:, 0], gates[:, 1], gates.stride(0)
+        else:
+            x_new, gv, gt, gstride = None, None, None, 0
+        _lib.call("vgpa_residual_ln_fwd", x, y, gv, gt, gstride, ln_w, ln_b, sv, s1v, st, s1t, mstride, B, S, D, text_len, float(eps),
+                  x_new, n, mean, rstd, _stream())
+        xs = x if y is None else x_new
+        ctx.save_for_backward(xs, mean, rstd, ln_w, mod, gates if y is not None else None)
+        ctx.text_len = text_len
+        ctx.has_y = y is not None
+        return x_new, n          # x_new is None when there is no y (plain LN-modulate)
+
+    @staticmethod
+    def backward(ctx, dx_new, dn):
+        xs, mean, rstd, ln_w, mod, gates = ctx.saved_tensors
+        B, S, D = xs.shape
+        if dn is None:
+            dn = torch.zeros_like(xs)
+        dn = dn.contiguous()
+        dres = None if dx_new is None else dx_new.contiguous()
+        dx = torch.empty_like(xs)
+        _, s1v, _, s1t, mstride = _mod_ptrs(mod)
+        if ctx.has_y:
+            dy = torch.empty_like(xs)
+            gv, gt, gstride = gates[:, 0], gates[:, 1], gates.stride(0)
+        else:
+            dy, gv, gt, gstride = None, None, None, 0
+        _lib.call("vgpa_residual_ln_bwd", dn, xs, mean, rstd, ln_w, s1v, s1t, mstride, gv, gt, gstride, dres, B, S, D, ctx.text_len, dx, dy,
+                  _stream())
+        return dx, dy, None, None, None, None, None, None
+
+
+def residual_ln(x, y, gates, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
+    """-> (x + gate*y, LN-modulate of that).  One HIP pass forward, one backward."""
+    return _ResidualLNFn.apply(x, y, gates, ln_w, ln_b, mod, text_len, eps)
 
 
 class _GateResidualFn(torch.autograd.Function):

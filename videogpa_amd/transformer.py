@@ -195,17 +195,23 @@ class CogVideoXBlock(nn.Module):
         self.ff = FeedForward(dim, 4 * dim)
         self.eps = eps
 
-    def forward(self, x, temb, text_len, rope):
-        mod, gates = self.norm1.modulation(temb)
-        n = ops.ln_modulate(x, _f32(self.norm1.norm.weight), _f32(self.norm1.norm.bias), mod, text_len, self.eps)
+    def modulations(self, temb):
+        """((mod1, gates1), (mod2, gates2)) of this block for one conditioning embedding."""
+        return self.norm1.modulation(temb), self.norm2.modulation(temb)
+
+    def norm1_params(self):
+        return _f32(self.norm1.norm.weight), _f32(self.norm1.norm.bias)
+
+    def forward(self, x, n, gates1, mod2, gates2, text_len, rope, nxt_w, nxt_b, nxt_mod, nxt_eps):
+        """x: residual stream; n = norm1(x) already modulated (produced by the previous block's fused residual+LN pass).
+        Returns (x_out, n_next) where n_next is the NEXT normalisation (next block's norm1, or the model's norm_final)
+        applied to x_out -- each gated residual add is fused with the LayerNorm that consumes it."""
         a = self.attn1(n, text_len, rope)
-        x = ops.gate_residual(x, a, gates, text_len)
-        mod, gates = self.norm2.modulation(temb)
-        n = ops.ln_modulate(x, _f32(self.norm2.norm.weight), _f32(self.norm2.norm.bias), mod, text_len, self.eps)
-        u = F.linear(n, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
+        x, n2 = ops.residual_ln(x, a, gates1, _f32(self.norm2.norm.weight), _f32(self.norm2.norm.bias), mod2, text_len, self.eps)
+        u = F.linear(n2, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
         g = ops.gelu_tanh(u)
         f = F.linear(g, self.ff.net[2].weight, self.ff.net[2].bias)
-        return ops.gate_residual(x, f, gates, text_len)
+        return ops.residual_ln(x, f, gates2, nxt_w, nxt_b, nxt_mod, text_len, nxt_eps)
 
 
 def timestep_sincos(t, dim, flip_sin_to_cos=True, freq_shift=0, max_period=10000):
@@ -320,14 +326,23 @@ class CogVideoXTransformer3DModel(nn.Module):
         if image_rotary_emb is not None:
             rope = (image_rotary_emb[0].float().contiguous(), image_rotary_emb[1].float().contiguous())
 
-        for blk in self.transformer_blocks:
-            if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
-                x = torch.utils.checkpoint.checkpoint(blk, x, emb, Lt, rope, use_reentrant=False)
+        blocks = self.transformer_blocks
+        mods = [blk.modulations(emb) for blk in blocks]
+        w0, b0 = blocks[0].norm1_params()
+        n = ops.ln_modulate(x, w0, b0, mods[0][0][0], Lt, cfg.norm_eps)
+        for i, blk in enumerate(blocks):
+            (_, gates1), (mod2, gates2) = mods[i]
+            if i + 1 < len(blocks):
+                (nw, nb), nmod = blocks[i + 1].norm1_params(), mods[i + 1][0][0]
             else:
-                x = blk(x, emb, Lt, rope)
+                (nw, nb), nmod = (_f32(self.norm_final.weight), _f32(self.norm_final.bias)), None
+            args = (x, n, gates1, mod2, gates2, Lt, rope, nw, nb, nmod, cfg.norm_eps)
+            if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
+                x, n = torch.utils.checkpoint.checkpoint(blk, *args, use_reentrant=False)
+            else:
+                x, n = blk(*args)
 
-        hv = x[:, Lt:].contiguous()
-        hv = ops.ln_modulate(hv, _f32(self.norm_final.weight), _f32(self.norm_final.bias), None, 0, cfg.norm_eps)
+        hv = n[:, Lt:].contiguous()          # norm_final was applied to every token by the last fused pass
         m = F.linear(F.silu(emb), self.norm_out.linear.weight, self.norm_out.linear.bias)
         shift, scale = m.chunk(2, dim=1)
         mod = torch.stack([shift, 1 + scale, shift, 1 + scale], dim=1).float().contiguous().detach()
