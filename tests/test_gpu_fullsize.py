@@ -1,0 +1,99 @@
+"""BASELINE config-2 sizes (S = 17 776 tokens, 48 heads, D = 3072) checked through size-independent properties -- no
+O(S^2) reference needed: row-stochastic softmax, linearity in V, key-permutation invariance, gradient checksums,
+scheduler identities, LayerNorm statistics, ln 2 at B = 0.  -m gpu only."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+S, H, TEXT = 17776, 48, 226
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from videogpa_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def qkv():
+    g = torch.Generator(device="cuda").manual_seed(2)
+    q, k, v = (torch.randn(1, H, S, 64, generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
+    return q, k, v
+
+
+def _o(ops, q, k, v):
+    o, lse = ops.attention_fwd_raw(q, k, v)
+    return o.view(1, S, H, 64).permute(0, 2, 1, 3), lse
+
+
+def test_softmax_rows_sum_to_one_constant_v(ops, qkv):
+    q, k, _ = qkv
+    c = torch.linspace(-2, 2, 64, device="cuda").to(torch.bfloat16)
+    o, _ = _o(ops, q, k, c.expand(1, H, S, 64).contiguous())
+    assert (o.float() - c.float()).abs().max().item() <= 0.016     # one bf16 ulp at |c| <= 2
+
+
+def test_linearity_in_v_and_key_permutation_invariance(ops, qkv):
+    q, k, v = qkv
+    g = torch.Generator(device="cuda").manual_seed(3)
+    v2 = torch.randn(1, H, S, 64, generator=g, device="cuda").to(torch.bfloat16)
+    o1, lse1 = _o(ops, q, k, v)
+    o2, _ = _o(ops, q, k, v2)
+    o12, _ = _o(ops, q, k, (v.float() + v2.float()).to(torch.bfloat16))
+    assert (o12.float() - (o1.float() + o2.float())).abs().max().item() < 0.03
+    perm = torch.randperm(S, generator=g, device="cuda")
+    op, lsep = _o(ops, q, k[:, :, perm].contiguous(), v[:, :, perm].contiguous())
+    assert (op.float() - o1.float()).abs().max().item() < 0.01
+    assert (lsep - lse1).abs().max().item() < 2e-3
+
+
+def test_backward_checksums(ops, qkv):
+    """sum_k dV[k] = sum_q dO[q] (rows of P sum to 1);  sum_k dK[k] = 0 and dQ = 0 for identical keys (rows of dS sum to 0)."""
+    q, k, v = qkv
+    g = torch.Generator(device="cuda").manual_seed(4)
+    do = torch.randn(1, H, S, 64, generator=g, device="cuda").to(torch.bfloat16)
+    o, lse = ops.attention_fwd_raw(q, k, v)
+    ov = o.view(1, S, H, 64).permute(0, 2, 1, 3)
+    dq, dk, dv = (torch.empty(1, H, S, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    ops.attention_bwd_raw(q, k, v, ov, do, lse, dq, dk, dv)
+    sdv, sdo = dv.float().sum(2), do.float().sum(2)
+    assert (sdv - sdo).abs().max().item() < 0.02 * sdo.abs().max().item() + 0.5
+    col = dk.float().sum(2).abs().max().item()
+    assert col < 0.02 * dk.float().abs().sum(2).max().item() + 0.05, col
+    kc = k[:, :, :1].expand(1, H, S, 64).contiguous()                 # all keys identical -> uniform attention
+    o2, lse2 = ops.attention_fwd_raw(q, kc, v)
+    s_uniform = (ops.prescale_q(q).float() * kc.float()).sum(-1)       # every key gives the same (log2-domain) score
+    assert (lse2 - (s_uniform + math.log2(S))).abs().max().item() < 2e-2
+    ops.attention_bwd_raw(q, kc, v, o2.view(1, S, H, 64).permute(0, 2, 1, 3), do, lse2, dq, dk, dv)
+    assert dq.float().abs().max().item() < 2e-3
+    assert (o2.view(1, S, H, 64).permute(0, 2, 1, 3).float() - v.float().mean(2, keepdim=True)).abs().max().item() < 0.01
+
+
+def test_scheduler_identity_and_loss_ln2_full_latent(ops):
+    from videogpa_amd.scheduler import CogVideoXDPMScheduler
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B = 2
+    x = (0.7 * torch.randn(B, 2, 13, 16, 60, 90, generator=g, device="cuda")).to(torch.bfloat16)
+    eps = torch.randn(B, 13, 16, 60, 90, generator=g, device="cuda").to(torch.bfloat16)
+    t = torch.tensor([311, 999], device="cuda")
+    sch = CogVideoXDPMScheduler()
+    xt, vt = sch.noise_velocity_paired(x, eps, t)
+    a = sch.alphas_cumprod.to(torch.bfloat16)[t.cpu()].float().cuda().view(B, 1, 1, 1, 1, 1)
+    rec = a.sqrt() * xt.float() - (1 - a).sqrt() * vt.float()          # sqrt(abar) x_t - sqrt(1-abar) v = x
+    assert (rec - x.float()).abs().max().item() < 0.06
+    assert torch.equal(xt[1], eps[1:2].expand(2, -1, -1, -1, -1).reshape(xt[1].shape))   # zero terminal SNR: x_999 = eps
+    out = ops.dpo_loss_paired(xt, xt.clone(), vt, beta=500.0)
+    assert abs(out[0].item() - math.log(2.0)) < 1e-6
+
+
+def test_layernorm_statistics_full_stream(ops):
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = (3 * torch.randn(2, S, 3072, generator=g, device="cuda") + 1.5).to(torch.bfloat16)
+    n = ops.ln_modulate(x, torch.ones(3072, device="cuda"), torch.zeros(3072, device="cuda"), None, 0, 1e-5).float()
+    assert n.mean(-1).abs().max().item() < 2e-3
+    assert (n.var(-1, unbiased=False) - 1).abs().max().item() < 5e-3
