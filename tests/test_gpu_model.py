@@ -214,6 +214,9 @@ def test_i2v_pair_step_with_condition_channels():
     out = tr.shared_step_paired(x_pair, txt, cond_pair=cond_pair)
     assert abs(out.loss.item() - math.log(2.0)) < 1e-6      # LoRA B = 0
     out.loss.backward()
+    assert torch.equal(tr.i2v_condition_pair(img, 3), cond_pair)
+    out2 = tr._shared_step({"x_pair": x_pair, "prompt_emb": txt, "image_latent": img})
+    assert abs(out2.loss.item() - math.log(2.0)) < 1e-6
 
 
 @pytest.mark.parametrize("beta,tol", [(1.0, 1e-3), (50.0, 5e-2)])

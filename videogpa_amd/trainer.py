@@ -98,13 +98,30 @@ class CogVideoXDPOTrainer(nn.Module):
                                                             label_smoothing=lf.label_smoothing, loss_type=lf.loss_type)
         return LossOutput(loss=loss, reward_margin=margin.detach(), winner_reward=wr.detach(), loser_reward=lr.detach(), accuracy=acc.detach())
 
+    @staticmethod
+    def i2v_condition_pair(image_latent, num_frames):
+        """I2V conditioning (train/CogVideoX-I2V-5B/03_train.py:127-136): the first-frame latent [B,1,C,H,W] (already VAE-encoded
+        and scaled -- the VAE is a third-party network outside this path) zero-padded to `num_frames` frames, shared by win
+        and lose -> [B,2,F,C,H,W], concatenated on the channel axis after noising."""
+        B, one, C, H, W = image_latent.shape
+        pad = image_latent.new_zeros(B, num_frames - one, C, H, W)
+        cond = torch.cat([image_latent, pad], dim=1)
+        return torch.stack([cond, cond], dim=1)
+
     def _shared_step(self, batch, timesteps=None, noise=None) -> LossOutput:
-        """Reference-shaped entry: batch['x_win'/'x_lose'] [B,C,F,H,W], batch['prompt_emb'] (:116-157)."""
+        """Reference-shaped entry: batch['x_win'/'x_lose'] [B,C,F,H,W], batch['prompt_emb'] (:116-157); an optional
+        batch['image_latent'] [B,1,C,H,W] (or [B,C,1,H,W]) switches to the I2V form (32 input channels)."""
         if "x_pair" in batch:
             x_pair = batch["x_pair"]
         else:
             x_pair = torch.stack([batch["x_win"].permute(0, 2, 1, 3, 4), batch["x_lose"].permute(0, 2, 1, 3, 4)], dim=1)
-        return self.shared_step_paired(x_pair.contiguous(), batch["prompt_emb"], timesteps, noise)
+        cond_pair = None
+        if batch.get("image_latent") is not None:
+            il = batch["image_latent"]
+            if il.shape[1] != 1:
+                il = il.permute(0, 2, 1, 3, 4)
+            cond_pair = self.i2v_condition_pair(il.to(x_pair.dtype), x_pair.shape[2])
+        return self.shared_step_paired(x_pair.contiguous(), batch["prompt_emb"], timesteps, noise, cond_pair=cond_pair)
 
     def training_step(self, batch, batch_idx=0):
         if self.start_time is None:
