@@ -51,6 +51,12 @@ int32_t vgpa_noise_velocity_paired(const void* x_pair, const void* noise, const 
                                    const float* sqrt_1m_abar, int64_t B, int64_t N, int32_t num_train_timesteps,
                                    int32_t dtype, void* x_noisy_pair, void* v_target_pair, vgpa_stream_t stream);
 
+/* flow-matching variant (train/Wan2.2-TI2V-5B/03_train.py:103-116): x_t = (1-sigma) x + sigma eps (fp32 when xt_f32, as
+ * torch's promotion gives), v = eps - x; sigma fp32 [B]. */
+int32_t vgpa_flow_noise_velocity_paired(const void* x_pair, const void* noise, const float* sigma, int64_t B, int64_t N,
+                                        int32_t dtype, int32_t xt_f32, void* x_noisy_pair, void* v_target_pair,
+                                        vgpa_stream_t stream);
+
 /* ---- AdaLN-Zero pieces of CogVideoXBlock (diffusers CogVideoXLayerNormZero / AdaLayerNorm / LayerNorm), reached
  * from train/CogVideoX-5B/03_train.py:134-151.  x, out, dy, dx: bf16 [B,S,D], text tokens first (rows < text_len).
  * Per-range fp32 vectors [B,D] with a common batch stride; all four modulation pointers NULL = plain LayerNorm. */

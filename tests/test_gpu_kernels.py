@@ -418,3 +418,24 @@ def test_residual_ln_fused_equals_composition(ops, B, S, D, Lt):
     for i in (2, 3):
         sc = u[i].float().abs().max().item()
         assert (f[i].float() - u[i].float()).abs().max().item() <= 0.02 * sc, i
+
+
+def test_flow_matching_noise_velocity_bit_exact(ops):
+    """Wan2.2 flow-matching step inputs (train/Wan2.2-TI2V-5B/03_train.py:103-116,203-207,235-236), bit-exact vs the torch
+    expressions of the reference incl. its fp32 promotion of x_t."""
+    g = torch.Generator().manual_seed(21)
+    B, shape = 3, (48, 5, 6, 8)                                   # Wan latents are [C,F,H,W]
+    x = torch.randn(B, 2, *shape, generator=g).to(torch.bfloat16)
+    eps = torch.randn(B, *shape, generator=g).to(torch.bfloat16)
+    t = torch.tensor([1, 500, 999])
+    sigma = ops.flow_sigma(t, 1000, 5.0)
+    s_ref = t.float() / 1000
+    s_ref = 5.0 * s_ref / (1 + (5.0 - 1) * s_ref)
+    assert torch.equal(sigma, s_ref)
+    xt, v = ops.flow_noise_velocity_paired(dev(x), dev(eps), dev(sigma))
+    sg = s_ref.view(B, 1, 1, 1, 1)
+    for p in range(2):
+        ref_xt = (1.0 - sg) * x[:, p] + sg * eps
+        assert ref_xt.dtype == torch.float32 and xt.dtype == torch.float32
+        assert torch.equal(xt[:, p].cpu(), ref_xt)
+        assert torch.equal(v[:, p].cpu(), eps - x[:, p])

@@ -21,6 +21,7 @@ SIGNATURES = {
     "vgpa_dpo_loss_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, F32, I32, I32, P, P, P, P, SZ, P]),
     "vgpa_dpo_loss_bwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I32, F32, I32, P, P, P, P, P]),
     "vgpa_noise_velocity_paired": (I32, [P, P, P, P, P, I64, I64, I32, I32, P, P, P]),
+    "vgpa_flow_noise_velocity_paired": (I32, [P, P, P, I64, I64, I32, I32, P, P, P]),
     "vgpa_ln_modulate_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P, P, P, P]),
     "vgpa_ln_modulate_bwd": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P]),
     "vgpa_residual_ln_fwd": (I32, [P, P, P, P, I64, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P, P, P, P, P]),

@@ -50,6 +50,53 @@ __global__ __launch_bounds__(256) void noise_velocity_kernel(const void* __restr
     }
 }
 
+// Flow-matching form (train/Wan2.2-TI2V-5B/03_train.py:103-116,203-207,235-236): sigma[b] fp32,
+//   x_t = (1 - sigma) * x + sigma * eps   evaluated in fp32 as torch's type promotion does (fp32 sigma times bf16 latent),
+//   v   = eps - x                         in the latent dtype.
+// XT_F32 selects an fp32 x_t (the reference's result dtype) or one rounded to the latent dtype.
+template <int DT, bool XT_F32>
+__global__ __launch_bounds__(256) void flow_noise_velocity_kernel(const void* __restrict__ x, const void* __restrict__ noise,
+                                                                    const float* __restrict__ sigma, int64_t N, void* __restrict__ xt,
+                                                                    void* __restrict__ v) {
+    const int b = blockIdx.y;
+    const float sg = sigma[b];
+    const float om = 1.0f - sg;
+    const size_t on = (size_t)b * N, ox = (size_t)b * 2 * N;
+    const int64_t n8 = N >> 3;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n8; c += (int64_t)gridDim.x * 256) {
+        const size_t i = (size_t)c << 3;
+        float e[8], a[8], o1[8], o2[8];
+        load8<DT>(noise, on + i, e);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            load8<DT>(x, ox + (size_t)p * N + i, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o1[j] = om * a[j] + sg * e[j];
+                o2[j] = rnd<DT>(e[j] - a[j]);
+            }
+            if (XT_F32) store8<VGPA_DTYPE_F32>(xt, ox + (size_t)p * N + i, o1);
+            else store8<DT>(xt, ox + (size_t)p * N + i, o1);
+            store8<DT>(v, ox + (size_t)p * N + i, o2);
+        }
+    }
+}
+
+extern "C" int32_t vgpa_flow_noise_velocity_paired(const void* x_pair, const void* noise, const float* sigma, int64_t B, int64_t N, int32_t dtype,
+                                                   int32_t xt_f32, void* x_noisy_pair, void* v_target_pair, hipStream_t stream) {
+    if (!x_pair || !noise || !sigma || !x_noisy_pair || !v_target_pair || B <= 0 || N <= 0 || B > 65535 || N % 8 != 0) return VGPA_ERR_INVALID;
+    int64_t nb = (N / 8 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    dim3 grid((unsigned)nb, (unsigned)B);
+#define FL(DT, F) VGPA_LAUNCH((flow_noise_velocity_kernel<DT, F>), grid, dim3(256), 0, stream, x_pair, noise, sigma, N, x_noisy_pair, v_target_pair)
+    if (dtype == VGPA_DTYPE_BF16) { if (xt_f32) FL(VGPA_DTYPE_BF16, true); else FL(VGPA_DTYPE_BF16, false); }
+    else if (dtype == VGPA_DTYPE_F32) FL(VGPA_DTYPE_F32, true);
+    else return VGPA_ERR_INVALID;
+#undef FL
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
 extern "C" int32_t vgpa_noise_velocity_paired(const void* x_pair, const void* noise, const int64_t* t, const float* sqrt_abar,
                                               const float* sqrt_1m_abar, int64_t B, int64_t N, int32_t num_train_timesteps,
                                               int32_t dtype, void* x_noisy_pair, void* v_target_pair, hipStream_t stream) {

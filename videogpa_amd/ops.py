@@ -155,6 +155,25 @@ def noise_velocity_paired(x_pair, noise, t, sqrt_abar, sqrt_1m_abar):
     return xt, v
 
 
+def flow_sigma(timesteps, num_train_timesteps=1000, shift=5.0):
+    """get_sigma_from_timestep (train/Wan2.2-TI2V-5B/03_train.py:103-106)."""
+    s = timesteps.float() / num_train_timesteps
+    return shift * s / (1 + (shift - 1) * s)
+
+
+def flow_noise_velocity_paired(x_pair, noise, sigma, xt_fp32=True):
+    """Flow-matching noising + velocity target over the paired layout: x_pair [B,2,...], noise [B,...], sigma [B] fp32 ->
+    (x_t pair [fp32 like the reference's promoted result, or latent dtype], v-target pair = noise - x)."""
+    dt = x_pair.dtype
+    _req(x_pair, dt), _req(noise, dt), _req(sigma, torch.float32)
+    B = x_pair.shape[0]
+    N = noise.numel() // B
+    xt = torch.empty(x_pair.shape, dtype=torch.float32 if (xt_fp32 or dt == torch.float32) else dt, device=x_pair.device)
+    v = torch.empty_like(x_pair)
+    _lib.call("vgpa_flow_noise_velocity_paired", x_pair, noise, sigma, B, N, _DT[dt], 1 if xt.dtype == torch.float32 else 0, xt, v, _stream())
+    return xt, v
+
+
 # --------------------------------------------------------------------------------------------- AdaLN-Zero pieces
 class _LNModulateFn(torch.autograd.Function):
     @staticmethod
