@@ -335,13 +335,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             dp = mfma32(kx, dx, dp);                                                                     // - delta[q]
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(vl, kb * 32, ks, lane), dof[ks], dp);   // dP^T[key,q] - delta
+            if (tail) {   // keys past the end contribute nothing: exp2(-inf) = 0 (masking kept out of the exp loop)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * TILE + kb * 32 + acc_row(r, hi) >= S) s[r] = -INFINITY;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-                if (tail) {
-                    if (t * TILE + kb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
-                    if (t * TILE + kb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
-                }
+                const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
                 f32x2_t d = {dp[r], dp[r + 1]};
                 d = d * p;                                                                               // dS^T
                 s[r] = d[0];
@@ -466,13 +467,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key] - delta
             f32x16_t ds;
+            if (tail) {   // query rows past the end: exp2(-inf) = 0 (masking kept out of the exp loop)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * TILE + qb * 32 + acc_row(r, hi) >= S) s[r] = -INFINITY;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-                if (tail) {
-                    if (t * TILE + qb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
-                    if (t * TILE + qb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
-                }
+                const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
                 f32x2_t d = {dp[r], dp[r + 1]};
                 d = d * p;
                 s[r] = p[0];
@@ -647,13 +649,14 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key] - delta
             f32x16_t ds;
+            if (tail) {   // query rows past the end: exp2(-inf) = 0 (masking kept out of the exp loop)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (tq * TILE + qb * 32 + acc_row(r, hi) >= S) s[r] = -INFINITY;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-                if (tail) {
-                    if (tq * TILE + qb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
-                    if (tq * TILE + qb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
-                }
+                const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
                 f32x2_t d = {dp[r], dp[r + 1]};
                 d = d * p;
                 s[r] = p[0];
