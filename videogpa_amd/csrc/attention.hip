@@ -460,12 +460,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             f32x16_t s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-            s = mfma32(frag_row(ql, qb * 32, 4, lane), ones, s);                                         // - lse2[q]
+            // all ten row fragments of this q-block are read up front so the two MFMA chains below issue back to back
+            bf16x8_t qa[5], da[5];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(ql, qb * 32, ks, lane), kf[ks], s);      // S[q,key] - lse2
-            dp = mfma32(frag_row(dol, qb * 32, 4, lane), ones, dp);                                      // - delta[q]
+            for (int ks = 0; ks < 5; ++ks) { qa[ks] = frag_row(ql, qb * 32, ks, lane); da[ks] = frag_row(dol, qb * 32, ks, lane); }
+            s = mfma32(qa[4], ones, s);                                                                  // - lse2[q]
+            dp = mfma32(da[4], ones, dp);                                                                // - delta[q]
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key] - delta
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(qa[ks], kf[ks], s);                                                           // S[q,key] - lse2
+                dp = mfma32(da[ks], vf[ks], dp);                                                         // dP[q,key] - delta
+            }
             f32x16_t ds;
             if (tail) {   // query rows past the end: exp2(-inf) = 0 (masking kept out of the exp loop)
 #pragma unroll
