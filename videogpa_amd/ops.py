@@ -27,6 +27,38 @@ def _i64x3(*v):
     return (ctypes.c_int64 * 3)(*v)
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual kernel launches on the launch stream (bench.py's live roofline leg).
+    Disabled (None) by default: zero overhead in the product path."""
+
+    def __init__(self):
+        self.records = {}
+
+    def run(self, name, work, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.setdefault(name, []).append((a, b, work))
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "work_per_launch": recs[0][2]}
+        return out
+
+
+TIMER = None   # set to a KernelTimer() to time launches
+
+
+def _timed(name, work, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.run(name, work, fn)
+
+
 # --------------------------------------------------------------------------------------------- DPO loss
 class _DPOLossFn(torch.autograd.Function):
     @staticmethod
@@ -440,38 +472,6 @@ def _bhs_strides(t):
     """element strides {batch, head, token} of a [B,H,S,64] view"""
     assert t.stride(3) == 1
     return _i64x3(t.stride(0), t.stride(1), t.stride(2))
-
-
-class KernelTimer:
-    """Optional HIP-event timing of individual kernel launches on the launch stream (bench.py's live roofline leg).
-    Disabled (None) by default: zero overhead in the product path."""
-
-    def __init__(self):
-        self.records = {}
-
-    def run(self, name, work, fn):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        fn()
-        b.record()
-        self.records.setdefault(name, []).append((a, b, work))
-
-    def summary(self):
-        out = {}
-        for name, recs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "work_per_launch": recs[0][2]}
-        return out
-
-
-TIMER = None   # set to a KernelTimer() to time launches
-
-
-def _timed(name, work, fn):
-    if TIMER is None:
-        fn()
-    else:
-        TIMER.run(name, work, fn)
 
 
 LOG2E = 1.4426950408889634
