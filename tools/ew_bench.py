@@ -44,3 +44,6 @@ xr2 = x.clone().requires_grad_(True)
 n1 = ops.ln_modulate_v1(xr2, w, bb, mod, Lt, 1e-5)
 show("ln_modulate v1 bwd", t(lambda: torch.autograd.grad(n1, xr2, y, retain_graph=True)), 3)
 show("gelu fwd", t(lambda: ops.gelu_tanh(u)), 8)
+ur = u.clone().requires_grad_(True)
+gu = ops.gelu_tanh(ur)
+show("gelu bwd", t(lambda: torch.autograd.grad(gu, ur, u, retain_graph=True)), 12)

@@ -193,9 +193,10 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* __rest
 }
 
 __device__ __forceinline__ float tanh_fast(float z) {
-    // 1 - 2/(1+e^{2z}); saturates cleanly for |z| large
-    const float e = __expf(2.f * z);
-    return 1.f - 2.f / (1.f + e);
+    // tanh z = 1 - 2/(1 + e^{2z}) with the hardware exp2 / rcp (1 ulp-class; the result is rounded to bf16 anyway).
+    // e^{2z} -> inf gives 1, -> 0 gives -1: saturates cleanly.
+    const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);   // 2 * log2(e)
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
 }
 
 __global__ __launch_bounds__(256) void gelu_tanh_fwd_kernel(const bf16_t* __restrict__ u, int64_t total8, bf16_t* __restrict__ out) {
