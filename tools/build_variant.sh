@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build a variant libvgpa_hip.so with extra -D flags on attention.hip (for A/B runs inside ONE gpurun session):
+#   tools/build_variant.sh NAME [-DFOO ...]   ->  var/lib_NAME.so   (swap in with: cp var/lib_NAME.so videogpa_amd/csrc/libvgpa_hip.so)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+python -m videogpa_amd.build >/dev/null
+mkdir -p var /tmp/vobj_$name
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -munsafe-fp-atomics -Wno-unused-function \
+  -I include -I videogpa_amd/csrc "$@" -c videogpa_amd/csrc/attention.hip -o /tmp/vobj_$name/attention.o
+objs=$(ls videogpa_amd/csrc/_obj/*.o | grep -v attention.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/vobj_$name/attention.o -o var/lib_$name.so
+echo "built var/lib_$name.so"

@@ -102,19 +102,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     tile_load(Vb, sv.s, 0, S, vr);
     tile_store(lds, kr);
     tile_store(lds + 2 * TILE_ELEMS, vr);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) frags_arrived(qf[j]);
+    const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
+    const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const bf16_t* kl = lds + (t & 1) * TILE_ELEMS;
         const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
         if (t + 1 < nt) {
-            tile_load(Kb, sk.s, (t + 1) * TILE, S, kr);
-            tile_load(Vb, sv.s, (t + 1) * TILE, S, vr);
+            tile_load_buf(krs, sk.s, (t + 1) * TILE, koff, kr);
+            tile_load_buf(vrs, sv.s, (t + 1) * TILE, voff, vr);
         }
         const bool tail = (t == nt - 1) && (S & (TILE - 1));
         f32x16_t s[QB][2];
         float psum[QB];
-        bool slow = (t == 0);
+        bool slow = (t == 0) || tail;   // the ragged last tile is masked on the slow path only: the fast path stays branch-free
         if (!slow) {
             // fast path: accumulators = c*q.k - m  ->  P = exp2(.)
 #pragma unroll
@@ -139,11 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        f32x2_t p = {__builtin_amdgcn_exp2f(s[j][kb][r]), __builtin_amdgcn_exp2f(s[j][kb][r + 1])};
-                        if (tail) {
-                            if (t * TILE + kb * 32 + acc_row(r, hi) >= S) p[0] = 0.f;
-                            if (t * TILE + kb * 32 + acc_row(r + 1, hi) >= S) p[1] = 0.f;
-                        }
+                        const f32x2_t p = {__builtin_amdgcn_exp2f(s[j][kb][r]), __builtin_amdgcn_exp2f(s[j][kb][r + 1])};
                         s[j][kb][r] = p[0];
                         s[j][kb][r + 1] = p[1];
                         ps2 += p;
@@ -276,27 +276,35 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =====================================================================================================
 // Backward, dQ:  dQ = scale * sum_k dS[q,k] K[k],  dS = P o (dP - delta),  P = exp2(c*s - lse2),  dP = dO V^T
 // =====================================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
-                                                            const float* __restrict__ LSE2, const float* __restrict__ DELTA,
-                                                            bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo,
-                                                            TStride sdq, int S, int H, int n_qt, float scale) {
+template <int QB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                               const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                               bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo,
+                                                               TStride sdq, int S, int H, int n_qt, float scale) {
+    // a wave owns QB blocks of 32 query rows: every K / V fragment read from LDS feeds QB MFMAs
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // K[2], V[2]
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = vid / n_qt, qt = vid % n_qt;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int q0 = qt * WG_ROWS + wave * 32;
+    const int q0 = (qt * 4 + wave) * (32 * QB);
 
     const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
     const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
-    bf16x8_t qf[4], dof[4];
-    load_row_frags(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0, S, lane, qf);
-    load_row_frags(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0, S, lane, dof);
-    int qc = q0 + (lane & 31);
-    qc = qc < S ? qc : S - 1;
-    const bf16x8_t qx = shift_frag(LSE2[(int64_t)bh * S + qc], hi);   // -lse folded into the QK^T chain (see forward)
-    const bf16x8_t dx = shift_frag(DELTA[(int64_t)bh * S + qc], hi);  // -delta folded into the dP chain
+    bf16x8_t qf[QB][4], dof[QB][4], qx[QB], dx[QB];
+    f32x16_t dq[QB][2];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        load_row_frags(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0 + 32 * j, S, lane, qf[j]);
+        load_row_frags(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0 + 32 * j, S, lane, dof[j]);
+        int qc = q0 + 32 * j + (lane & 31);
+        qc = qc < S ? qc : S - 1;
+        qx[j] = shift_frag(LSE2[(int64_t)bh * S + qc], hi);   // -lse folded into the QK^T chain (see forward)
+        dx[j] = shift_frag(DELTA[(int64_t)bh * S + qc], hi);  // -delta folded into the dP chain
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dq[j][0][i] = 0.f; dq[j][1][i] = 0.f; }
+    }
     bf16x8_t kx;
     {
         float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -304,55 +312,76 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         kx = f32_to_frag(o8);
     }
 
-    f32x16_t dq[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
-
     const int nt = (S + TILE - 1) / TILE;
     u32x4_t kr[2], vr[2];
     tile_load(Kb, sk.s, 0, S, kr);
     tile_load(Vb, sv.s, 0, S, vr);
     tile_store(lds, kr);
     tile_store(lds + 2 * TILE_ELEMS, vr);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) { frags_arrived(qf[j]); frags_arrived(dof[j]); }
+    const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
+    const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const bf16_t* kl = lds + (t & 1) * TILE_ELEMS;
         const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
         if (t + 1 < nt) {
-            tile_load(Kb, sk.s, (t + 1) * TILE, S, kr);
-            tile_load(Vb, sv.s, (t + 1) * TILE, S, vr);
+            tile_load_buf(krs, sk.s, (t + 1) * TILE, koff, kr);
+            tile_load_buf(vrs, sv.s, (t + 1) * TILE, voff, vr);
         }
         const bool tail = (t == nt - 1) && (S & (TILE - 1));
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16_t s, dp;
+            f32x16_t s[QB], dp[QB];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-            s = mfma32(kx, qx, s);                                                                       // - lse2[q]
+            for (int j = 0; j < QB; ++j) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(kl, kb * 32, ks, lane), qf[ks], s);      // S^T[key,q] - lse2
-            dp = mfma32(kx, dx, dp);                                                                     // - delta[q]
+                for (int i = 0; i < 16; ++i) { s[j][i] = 0.f; dp[j][i] = 0.f; }
+                s[j] = mfma32(kx, qx[j], s[j]);                                                          // - lse2[q]
+                dp[j] = mfma32(kx, dx[j], dp[j]);                                                        // - delta[q]
+            }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(vl, kb * 32, ks, lane), dof[ks], dp);   // dP^T[key,q] - delta
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) s[j] = mfma32(kf, qf[j][ks], s[j]);                         // S^T[key,q] - lse2
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t vf = frag_row(vl, kb * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) dp[j] = mfma32(vf, dof[j][ks], dp[j]);                      // dP^T[key,q] - delta
+            }
             if (tail) {   // keys past the end contribute nothing: exp2(-inf) = 0 (masking kept out of the exp loop)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t * TILE + kb * 32 + acc_row(r, hi) >= S) s[r] = -INFINITY;
+                for (int j = 0; j < QB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * TILE + kb * 32 + acc_row(r, hi) >= S) s[j][r] = -INFINITY;
             }
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-                f32x2_t d = {dp[r], dp[r + 1]};
-                d = d * p;                                                                               // dS^T
-                s[r] = d[0];
-                s[r + 1] = d[1];
-            }
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t p = {__builtin_amdgcn_exp2f(s[j][r]), __builtin_amdgcn_exp2f(s[j][r + 1])};
+                    f32x2_t d = {dp[j][r], dp[j][r + 1]};
+                    d = d * p;                                                                           // dS^T
+                    s[j][r] = d[0];
+                    s[j][r + 1] = d[1];
+                }
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const bf16x8_t dsf = pack_frag(s, 8 * cc);
+                bf16x8_t dsf[QB];
 #pragma unroll
-                for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_tr(kl, kb * 32 + 16 * cc, db * 32, lane), dsf, dq[db]);  // dQ^T[d,q]
+                for (int j = 0; j < QB; ++j) dsf[j] = pack_frag(s[j], 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8_t ktf = frag_tr(kl, kb * 32 + 16 * cc, db * 32, lane);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) dq[j][db] = mfma32(ktf, dsf[j], dq[j][db]);             // dQ^T[d,q]
+                }
             }
         }
         if (t + 1 < nt) {
@@ -361,18 +390,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         }
         __syncthreads();
     }
-    const int q = q0 + (lane & 31);
-    if (q < S) {
-        bf16_t* op = dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s);
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int j = 0; j < QB; ++j) {
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < S) {
+            bf16_t* op = dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2_t w;
-                w[0] = pack_bf16x2(dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale);
-                w[1] = pack_bf16x2(dq[db][4 * g + 2] * scale, dq[db][4 * g + 3] * scale);
-                *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
-            }
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t w;
+                    w[0] = pack_bf16x2(dq[j][db][4 * g] * scale, dq[j][db][4 * g + 1] * scale);
+                    w[1] = pack_bf16x2(dq[j][db][4 * g + 2] * scale, dq[j][db][4 * g + 3] * scale);
+                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+                }
+        }
     }
 }
 
@@ -444,14 +476,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     tile_store(lds, qr);
     tile_store(lds + 2 * TILE_ELEMS, dor);
     stat_store(0);
+    frags_arrived(kf);
+    frags_arrived(vf);
+    const rsrc_t qrs = tile_rsrc(Qb, sq.s, S), dors = tile_rsrc(dOb, sdo.s, S);
+    const uint32_t qoff = tile_lane_byte_offset(sq.s), dooff = tile_lane_byte_offset(sdo.s);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const bf16_t* ql = lds + (t & 1) * TILE_ELEMS;
         const bf16_t* dol = lds + (2 + (t & 1)) * TILE_ELEMS;
         if (t + 1 < nt) {
-            tile_load(Qb, sq.s, (t + 1) * TILE, S, qr);
-            tile_load(dOb, sdo.s, (t + 1) * TILE, S, dor);
+            tile_load_buf(qrs, sq.s, (t + 1) * TILE, qoff, qr);
+            tile_load_buf(dors, sdo.s, (t + 1) * TILE, dooff, dor);
             stat_load(t + 1);
         }
         const bool tail = (t == nt - 1) && (S & (TILE - 1));
@@ -745,6 +781,9 @@ static inline bool range_ok(const int64_t* st, int64_t B, int64_t H, int64_t S) 
 static inline TStride mk(const int64_t* st) { TStride t; t.b = (uint32_t)st[0]; t.h = (uint32_t)st[1]; t.s = (uint32_t)st[2]; return t; }
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+#ifndef DQ_QB
+#define DQ_QB 2    // query blocks (of 32 rows) per wave in the dQ kernel
+#endif
 #ifndef FWD_QB
 #define FWD_QB 2   // query blocks (of 32 rows) per wave in the forward kernel
 #endif
@@ -816,8 +855,8 @@ int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dq_strides) ||
         !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dq))
         return VGPA_ERR_INVALID;
-    const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
-    VGPA_LAUNCH(attn_bwd_dq_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+    const int n_t = (int)((S + DQ_QB * WG_ROWS - 1) / (DQ_QB * WG_ROWS));
+    VGPA_LAUNCH((attn_bwd_dq_kernel<DQ_QB>), dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides),
                        mk(do_strides), mk(dq_strides), (int)S, (int)H, n_t, scale);
     VGPA_CHECK_LAUNCH();

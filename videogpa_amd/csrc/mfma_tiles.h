@@ -48,6 +48,22 @@ __device__ __forceinline__ void tile_load(const bf16_t* base, uint32_t row_strid
         r[j] = *reinterpret_cast<const u32x4_t*>(base + ((uint32_t)row * row_stride + (uint32_t)((c & 7) * 8)));
     }
 }
+// The loop form: buffer loads.  The descriptor covers rows [0, S) of one (batch, head) slice, the per-lane byte offset
+// is computed once, the tile's row offset rides in an SGPR -- no per-iteration address VALU (the clamped form above
+// costs ~20 VALU instructions per tile in loops that are VALU-issue bound) -- and rows at or past S are out of range,
+// i.e. read as zeros, so the ragged last tile needs no special load path.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t tile_rsrc(const bf16_t* base /* wave-uniform */, uint32_t row_stride, int S) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, ((uint32_t)(S - 1) * row_stride + (uint32_t)HD) * 2u, 0x00020000);
+}
+__device__ __forceinline__ uint32_t tile_lane_byte_offset(uint32_t row_stride) {
+    return ((uint32_t)(threadIdx.x >> 3) * row_stride + (uint32_t)((threadIdx.x & 7) * 8)) * 2u;
+}
+__device__ __forceinline__ void tile_load_buf(rsrc_t rs, uint32_t row_stride, int row0, uint32_t lane_off, u32x4_t (&r)[2]) {
+    const uint32_t soff = (uint32_t)row0 * row_stride * 2u;   // uniform
+    r[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, soff, 0);
+    r[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, soff + 64u * row_stride, 0);   // rows +32
+}
 __device__ __forceinline__ void tile_store(bf16_t* lds, const u32x4_t (&r)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -85,6 +101,15 @@ __device__ __forceinline__ void load_row_frags(const bf16_t* base, uint32_t row_
     const bf16_t* p = base + ((uint32_t)r * row_stride + (uint32_t)((lane >> 5) * 8));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(p + ks * 16);
+}
+
+// Make the compiler wait HERE for fragments loaded from HBM (a zero-instruction use).  Without it hipcc's waitcnt pass
+// first meets the use inside the tile loop, keeps "a VMEM load may still be writing these registers" in the loop-header
+// state, and emits s_waitcnt vmcnt(3..0) in front of the loop's MFMAs -- which also drains the loop's own K/V prefetch
+// loads in every iteration.
+__device__ __forceinline__ void frags_arrived(const bf16x8_t (&f)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(f[ks]));
 }
 
 // row index inside a 32-row MFMA block of accumulator register r for this lane
