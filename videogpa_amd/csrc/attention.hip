@@ -51,6 +51,21 @@ __device__ __forceinline__ bf16x8_t shift_frag(float m, int hi) {
     return f32_to_frag(o);
 }
 
+// -DFWD_DIAG: s_memtime stamps at four points of tiles 128..131 plus HW_ID, written INTO THE LSE BUFFER (the results are
+// then wrong by design); decoded by tools/fwd_diag.py.  -DFWD_DYN_LDS=90000 forces one workgroup per CU.
+#ifdef FWD_DIAG
+#define DIAG_STAMP(P)                                                                               \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) if (t == 128 + i_) diag_t[4 * i_ + (P)] = (unsigned)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#else
+#define DIAG_STAMP(P)
+#endif
+#ifndef FWD_DYN_LDS
+#define FWD_DYN_LDS 0
+#endif
 #define PSUM_TRIGGER 1024.0f   // a half-lane tile sum above this (or inf/NaN) means some score outgrew the running max by > ~2^5
 
 // QB = 32-row query blocks per wave.
@@ -106,6 +121,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int j = 0; j < QB; ++j) frags_arrived(qf[j]);
     const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
     const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
+#ifdef FWD_DIAG
+    unsigned diag_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long diag_start = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
@@ -116,6 +135,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             tile_load_buf(vrs, sv.s, (t + 1) * TILE, voff, vr);
         }
         const bool tail = (t == nt - 1) && (S & (TILE - 1));
+        DIAG_STAMP(0);
         f32x16_t s[QB][2];
         float psum[QB];
         bool slow = (t == 0) || tail;   // the ragged last tile is masked on the slow path only: the fast path stays branch-free
@@ -202,8 +222,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 psum[j] = ps;
             }
         }
+        DIAG_STAMP(1);
 #pragma unroll
         for (int j = 0; j < QB; ++j) l[j] += psum[j];
+        if (t + 1 < nt) {   // the other buffer is free since the last barrier: store before the PV product so the LDS write latency hides under it
+            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
+            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, vr);
+        }
         // O^T[d, q] += V^T[d, key] P^T[key, q]; each V fragment feeds all QB query blocks
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -219,13 +244,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                     for (int j = 0; j < QB; ++j) o[j][db] = mfma32(vf, pf[j], o[j][db]);
                 }
             }
-        if (t + 1 < nt) {
-            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
-            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, vr);
-        }
+        DIAG_STAMP(2);
         __syncthreads();
+        DIAG_STAMP(3);
     }
 
+#ifdef FWD_DIAG
+    {
+        const unsigned long long diag_end = __builtin_amdgcn_s_memtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) {
+            unsigned* d = reinterpret_cast<unsigned*>(LSE2) + ((size_t)blockIdx.x * 4 + wave) * 32;
+            d[0] = hwid; d[1] = xcc; d[2] = (unsigned)diag_start; d[3] = (unsigned)(diag_start >> 32);
+            d[4] = (unsigned)diag_end; d[5] = (unsigned)(diag_end >> 32); d[6] = vid; d[7] = 0;
+            for (int i = 0; i < 16; ++i) d[16 + i] = diag_t[i];
+        }
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const float lt = l[j] + other_half(l[j]);
@@ -242,7 +279,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                     w[1] = pack_bf16x2(o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
                     *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
                 }
+#ifndef FWD_DIAG
             if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
+#endif
         }
     }
 }
@@ -805,7 +844,7 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
     const int n_qt = (int)((S + FWD_QB * WG_ROWS - 1) / (FWD_QB * WG_ROWS));
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
-    VGPA_LAUNCH((attn_fwd_kernel<FWD_QB>), dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+    VGPA_LAUNCH((attn_fwd_kernel<FWD_QB>), dim3((unsigned)nblk), dim3(256), FWD_DYN_LDS, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                 (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
