@@ -356,6 +356,31 @@ def test_attention_outlier_scores_late_rescale_many_tiles(ops):
     assert torch.isfinite(lse).all()
 
 
+@pytest.mark.parametrize("S", [130, 1000])
+def test_attention_extreme_outliers_strip_redo(ops, S):
+    """Scores that outgrow the running max by more than the optimistic exp2 can represent (> 2^64, and > 2^128 = inf) in
+    late tiles: the forward has to notice and redo the query strip with the plain online softmax.  Also an early huge
+    score followed by ordinary ones (everything after it underflows against the new max)."""
+    g = torch.Generator().manual_seed(S)
+    B, H = 1, 2
+    q, k, v = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16) for _ in range(3))
+    for key, row, gain in ((S - 3, 5, 70.0), (S - 60, 40, 130.0), (70, 9, 200.0)):
+        k[0, 0, key] = (q[0, 0, row].float() * gain / 8).to(torch.bfloat16)
+    # scores of +-100 nats make the result ill-conditioned in the bf16 rounding of q*scale*log2(e): hand the kernel the
+    # pre-scaled q (its documented contract) and build the fp64 reference from exactly those values
+    qp = (q.float() * (0.125 * 1.4426950408889634)).to(torch.bfloat16)
+    o, lse = ops.attention_fwd_raw(dev(qp), dev(k), dev(v), q_prescaled=True)
+    s2 = qp.double() @ k.double().transpose(-1, -2)                      # log2 units
+    mx = s2.max(-1, keepdim=True).values
+    p = torch.exp2(s2 - mx)
+    o_ref = (p @ v.double()) / p.sum(-1, keepdim=True)
+    lse_ref = (mx + torch.log2(p.sum(-1, keepdim=True))).squeeze(-1)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    err = (o.view(B, S, H, 64).permute(0, 2, 1, 3).double().cpu() - o_ref).abs()
+    assert (err <= 0.02 + 0.008 * o_ref.abs()).all(), err.max().item()   # 0.008 |o|: bf16 rounding of one-hot rows (|v| up to ~4)
+    assert ((lse.double().cpu() - lse_ref).abs() <= 1e-3 + 1e-5 * lse_ref.abs()).all()
+
+
 def test_cabi_rejects_bad_arguments(ops):
     from videogpa_amd import _lib
     lib = _lib.load()

@@ -76,8 +76,8 @@ __device__ __forceinline__ bf16x8_t shift_frag(float m, int hi) {
 //    tile's partial sum is checked; only when a wave sees a sum above PSUM_TRIGGER (always on the first tile) does it
 //    take the slow path: recompute S, take the true max, raise m, rescale O and l (wave-uniform, so both half-lanes
 //    of a row always share one m).  P stays <= ~2^10, harmless in bf16 / fp32.
-template <int QB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int QB, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 && QB == 1) ? 4 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                          float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
                                                          int S, int H, int n_qt) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int bh = vid / n_qt, qt = vid % n_qt;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int q0 = (qt * 4 + wave) * (32 * QB);
+    const int q0 = (qt * NW + wave) * (32 * QB);
 
     const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
     const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
 
     const int nt = (S + TILE - 1) / TILE;
-    u32x4_t kr[2], vr[2];
+    u32x4_t kr[8 / NW], vr[8 / NW];
     tile_load(Kb, sk.s, 0, S, kr);
     tile_load(Vb, sv.s, 0, S, vr);
     tile_store(lds, kr);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         if (lane == 0) {
-            unsigned* d = reinterpret_cast<unsigned*>(LSE2) + ((size_t)blockIdx.x * 4 + wave) * 32;
+            unsigned* d = reinterpret_cast<unsigned*>(LSE2) + ((size_t)blockIdx.x * NW + wave) * 32;
             d[0] = hwid; d[1] = xcc; d[2] = (unsigned)diag_start; d[3] = (unsigned)(diag_start >> 32);
             d[4] = (unsigned)diag_end; d[5] = (unsigned)(diag_end >> 32); d[6] = vid; d[7] = 0;
             for (int i = 0; i < 16; ++i) d[16 + i] = diag_t[i];
@@ -282,6 +282,288 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #ifndef FWD_DIAG
             if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
 #endif
+        }
+    }
+}
+
+// =====================================================================================================
+// Forward, software-pipelined (what vgpa_attn_fwd launches; the kernel above is kept as -DFWD_V1 for the phase-stamp
+// diagnostics and as the reference point of DESIGN.md 4.1).  The tile loop body is ONE basic block in which independent work of
+// neighbouring half-tiles (32 keys) can overlap inside a wave:
+//     sB = QK^T(t, keys 32..63)   ||  pA = exp2(sA)            sA = scores of (t, keys 0..31), made one step earlier
+//     O += V^T pA^T               ||  pB = exp2(sB)
+//     sA = QK^T(t+1, keys 0..31)  ||  O += V^T pB^T
+// with the same 64 score registers (exp in place; a half is overwritten right after its PV consumed it).  To make that
+// legal the softmax check moves BEHIND the PV product: P is formed against the running max m, the tile is accumulated
+// unconditionally, and only then is the tile's partial sum looked at.  A sum above PSUM_TRIGGER means some score
+// outgrew m; O and l are still exactly consistent (everything is scaled by 2^-m), so the repair is "raise m to the true
+// max, rescale O, l and the already-made sA" -- nothing is recomputed.  What cannot be repaired is an overflow inside a
+// single tile (a score > m + 64 in log2 units; impossible for LayerNorm-ed q, k with sane weights): it sets a workgroup
+// flag and the q-strip is redone by the plain online-softmax loop (safe_tile for every tile), which also handles the
+// first tile (establishes m) and the ragged last tile.  K tiles: 3-slot LDS ring, V tiles: 2-slot ring.
+// =====================================================================================================
+#define PSUM_OVERFLOW 1.8446744e19f   // 2^64: a half-lane tile sum above this (or NaN) -> redo the strip in safe mode
+
+template <int QB>
+__device__ __forceinline__ void qk_half(const bf16_t* kl, int kb, int lane, const bf16x8_t& kx, const bf16x8_t (&qx)[QB],
+                                        const bf16x8_t (&qf)[QB][4], f32x16_t (&s)[QB]) {
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[j][i] = 0.f;
+        s[j] = mfma32(kx, qx[j], s[j]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) s[j] = mfma32(kf, qf[j][ks], s[j]);
+    }
+}
+
+template <int QB>
+__device__ __forceinline__ void exp_half(f32x16_t (&s)[QB], f32x2_t (&ps2)[QB]) {
+#pragma unroll
+    for (int j = 0; j < QB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2_t p = {__builtin_amdgcn_exp2f(s[j][r]), __builtin_amdgcn_exp2f(s[j][r + 1])};
+            s[j][r] = p[0];
+            s[j][r + 1] = p[1];
+            ps2[j] += p;
+        }
+}
+
+template <int QB>
+__device__ __forceinline__ void pv_half(const bf16_t* vl, int kb, int lane, const f32x16_t (&s)[QB], f32x16_t (&o)[QB][2]) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        bf16x8_t pf[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) pf[j] = pack_frag(s[j], 8 * cc);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const bf16x8_t vf = frag_tr(vl, kb * 32 + 16 * cc, db * 32, lane);
+#pragma unroll
+            for (int j = 0; j < QB; ++j) o[j][db] = mfma32(vf, pf[j], o[j][db]);
+        }
+    }
+}
+
+// exact row max of tile (kl) over the valid keys, both halves; raises m and rescales O, l (and `carry`, scores that were
+// already made against the old m).  Returns with qx holding the new shift and s0 / s1 the raw scores.
+template <int QB, bool HAS_CARRY>
+__device__ __forceinline__ void raise_max(const bf16_t* kl, int key0, int S, bool tail, int lane, int hi, const bf16x8_t (&qf)[QB][4],
+                                          bf16x8_t (&qx)[QB], float (&m)[QB], float (&l)[QB], f32x16_t (&o)[QB][2],
+                                          f32x16_t (&carry)[QB], f32x16_t (&s0)[QB], f32x16_t (&s1)[QB]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        f32x16_t(&s)[QB] = kb ? s1 : s0;
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[j][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < QB; ++j) s[j] = mfma32(kf, qf[j][ks], s[j]);
+        }
+        if (tail) {
+#pragma unroll
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + kb * 32 + acc_row(r, hi) >= S) s[j][r] = -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        float mx = s0[j][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[j][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[j][r]);
+        mx = fmaxf(mx, other_half(mx));
+        const float m_new = fmaxf(m[j], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);   // m = -inf on the first tile: alpha = 0, O = l = 0 stay 0
+        if (HAS_CARRY) {
+            const float d = m[j] - m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) carry[j][i] += d;
+        }
+        m[j] = m_new;
+        qx[j] = shift_frag(m_new, hi);
+        l[j] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[j][0][i] *= alpha; o[j][1][i] *= alpha; }
+    }
+}
+
+// plain online-softmax step for one tile (first tile, ragged last tile, and every tile of the safe-mode redo)
+template <int QB>
+__device__ __forceinline__ void safe_tile(const bf16_t* kl, const bf16_t* vl, int key0, int S, bool tail, int lane, int hi,
+                                          const bf16x8_t (&qf)[QB][4], bf16x8_t (&qx)[QB], float (&m)[QB], float (&l)[QB],
+                                          f32x16_t (&o)[QB][2]) {
+    f32x16_t s0[QB], s1[QB];
+    raise_max<QB, false>(kl, key0, S, tail, lane, hi, qf, qx, m, l, o, s0, s0, s1);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p0 = __builtin_amdgcn_exp2f(s0[j][r] - m[j]), p1 = __builtin_amdgcn_exp2f(s1[j][r] - m[j]);
+            s0[j][r] = p0;
+            s1[j][r] = p1;
+            ps += p0 + p1;
+        }
+        l[j] += ps;
+    }
+    pv_half<QB>(vl, 0, lane, s0, o);
+    pv_half<QB>(vl, 1, lane, s1, o);
+}
+
+template <int QB>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                 const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                                 float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
+                                                                 int S, int H, int n_qt) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[5 * TILE_ELEMS];  // K ring [3], V ring [2]
+    __shared__ int redo_flag;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int q0 = (qt * 4 + wave) * (32 * QB);
+
+    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
+    bf16_t* const kring = lds;
+    bf16_t* const vring = lds + 3 * TILE_ELEMS;
+
+    bf16x8_t qf[QB][4], qx[QB];
+    f32x16_t o[QB][2];
+    float m[QB], l[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        load_row_frags(Qb, sq.s, q0 + 32 * j, S, lane, qf[j]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
+        m[j] = -INFINITY;
+        l[j] = 0.f;
+        qx[j] = shift_frag(0.f, hi);
+    }
+    bf16x8_t kx;   // K-side of the shift k-step: ones in k-slots 0..2 of the lower half-lanes
+    {
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
+        kx = f32_to_frag(o8);
+    }
+
+    const int nt = (S + TILE - 1) / TILE;
+    const bool ragged = (S & (TILE - 1)) != 0;
+    const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
+    const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
+    u32x4_t kr[2], vr[2];
+    if (threadIdx.x == 0) redo_flag = 0;
+    // prologue: K(0..2), V(0..1) -> LDS (rows past S read as zeros; their scores are masked or unused)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        tile_load_buf(krs, sk.s, i * TILE, koff, kr);
+        tile_store(kring + i * TILE_ELEMS, kr);
+        if (i < 2) {
+            tile_load_buf(vrs, sv.s, i * TILE, voff, vr);
+            tile_store(vring + i * TILE_ELEMS, vr);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) frags_arrived(qf[j]);
+    __syncthreads();
+
+    // first tile: establishes m (also the ragged tile when nt == 1)
+    safe_tile<QB>(kring, vring, 0, S, ragged && nt == 1, lane, hi, qf, qx, m, l, o);
+
+    f32x16_t sA[QB], sB[QB];
+    if (nt > 2) qk_half<QB>(kring + TILE_ELEMS, 0, lane, kx, qx, qf, sA);
+    int kslot = 1, vslot = 1;   // ring slots of tile t
+    for (int t = 1; t < nt - 1; ++t) {
+        const bf16_t* kl = kring + kslot * TILE_ELEMS;
+        const int kslot1 = kslot == 2 ? 0 : kslot + 1, kslot2 = kslot1 == 2 ? 0 : kslot1 + 1;
+        const bf16_t* kl1 = kring + kslot1 * TILE_ELEMS;
+        const bf16_t* vl = vring + vslot * TILE_ELEMS;
+        tile_load_buf(krs, sk.s, (t + 2) * TILE, koff, kr);   // one staging register set, used for K then for V
+        f32x2_t ps2[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) ps2[j] = (f32x2_t){0.f, 0.f};
+        qk_half<QB>(kl, 1, lane, kx, qx, qf, sB);
+        exp_half<QB>(sA, ps2);
+        pv_half<QB>(vl, 0, lane, sA, o);
+        tile_store(kring + kslot2 * TILE_ELEMS, kr);
+        tile_load_buf(vrs, sv.s, (t + 1) * TILE, voff, kr);
+#ifndef PIPE_NO_SB
+        // nothing crosses: everything that reads the old sA is done before the next half-tile's scores are started, so
+        // they are written into the same registers (otherwise the rotation costs 32 register copies per tile)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        exp_half<QB>(sB, ps2);
+        qk_half<QB>(kl1, 0, lane, kx, qx, qf, sA);
+        pv_half<QB>(vl, 1, lane, sB, o);
+        bool grew = false, over = false;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const float psum = ps2[j][0] + ps2[j][1];
+            l[j] += psum;
+            grew = grew || !(psum <= PSUM_TRIGGER);
+            over = over || !(psum <= PSUM_OVERFLOW);
+        }
+        if (__any(grew)) {
+            if (__any(over)) redo_flag = 1;
+            raise_max<QB, true>(kl, t * TILE, S, false, lane, hi, qf, qx, m, l, o, sA, sB, sB);
+        }
+        tile_store(vring + (vslot ^ 1) * TILE_ELEMS, kr);
+        kslot = kslot1;
+        vslot ^= 1;
+        __syncthreads();
+    }
+    if (nt > 1) safe_tile<QB>(kring + kslot * TILE_ELEMS, vring + vslot * TILE_ELEMS, (nt - 1) * TILE, S, ragged, lane, hi, qf, qx, m, l, o);
+
+    if (redo_flag) {   // workgroup-uniform (written before the loop's last barrier); essentially never taken
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
+            m[j] = -INFINITY;
+            l[j] = 0.f;
+        }
+        for (int t = 0; t < nt; ++t) {
+            __syncthreads();
+            tile_load_buf(krs, sk.s, t * TILE, koff, kr);
+            tile_load_buf(vrs, sv.s, t * TILE, voff, vr);
+            tile_store(kring, kr);
+            tile_store(vring, vr);
+            __syncthreads();
+            safe_tile<QB>(kring, vring, t * TILE, S, ragged && t == nt - 1, lane, hi, qf, qx, m, l, o);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const float lt = l[j] + other_half(l[j]);
+        const float inv = 1.f / lt;
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < S) {
+            bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t w;
+                    w[0] = pack_bf16x2(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv);
+                    w[1] = pack_bf16x2(o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+                }
+            if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
         }
     }
 }
@@ -450,7 +732,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // =====================================================================================================
 // Backward, dK / dV:  dV = P^T dO ,  dK = scale * dS^T Q       (workgroup owns 128 keys, streams 64-query tiles)
 // =====================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+#ifndef DKV_WAVES
+#define DKV_WAVES 2
+#endif
+__global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                              const float* __restrict__ LSE2, const float* __restrict__ DELTA,
                                                              bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, TStride sq, TStride sk,
@@ -823,6 +1108,9 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 #ifndef DQ_QB
 #define DQ_QB 2    // query blocks (of 32 rows) per wave in the dQ kernel
 #endif
+#ifndef FWD_NW
+#define FWD_NW 4   // waves per workgroup in the forward kernel
+#endif
 #ifndef FWD_QB
 #define FWD_QB 2   // query blocks (of 32 rows) per wave in the forward kernel
 #endif
@@ -841,10 +1129,18 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
     if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides)) return VGPA_ERR_INVALID;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
-    const int n_qt = (int)((S + FWD_QB * WG_ROWS - 1) / (FWD_QB * WG_ROWS));
+    const int n_qt = (int)((S + FWD_QB * FWD_NW * 32 - 1) / (FWD_QB * FWD_NW * 32));
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
-    VGPA_LAUNCH((attn_fwd_kernel<FWD_QB>), dim3((unsigned)nblk), dim3(256), FWD_DYN_LDS, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+#ifndef FWD_V1   // product path: the software-pipelined kernel; -DFWD_V1 builds the three-block kernel (diagnostic hooks live there)
+    if (FWD_NW == 4) {
+        VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB>), dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
+        VGPA_CHECK_LAUNCH();
+        return VGPA_OK;
+    }
+#endif
+    VGPA_LAUNCH((attn_fwd_kernel<FWD_QB, FWD_NW>), dim3((unsigned)nblk), dim3(64 * FWD_NW), FWD_DYN_LDS, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                 (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;

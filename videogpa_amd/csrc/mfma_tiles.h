@@ -72,6 +72,19 @@ __device__ __forceinline__ void tile_store(bf16_t* lds, const u32x4_t (&r)[2]) {
     }
 }
 
+// the same three for 512-thread workgroups (one 16-byte chunk per thread and tile)
+__device__ __forceinline__ void tile_load(const bf16_t* base, uint32_t row_stride, int row0, int S, u32x4_t (&r)[1]) {
+    int row = row0 + (threadIdx.x >> 3);
+    row = row < S ? row : S - 1;
+    r[0] = *reinterpret_cast<const u32x4_t*>(base + ((uint32_t)row * row_stride + (uint32_t)((threadIdx.x & 7) * 8)));
+}
+__device__ __forceinline__ void tile_load_buf(rsrc_t rs, uint32_t row_stride, int row0, uint32_t lane_off, u32x4_t (&r)[1]) {
+    r[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, (uint32_t)row0 * row_stride * 2u, 0);
+}
+__device__ __forceinline__ void tile_store(bf16_t* lds, const u32x4_t (&r)[1]) {
+    *reinterpret_cast<u32x4_t*>(lds + (threadIdx.x >> 3) * PITCH + (threadIdx.x & 7) * 8) = r[0];
+}
+
 // A/B fragment whose contraction index runs along the row (d contiguous): lane (l&31, l>>5) reads 16 B.
 __device__ __forceinline__ bf16x8_t frag_row(const bf16_t* lds, int rowbase, int ks, int lane) {
     return *reinterpret_cast<const bf16x8_t*>(lds + (rowbase + (lane & 31)) * PITCH + ks * 16 + (lane >> 5) * 8);
