@@ -158,15 +158,18 @@ def main():
     dt = float(tt.item())
 
     if rank == 0:
+        headline = (args.layers, args.frames, args.height, args.width, args.rank_r, args.checkpoint) == (42, 13, 60, 90, 64, False)
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
         out = {
             "metric": "DPO preference-pair steps/sec, CogVideoX-5B 49f@480x720", "value": value, "unit": "pair-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720 -> "
-                                   f"paired latents [1,2,{F_},16,{H_},{W_}], S={S} tokens, LoRA r={args.rank_r} on to_q/to_k/to_v/to_out.0, "
-                                   "1 pair/GPU/step, optimizer step every step; random-init weights",
+            "config": {"workload": ("BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720 -> "
+                                    if headline else "NOT the headline config (debug flags): CogVideoX-5B-shaped transformer, ")
+                                   + f"paired latents [1,2,{F_},16,{H_},{W_}], S={S} tokens, {args.layers} blocks, LoRA r={args.rank_r} on "
+                                   "to_q/to_k/to_v/to_out.0, 1 pair/GPU/step, optimizer step every step; random-init weights"
+                                   + ("; per-block activation recompute" if args.checkpoint else ""),
                        "layers": args.layers, "tokens": S, "pairs_per_gpu": 1, "parallelism": f"dp{world}"},
             "loss": float(logs["train/loss"]),
             "step_flops_algorithmic": F_step,
