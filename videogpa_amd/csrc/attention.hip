@@ -19,6 +19,8 @@
 //    that XCD's private L2.
 #include "common.h"
 
+#include <type_traits>
+
 #include "mfma_tiles.h"
 
 // XCD-aware remap of the linear block id: consecutive virtual ids (same head) land on one XCD.
@@ -741,10 +743,12 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                                                              bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, TStride sq, TStride sk,
                                                              TStride sv, TStride sdo, TStride sdk, TStride sdv, int S, int H, int n_kt,
                                                              float kscale /* scale / (scale*log2e) = ln 2: Q is pre-scaled */) {
-    // Q[2], dO[2] tiles.  The 8 padding columns (64..71) of every row carry the row's softmax statistics as three bf16
-    // pieces (-lse in the Q tile, -delta in the dO tile); one extra MFMA k-step against a (1,1,1,0,...) operand folds
+    // Q[3], dO[3] tile rings.  The 8 padding columns (64..71) of every row carry the row's softmax statistics as three
+    // bf16 pieces (-lse in the Q tile, -delta in the dO tile); one extra MFMA k-step against a (1,1,1,0,...) operand folds
     // them into the S and dP accumulators, so P = exp2(acc) and dS = P * acc with no per-score subtract.
-    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS + 16];
+    // Software pipeline (as in the forward): the scores of the NEXT tile's first q-block are made at the end of this
+    // tile, between the two dV/dK products, so every stretch of the loop body has both MFMA and VALU work in it.
+    __shared__ __attribute__((aligned(16))) bf16_t lds[6 * TILE_ELEMS + 16];
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = vid / n_kt, kt = vid % n_kt;
     const int b = bh / H, h = bh % H;
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
         ones = f32_to_frag(o8);
     }
     // everything the statistics k-step can touch must be finite: clear the whole LDS array once
-    for (int i = threadIdx.x; i < (4 * TILE_ELEMS + 16) / 8; i += 256) {
+    for (int i = threadIdx.x; i < (6 * TILE_ELEMS + 16) / 8; i += 256) {
         u32x4_t z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4_t*>(lds + i * 8) = z;
     }
@@ -776,6 +780,8 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
     const int nt = (S + TILE - 1) / TILE;
+    bf16_t* const qring = lds;
+    bf16_t* const doring = lds + 3 * TILE_ELEMS;
     u32x4_t qr[2], dor[2];
     float st = 0.f;
     auto stat_load = [&](int t) {
@@ -785,86 +791,105 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             st = (threadIdx.x < TILE) ? Lb[q] : Db[q];
         }
     };
-    auto stat_store = [&](int buf) {   // threads 0..63: -lse pieces into the Q tile, 64..127: -delta pieces into the dO tile
+    auto stat_store = [&](int slot) {   // threads 0..63: -lse pieces into the Q tile, 64..127: -delta pieces into the dO tile
         if (threadIdx.x < 2 * TILE) {
             const float t0 = -st;
             const float a1 = round_bf16(t0), a2 = round_bf16(t0 - a1), a3 = round_bf16((t0 - a1) - a2);
             u32x4_t w = {pack_bf16x2(a1, a2), pack_bf16x2(a3, 0.f), 0u, 0u};
-            bf16_t* tile = lds + ((threadIdx.x < TILE ? 0 : 2) + buf) * TILE_ELEMS;
+            bf16_t* tile = (threadIdx.x < TILE ? qring : doring) + slot * TILE_ELEMS;
             *reinterpret_cast<u32x4_t*>(tile + (threadIdx.x & (TILE - 1)) * PITCH + 64) = w;
         }
     };
-    tile_load(Qb, sq.s, 0, S, qr);
-    tile_load(dOb, sdo.s, 0, S, dor);
-    stat_load(0);
-    tile_store(lds, qr);
-    tile_store(lds + 2 * TILE_ELEMS, dor);
-    stat_store(0);
-    frags_arrived(kf);
-    frags_arrived(vf);
     const rsrc_t qrs = tile_rsrc(Qb, sq.s, S), dors = tile_rsrc(dOb, sdo.s, S);
     const uint32_t qoff = tile_lane_byte_offset(sq.s), dooff = tile_lane_byte_offset(sdo.s);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // tiles 0 and 1 (a tile past the end reads zeros)
+        tile_load_buf(qrs, sq.s, i * TILE, qoff, qr);
+        tile_load_buf(dors, sdo.s, i * TILE, dooff, dor);
+        stat_load(i);
+        tile_store(qring + i * TILE_ELEMS, qr);
+        tile_store(doring + i * TILE_ELEMS, dor);
+        stat_store(i);
+    }
+    frags_arrived(kf);
+    frags_arrived(vf);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const bf16_t* ql = lds + (t & 1) * TILE_ELEMS;
-        const bf16_t* dol = lds + (2 + (t & 1)) * TILE_ELEMS;
-        if (t + 1 < nt) {
-            tile_load_buf(qrs, sq.s, (t + 1) * TILE, qoff, qr);
-            tile_load_buf(dors, sdo.s, (t + 1) * TILE, dooff, dor);
-            stat_load(t + 1);
+    // S[q,key] - lse2 and dP[q,key] - delta of one 32-row q-block
+    auto scores = [&](const bf16_t* ql, const bf16_t* dol, int qb, f32x16_t& s, f32x16_t& dp) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+        bf16x8_t qa[5], da[5];   // all ten row fragments are read up front so the two MFMA chains issue back to back
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) { qa[ks] = frag_row(ql, qb * 32, ks, lane); da[ks] = frag_row(dol, qb * 32, ks, lane); }
+        s = mfma32(qa[4], ones, s);
+        dp = mfma32(da[4], ones, dp);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = mfma32(qa[ks], kf[ks], s);
+            dp = mfma32(da[ks], vf[ks], dp);
         }
-        const bool tail = (t == nt - 1) && (S & (TILE - 1));
+    };
+    // P = exp2(s) (in place), dS = P * dp (into dp)
+    auto softmax_grad = [&](f32x16_t& s, f32x16_t& dp, int row0, bool mask) {
+        if (mask) {   // query rows past the end: exp2(-inf) = 0
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16_t s, dp;
+            for (int r = 0; r < 16; ++r)
+                if (row0 + acc_row(r, hi) >= S) s[r] = -INFINITY;
+        }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-            // all ten row fragments of this q-block are read up front so the two MFMA chains below issue back to back
-            bf16x8_t qa[5], da[5];
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
+            f32x2_t d = {dp[r], dp[r + 1]};
+            d = d * p;
+            s[r] = p[0];
+            s[r + 1] = p[1];
+            dp[r] = d[0];
+            dp[r + 1] = d[1];
+        }
+    };
+    // dV^T[d,key] += dO^T P,  dK^T[d,key] += Q^T dS   for one q-block
+    auto accumulate = [&](const bf16_t* ql, const bf16_t* dol, int qb, const f32x16_t& p, const f32x16_t& ds) {
 #pragma unroll
-            for (int ks = 0; ks < 5; ++ks) { qa[ks] = frag_row(ql, qb * 32, ks, lane); da[ks] = frag_row(dol, qb * 32, ks, lane); }
-            s = mfma32(qa[4], ones, s);                                                                  // - lse2[q]
-            dp = mfma32(da[4], ones, dp);                                                                // - delta[q]
+        for (int cc = 0; cc < 2; ++cc) {
+            const bf16x8_t pf = pack_frag(p, 8 * cc);
+            const bf16x8_t dsf = pack_frag(ds, 8 * cc);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = mfma32(qa[ks], kf[ks], s);                                                           // S[q,key] - lse2
-                dp = mfma32(da[ks], vf[ks], dp);                                                         // dP[q,key] - delta
-            }
-            f32x16_t ds;
-            if (tail) {   // query rows past the end: exp2(-inf) = 0 (masking kept out of the exp loop)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t * TILE + qb * 32 + acc_row(r, hi) >= S) s[r] = -INFINITY;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-                f32x2_t d = {dp[r], dp[r + 1]};
-                d = d * p;
-                s[r] = p[0];
-                s[r + 1] = p[1];
-                ds[r] = d[0];
-                ds[r + 1] = d[1];
-            }
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const bf16x8_t pf = pack_frag(s, 8 * cc);
-                const bf16x8_t dsf = pack_frag(ds, 8 * cc);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = mfma32(frag_tr(dol, qb * 32 + 16 * cc, db * 32, lane), pf, dv[db]);   // dV^T[d,key] += dO^T P
-                    dk[db] = mfma32(frag_tr(ql, qb * 32 + 16 * cc, db * 32, lane), dsf, dk[db]);   // dK^T[d,key] += Q^T dS
-                }
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = mfma32(frag_tr(dol, qb * 32 + 16 * cc, db * 32, lane), pf, dv[db]);
+                dk[db] = mfma32(frag_tr(ql, qb * 32 + 16 * cc, db * 32, lane), dsf, dk[db]);
             }
         }
-        if (t + 1 < nt) {
-            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, qr);
-            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, dor);
-            stat_store((t + 1) & 1);
-        }
+    };
+
+    f32x16_t s0, dp0;   // carried: scores of (tile t, q-block 0)
+    scores(qring, doring, 0, s0, dp0);
+    int slot = 0;       // ring slot of tile t
+    auto tile_body = [&](int t, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        const bf16_t* ql = qring + slot * TILE_ELEMS;
+        const bf16_t* dol = doring + slot * TILE_ELEMS;
+        tile_load_buf(qrs, sq.s, (t + 2) * TILE, qoff, qr);     // loads past the last tile read zeros into a slot nobody uses
+        tile_load_buf(dors, sdo.s, (t + 2) * TILE, dooff, dor);
+        stat_load(t + 2);
+        f32x16_t s1, dp1;
+        scores(ql, dol, 1, s1, dp1);
+        softmax_grad(s0, dp0, t * TILE, TAIL);
+        accumulate(ql, dol, 0, s0, dp0);
+        softmax_grad(s1, dp1, t * TILE + 32, TAIL);
+        scores(qring + slot1 * TILE_ELEMS, doring + slot1 * TILE_ELEMS, 0, s0, dp0);
+        accumulate(ql, dol, 1, s1, dp1);
+        tile_store(qring + slot2 * TILE_ELEMS, qr);
+        tile_store(doring + slot2 * TILE_ELEMS, dor);
+        stat_store(slot2);
+        slot = slot1;
         __syncthreads();
-    }
+    };
+    const bool ragged = (S & (TILE - 1)) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+    if (ragged) tile_body(nt - 1, std::true_type{});
     const int k = k0 + (lane & 31);
     if (k < S) {
         bf16_t* kp = dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s);
