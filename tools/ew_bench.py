@@ -47,3 +47,20 @@ show("gelu fwd", t(lambda: ops.gelu_tanh(u)), 8)
 ur = u.clone().requires_grad_(True)
 gu = ops.gelu_tanh(ur)
 show("gelu bwd", t(lambda: torch.autograd.grad(gu, ur, u, retain_graph=True)), 12)
+
+# LoRA kernels at the shapes the model uses (rank 64; fused q,k,v = three adapters side by side)
+M = B * S
+x2 = x.view(M, D)
+a1 = torch.randn(64, D, device="cuda").bfloat16()
+a3 = torch.randn(192, D, device="cuda").bfloat16()
+b1 = (0.01 * torch.randn(D, 64, device="cuda")).bfloat16()
+t1 = torch.randn(M, 64, device="cuda").bfloat16()
+t3 = torch.randn(M, 192, device="cuda").bfloat16()
+y1 = torch.randn(M, D, device="cuda").bfloat16()
+qkv = torch.randn(M, 3 * D, device="cuda").bfloat16()
+show("lora_down r=64", t(lambda: ops.lora_down(x2, a1)), 1)
+show("lora_down r=192 (q,k,v)", t(lambda: ops.lora_down(x2, a3)), 1)
+show("lora_up_add [M,3072] r=64 (RMW)", t(lambda: ops.lora_up_add(y1, t1, b1, 2.0)), 2)
+show("lora_up_add column slice of [M,9216]", t(lambda: ops.lora_up_add(qkv[:, D:2 * D], t3[:, 64:128], b1, 2.0)), 2)
+show("lora_grad dA = t^T x  [64 x 3072]", t(lambda: ops.lora_grad(t1, x2)), 1)
+show("lora_grad dB = dy^T t [3072 x 64]", t(lambda: ops.lora_grad(y1, t1)), 1)
