@@ -636,11 +636,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     }
 
     const int nt = (S + TILE - 1) / TILE;
-    u32x4_t kr[2], vr[2];
+    u32x4_t kr[2];   // one staging register set: K of the next tile during the first key half, V during the second
     tile_load(Kb, sk.s, 0, S, kr);
-    tile_load(Vb, sv.s, 0, S, vr);
     tile_store(lds, kr);
-    tile_store(lds + 2 * TILE_ELEMS, vr);
+    tile_load(Vb, sv.s, 0, S, kr);
+    tile_store(lds + 2 * TILE_ELEMS, kr);
 #pragma unroll
     for (int j = 0; j < QB; ++j) { frags_arrived(qf[j]); frags_arrived(dof[j]); }
     const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
@@ -650,10 +650,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int t = 0; t < nt; ++t) {
         const bf16_t* kl = lds + (t & 1) * TILE_ELEMS;
         const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
-        if (t + 1 < nt) {
-            tile_load_buf(krs, sk.s, (t + 1) * TILE, koff, kr);
-            tile_load_buf(vrs, sv.s, (t + 1) * TILE, voff, vr);
-        }
+        tile_load_buf(krs, sk.s, (t + 1) * TILE, koff, kr);   // past the last tile: zeros into a buffer nobody reads
         const bool tail = (t == nt - 1) && (S & (TILE - 1));
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -706,11 +703,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     for (int j = 0; j < QB; ++j) dq[j][db] = mfma32(ktf, dsf[j], dq[j][db]);             // dQ^T[d,q]
                 }
             }
+            if (kb == 0) {
+                tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
+                tile_load_buf(vrs, sv.s, (t + 1) * TILE, voff, kr);
+            }
         }
-        if (t + 1 < nt) {
-            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
-            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, vr);
-        }
+        tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, kr);
         __syncthreads();
     }
 #pragma unroll
