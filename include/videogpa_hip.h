@@ -108,6 +108,14 @@ int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void*
 int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
                       const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H,
                       int64_t S, int64_t head_dim, float scale, vgpa_stream_t stream);
+/* The same with a caller-owned workspace (>= vgpa_attn_fwd_workspace_bytes): when the number of (head, 256-row strip)
+ * tasks leaves a mostly empty last scheduling round on the device, those leftover tasks are cut into key-range chunks
+ * (second small launch + merge) instead.  split_mode: -1 automatic, 0 never, k >= 2 force k chunks for every task. */
+size_t vgpa_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t S);
+int32_t vgpa_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
+                         const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H,
+                         int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes,
+                         vgpa_stream_t stream);
 size_t vgpa_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t S);
 int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_strides, const int64_t* do_strides, float* delta,
                             int64_t B, int64_t H, int64_t S, int64_t head_dim, vgpa_stream_t stream);

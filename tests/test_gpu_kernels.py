@@ -381,6 +381,22 @@ def test_attention_extreme_outliers_strip_redo(ops, S):
     assert ((lse.double().cpu() - lse_ref).abs() <= 1e-3 + 1e-5 * lse_ref.abs()).all()
 
 
+@pytest.mark.parametrize("S,split", [(1000, 4), (1000, 8), (2100, 3), (641, 5)])
+def test_attention_fwd_key_range_split_matches_single_launch(ops, S, split):
+    """The launcher's tail treatment (tasks cut into key-range chunks + merge, vgpa_attn_fwd_ws) against the single launch
+    and the fp64 reference, incl. a spiked key in a late chunk and a ragged last tile."""
+    g = torch.Generator().manual_seed(S + split)
+    B, H = 1, 3
+    q, k, v = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16) for _ in range(3))
+    k[0, 1, S - 70] = (q[0, 1, 11].float() * 2.0).to(torch.bfloat16)
+    o0, lse0 = ops.attention_fwd_raw(dev(q), dev(k), dev(v), split_mode=0)
+    o1, lse1 = ops.attention_fwd_raw(dev(q), dev(k), dev(v), split_mode=split)
+    o_ref = _attn_ref(q, k, v)
+    assert (o1.view(B, S, H, 64).permute(0, 2, 1, 3).double().cpu() - o_ref).abs().max().item() < 0.02
+    assert (o1.float() - o0.float()).abs().max().item() < 0.02          # both round the same value to bf16: <= 1 ulp apart
+    assert (lse1 - lse0).abs().max().item() < 2e-3
+
+
 def test_cabi_rejects_bad_arguments(ops):
     from videogpa_amd import _lib
     lib = _lib.load()

@@ -15,6 +15,7 @@ ap.add_argument("--S", type=int, default=17776)
 ap.add_argument("--B", type=int, default=2)
 ap.add_argument("--H", type=int, default=48)
 ap.add_argument("--which", default="fwd,dkv,dq")
+ap.add_argument("--split", type=int, default=-1, help="forward split_mode: -1 automatic, 0 never")
 a = ap.parse_args()
 B, H, S = a.B, a.H, a.S
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -33,7 +34,7 @@ torch.cuda.synchronize()
 ops.TIMER = ops.KernelTimer()
 for _ in range(a.iters):
     if "fwd" in a.which:
-        ops.attention_fwd_raw(q, k, v)
+        ops.attention_fwd_raw(q, k, v, split_mode=a.split)
     if "dkv" in a.which or "dq" in a.which:
         ops.attention_bwd_raw(q, k, v, ov, dov, lse, dq, dk, dv)
 torch.cuda.synchronize()

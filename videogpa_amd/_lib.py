@@ -32,6 +32,8 @@ SIGNATURES = {
     "vgpa_qknorm_rope_fwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, F32, P]),
     "vgpa_qknorm_rope_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
+    "vgpa_attn_fwd_workspace_bytes": (SZ, [I64, I64, I64]),
+    "vgpa_attn_fwd_ws": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_grad_norm_workspace_bytes": (SZ, []),
     "vgpa_grad_norm": (I32, [P, I64, F32, P, P, SZ, P]),

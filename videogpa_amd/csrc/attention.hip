@@ -425,14 +425,21 @@ __device__ __forceinline__ void safe_tile(const bf16_t* kl, const bf16_t* vl, in
     pv_half<QB>(vl, 1, lane, s1, o);
 }
 
-template <int QB>
+// SPLIT = false: workgroup = task (one 256-row query strip of one head) task0 + remapped blockIdx, all key tiles.
+// SPLIT = true (the leftover tasks that would otherwise run as a mostly empty last scheduling round, see vgpa_attn_fwd_ws):
+// workgroup = (task, chunk) = (task0 + blockIdx / nsplit, blockIdx % nsplit) sweeps only key tiles [nt*chunk/nsplit,
+// nt*(chunk+1)/nsplit) and leaves its un-normalised O, m and l in `part`; attn_fwd_merge_kernel combines the chunks.
+// (blockIdx % nsplit is also the XCD the workgroup lands on for nsplit = 8: the workgroups of one XCD share one key range.)
+#define FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64], m[256], l[256]
+template <int QB, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
-                                                                 int S, int H, int n_qt) {
+                                                                 int S, int H, int n_qt, int task0, int nsplit, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[5 * TILE_ELEMS];  // K ring [3], V ring [2]
     __shared__ int redo_flag;
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
+    const int chunk = SPLIT ? (int)blockIdx.x % nsplit : 0;
     const int bh = vid / n_qt, qt = vid % n_qt;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
@@ -463,19 +470,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
         kx = f32_to_frag(o8);
     }
 
-    const int nt = (S + TILE - 1) / TILE;
-    const bool ragged = (S & (TILE - 1)) != 0;
+    const int nt_all = (S + TILE - 1) / TILE;
+    const int tb = SPLIT ? nt_all * chunk / nsplit : 0;              // this workgroup's key tiles: [tb, nt)
+    const int nt = SPLIT ? nt_all * (chunk + 1) / nsplit : nt_all;
+    const bool ragged = (S & (TILE - 1)) != 0 && nt == nt_all;       // the ragged tile, if any, is the global last one
     const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
     const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
     u32x4_t kr[2], vr[2];
     if (threadIdx.x == 0) redo_flag = 0;
-    // prologue: K(0..2), V(0..1) -> LDS (rows past S read as zeros; their scores are masked or unused)
+    // prologue: K(tb..tb+2), V(tb..tb+1) -> LDS (rows past S read as zeros; their scores are masked or unused)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        tile_load_buf(krs, sk.s, i * TILE, koff, kr);
+        tile_load_buf(krs, sk.s, (tb + i) * TILE, koff, kr);
         tile_store(kring + i * TILE_ELEMS, kr);
         if (i < 2) {
-            tile_load_buf(vrs, sv.s, i * TILE, voff, vr);
+            tile_load_buf(vrs, sv.s, (tb + i) * TILE, voff, vr);
             tile_store(vring + i * TILE_ELEMS, vr);
         }
     }
@@ -483,13 +492,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
     for (int j = 0; j < QB; ++j) frags_arrived(qf[j]);
     __syncthreads();
 
-    // first tile: establishes m (also the ragged tile when nt == 1)
-    safe_tile<QB>(kring, vring, 0, S, ragged && nt == 1, lane, hi, qf, qx, m, l, o);
+    // first tile: establishes m (also the ragged tile when it is the only one)
+    safe_tile<QB>(kring, vring, tb * TILE, S, ragged && nt - tb == 1, lane, hi, qf, qx, m, l, o);
 
     f32x16_t sA[QB], sB[QB];
-    if (nt > 2) qk_half<QB>(kring + TILE_ELEMS, 0, lane, kx, qx, qf, sA);
+    if (nt - tb > 2) qk_half<QB>(kring + TILE_ELEMS, 0, lane, kx, qx, qf, sA);
     int kslot = 1, vslot = 1;   // ring slots of tile t
-    for (int t = 1; t < nt - 1; ++t) {
+    for (int t = tb + 1; t < nt - 1; ++t) {
         const bf16_t* kl = kring + kslot * TILE_ELEMS;
         const int kslot1 = kslot == 2 ? 0 : kslot + 1, kslot2 = kslot1 == 2 ? 0 : kslot1 + 1;
         const bf16_t* kl1 = kring + kslot1 * TILE_ELEMS;
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
         vslot ^= 1;
         __syncthreads();
     }
-    if (nt > 1) safe_tile<QB>(kring + kslot * TILE_ELEMS, vring + vslot * TILE_ELEMS, (nt - 1) * TILE, S, ragged, lane, hi, qf, qx, m, l, o);
+    if (nt - tb > 1) safe_tile<QB>(kring + kslot * TILE_ELEMS, vring + vslot * TILE_ELEMS, (nt - 1) * TILE, S, ragged, lane, hi, qf, qx, m, l, o);
 
     if (redo_flag) {   // workgroup-uniform (written before the loop's last barrier); essentially never taken
 #pragma unroll
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
             m[j] = -INFINITY;
             l[j] = 0.f;
         }
-        for (int t = 0; t < nt; ++t) {
+        for (int t = tb; t < nt; ++t) {
             __syncthreads();
             tile_load_buf(krs, sk.s, t * TILE, koff, kr);
             tile_load_buf(vrs, sv.s, t * TILE, voff, vr);
@@ -547,6 +556,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
             __syncthreads();
             safe_tile<QB>(kring, vring, t * TILE, S, ragged && t == nt - 1, lane, hi, qf, qx, m, l, o);
         }
+    }
+
+    if (SPLIT) {   // partial result of this key range: un-normalised O (scaled by 2^-m), m, l
+        float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * FWD_PART_FLOATS;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const int r = wave * (32 * QB) + 32 * j + (lane & 31);
+            const float lt = l[j] + other_half(l[j]);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t w = {o[j][db][4 * g], o[j][db][4 * g + 1], o[j][db][4 * g + 2], o[j][db][4 * g + 3]};
+                    *reinterpret_cast<f32x4_t*>(pb + r * HD + db * 32 + 8 * g + 4 * hi) = w;
+                }
+            if (hi == 0) { pb[256 * HD + r] = m[j]; pb[256 * HD + 256 + r] = lt; }
+        }
+        return;
     }
 
 #pragma unroll
@@ -568,6 +595,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
             if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
         }
     }
+}
+
+// combine the key-range chunks of the split tasks: one wave per query row, lane = d
+__global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_qt, bf16_t* __restrict__ O,
+                                                               TStride so, float* __restrict__ LSE2, int S, int H) {
+    const int lane = threadIdx.x & 63, r = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6), tl = blockIdx.x >> 6;
+    const int vid = task0 + tl, bh = vid / n_qt, qt = vid % n_qt;
+    const int q = qt * 256 + r;
+    if (q >= S) return;
+    const float* pb = part + (size_t)tl * nsplit * FWD_PART_FLOATS;
+    float M = -INFINITY;
+    for (int c = 0; c < nsplit; ++c) M = fmaxf(M, pb[(size_t)c * FWD_PART_FLOATS + 256 * HD + r]);
+    float acc = 0.f, L = 0.f;
+    for (int c = 0; c < nsplit; ++c) {
+        const float* pc = pb + (size_t)c * FWD_PART_FLOATS;
+        const float w = __builtin_amdgcn_exp2f(pc[256 * HD + r] - M);
+        acc += w * pc[r * HD + lane];
+        L += w * pc[256 * HD + 256 + r];
+    }
+    const int b = bh / H, h = bh % H;
+    O[(size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + lane] = f32_to_bf16(acc / L);
+    if (lane == 0) LSE2[(int64_t)bh * S + q] = M + __builtin_amdgcn_logf(L);
 }
 
 // =====================================================================================================
@@ -1146,9 +1195,53 @@ extern "C" {
 // CONTRACT: q holds the queries PRE-MULTIPLIED by scale*log2(e) (vgpa_qknorm_rope_fwd writes them that way through
 // q_out_scale), in all four entry points; `scale` is still the softmax scale (used for the dQ / dK multipliers).
 // dq is the gradient w.r.t. the UNscaled query.
-int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
-                      const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
-                      int64_t head_dim, float scale, hipStream_t stream) {
+// Workgroup slots the attention kernels have on the current device (2 workgroups of 256 threads per CU): a launch whose
+// task count is not a multiple of this ends in a partially filled scheduling round.  Read once per process.
+static int wg_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+    }
+    return slots;
+}
+// How to run `tasks` equal tasks that each sweep `nt` tiles: n_main tasks as they are, the rest split `nsplit` ways along
+// the sweep so that they fill (at most) one round.  split_mode: -1 automatic, 0 never, k >= 2 force k chunks for ALL tasks
+// (tests).  Splitting is only worth it when the leftover round would be mostly empty and the chunks keep a few tiles each.
+static void split_plan(int64_t tasks, int nt, int split_mode, int max_split, int64_t* n_main, int* nsplit) {
+    *n_main = tasks;
+    *nsplit = 1;
+    if (split_mode == 0 || nt < 8) return;
+    if (split_mode >= 2) {
+        *n_main = 0;
+        *nsplit = split_mode < nt / 2 ? split_mode : nt / 2;
+        if (*nsplit > max_split) *nsplit = max_split;
+        return;
+    }
+    const int64_t slots = wg_slots();
+    const int64_t rem = tasks % slots;
+    if (tasks < slots || rem == 0 || rem * 2 > slots) return;      // a single round, a full last round, or one at least half full
+    int64_t k = slots / rem;
+    if (k > nt / 4) k = nt / 4;
+    if (k > max_split) k = max_split;
+    if (k < 2) return;
+    *n_main = tasks - rem;
+    *nsplit = (int)k;
+}
+#define FWD_MAX_SPLIT 16
+
+size_t vgpa_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t S) {
+    // worst case of split_plan: (leftover tasks) x (chunks) <= slots in automatic mode; forced mode (tests) splits every task
+    const int64_t n_qt = (S + 255) / 256, tasks = n_qt * B * H;
+    int64_t parts = wg_slots();
+    if (tasks * FWD_MAX_SPLIT < parts) parts = tasks * FWD_MAX_SPLIT;
+    return (size_t)parts * FWD_PART_FLOATS * sizeof(float);
+}
+
+static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
+                             const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
+                             int64_t head_dim, int32_t split_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
     if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides)) return VGPA_ERR_INVALID;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
@@ -1156,10 +1249,30 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
 #ifndef FWD_V1   // product path: the software-pipelined kernel; -DFWD_V1 builds the three-block kernel (diagnostic hooks live there)
-    if (FWD_NW == 4) {
-        VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB>), dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                    (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
-        VGPA_CHECK_LAUNCH();
+    if (FWD_NW == 4 && FWD_QB == 2) {
+        int64_t n_main = nblk;
+        int nsplit = 1;
+        if (workspace) split_plan(nblk, (int)((S + TILE - 1) / TILE), split_mode, FWD_MAX_SPLIT, &n_main, &nsplit);
+        const int64_t n_tail = nblk - n_main;
+        if (n_tail > 0 && ws_bytes < (size_t)n_tail * nsplit * FWD_PART_FLOATS * sizeof(float)) {
+            if (split_mode >= 2) return VGPA_ERR_WORKSPACE;
+            n_main = nblk;   // automatic mode: fall back to the single launch
+        }
+        if (n_main > 0) {
+            VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB, false>), dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                        (const bf16_t*)v, (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, 0, 1,
+                        (float*)nullptr);
+            VGPA_CHECK_LAUNCH();
+        }
+        if (n_main < nblk) {
+            VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB, true>), dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q,
+                        (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S,
+                        (int)H, n_qt, (int)n_main, nsplit, (float*)workspace);
+            VGPA_CHECK_LAUNCH();
+            VGPA_LAUNCH(attn_fwd_merge_kernel, dim3((unsigned)(n_tail * 64)), dim3(256), 0, stream, (const float*)workspace, nsplit, (int)n_main, n_qt,
+                        (bf16_t*)o, mk(o_strides), lse2, (int)S, (int)H);
+            VGPA_CHECK_LAUNCH();
+        }
         return VGPA_OK;
     }
 #endif
@@ -1167,6 +1280,24 @@ int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
                 (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
+}
+
+int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
+                      const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
+                      int64_t head_dim, float scale, hipStream_t stream) {
+    (void)scale;
+    return attn_fwd_impl(q, k, v, o, lse2, q_strides, k_strides, v_strides, o_strides, B, H, S, head_dim, 0, nullptr, 0, stream);
+}
+
+// Same, with a workspace (vgpa_attn_fwd_workspace_bytes) that lets the launcher cut the leftover tasks of a partially filled
+// last scheduling round into key-range chunks (a second small launch + a merge).  split_mode: -1 automatic, 0 never, k >= 2
+// force k chunks for every task.
+int32_t vgpa_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
+                         const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
+                         int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    (void)scale;
+    if (workspace && !al16(workspace)) return VGPA_ERR_INVALID;
+    return attn_fwd_impl(q, k, v, o, lse2, q_strides, k_strides, v_strides, o_strides, B, H, S, head_dim, split_mode, workspace, ws_bytes, stream);
 }
 
 // workspace: fp32 delta [B,H,S]  (vgpa_attn_bwd_workspace_bytes)

@@ -490,8 +490,10 @@ def prescale_q(q, scale=None):
     return (q.float() * (scale * LOG2E)).to(q.dtype)
 
 
-def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False):
-    """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32."""
+def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=-1):
+    """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32.
+    split_mode: -1 lets the launcher cut the tasks of a mostly empty last scheduling round into key-range chunks,
+    0 forbids it, k >= 2 forces k chunks for every task (tests)."""
     B, H, S, Dh = q.shape
     scale = Dh ** -0.5 if scale is None else scale
     if not q_prescaled:
@@ -499,9 +501,11 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False):
     o = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=q.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
+    ws_bytes = _lib.query("vgpa_attn_fwd_workspace_bytes", B, H, S) if split_mode != 0 else 0
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
     _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
-        "vgpa_attn_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
-        float(scale), _stream()))
+        "vgpa_attn_fwd_ws", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
+        float(scale), int(split_mode), ws if ws_bytes else None, ws_bytes, _stream()))
     return o, lse
 
 
