@@ -36,7 +36,7 @@ for _ in range(a.iters):
     if "fwd" in a.which:
         ops.attention_fwd_raw(q, k, v, split_mode=a.split)
     if "dkv" in a.which or "dq" in a.which:
-        ops.attention_bwd_raw(q, k, v, ov, dov, lse, dq, dk, dv)
+        ops.attention_bwd_raw(q, k, v, ov, dov, lse, dq, dk, dv, split_mode=a.split)
 torch.cuda.synchronize()
 unit = 2.0 * S * S * 64 * B * H
 hw_units = {"attn_fwd_kernel": 2, "attn_bwd_dkv_kernel": 4, "attn_bwd_dq_kernel": 3, "attn_bwd_fused_kernel": 5}

@@ -648,15 +648,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =====================================================================================================
 // Backward, dQ:  dQ = scale * sum_k dS[q,k] K[k],  dS = P o (dP - delta),  P = exp2(c*s - lse2),  dP = dO V^T
 // =====================================================================================================
-template <int QB>
+// SPLIT: as in the forward -- workgroup (task0 + blockIdx / nsplit, chunk blockIdx % nsplit) sweeps key tiles
+// [nt*chunk/nsplit, nt*(chunk+1)/nsplit) and leaves its unscaled fp32 dQ [128*QB][64] in `part`; attn_dq_merge_kernel adds them.
+template <int QB, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ LSE2, const float* __restrict__ DELTA,
                                                                bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo,
-                                                               TStride sdq, int S, int H, int n_qt, float scale) {
+                                                               TStride sdq, int S, int H, int n_qt, float scale, int task0, int nsplit,
+                                                               float* __restrict__ part) {
     // a wave owns QB blocks of 32 query rows: every K / V fragment read from LDS feeds QB MFMAs
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // K[2], V[2]
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
+    const int chunk = SPLIT ? (int)blockIdx.x % nsplit : 0;
     const int bh = vid / n_qt, qt = vid % n_qt;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
@@ -684,23 +688,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         kx = f32_to_frag(o8);
     }
 
-    const int nt = (S + TILE - 1) / TILE;
-    u32x4_t kr[2];   // one staging register set: K of the next tile during the first key half, V during the second
-    tile_load(Kb, sk.s, 0, S, kr);
-    tile_store(lds, kr);
-    tile_load(Vb, sv.s, 0, S, kr);
-    tile_store(lds + 2 * TILE_ELEMS, kr);
-#pragma unroll
-    for (int j = 0; j < QB; ++j) { frags_arrived(qf[j]); frags_arrived(dof[j]); }
+    const int nt_all = (S + TILE - 1) / TILE;
+    const int tb = SPLIT ? nt_all * chunk / nsplit : 0;              // this workgroup's key tiles: [tb, nt)
+    const int nt = SPLIT ? nt_all * (chunk + 1) / nsplit : nt_all;
     const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
     const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
+    u32x4_t kr[2];   // one staging register set: K of the next tile during the first key half, V during the second
+    tile_load_buf(krs, sk.s, tb * TILE, koff, kr);
+    tile_store(lds + (tb & 1) * TILE_ELEMS, kr);
+    tile_load_buf(vrs, sv.s, tb * TILE, voff, kr);
+    tile_store(lds + (2 + (tb & 1)) * TILE_ELEMS, kr);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) { frags_arrived(qf[j]); frags_arrived(dof[j]); }
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    for (int t = tb; t < nt; ++t) {
         const bf16_t* kl = lds + (t & 1) * TILE_ELEMS;
         const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
         tile_load_buf(krs, sk.s, (t + 1) * TILE, koff, kr);   // past the last tile: zeros into a buffer nobody reads
-        const bool tail = (t == nt - 1) && (S & (TILE - 1));
+        const bool tail = (t == nt_all - 1) && (S & (TILE - 1));
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t s[QB], dp[QB];
@@ -760,6 +766,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, kr);
         __syncthreads();
     }
+    if (SPLIT) {
+        float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * (128 * QB * HD);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const int r = wave * (32 * QB) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t w = {dq[j][db][4 * g], dq[j][db][4 * g + 1], dq[j][db][4 * g + 2], dq[j][db][4 * g + 3]};
+                    *reinterpret_cast<f32x4_t*>(pb + r * HD + db * 32 + 8 * g + 4 * hi) = w;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const int q = q0 + 32 * j + (lane & 31);
@@ -778,25 +799,45 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     }
 }
 
+// sum the key-range chunks of the split dQ tasks: one wave per query row, lane = d
+__global__ __launch_bounds__(256) void attn_dq_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_qt, int rows_per_task,
+                                                              bf16_t* __restrict__ dQ, TStride sdq, int S, int H, float scale) {
+    const int lane = threadIdx.x & 63, rows4 = rows_per_task >> 2;
+    const int r = ((int)blockIdx.x % rows4) * 4 + (threadIdx.x >> 6), tl = (int)blockIdx.x / rows4;
+    const int vid = task0 + tl, bh = vid / n_qt, qt = vid % n_qt;
+    const int q = qt * rows_per_task + r;
+    if (q >= S) return;
+    const float* pb = part + (size_t)tl * nsplit * rows_per_task * HD + r * HD + lane;
+    float acc = 0.f;
+    for (int c = 0; c < nsplit; ++c) acc += pb[(size_t)c * rows_per_task * HD];
+    const int b = bh / H, h = bh % H;
+    dQ[(size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s + lane] = f32_to_bf16(acc * scale);
+}
+
 // =====================================================================================================
 // Backward, dK / dV:  dV = P^T dO ,  dK = scale * dS^T Q       (workgroup owns 128 keys, streams 64-query tiles)
 // =====================================================================================================
 #ifndef DKV_WAVES
 #define DKV_WAVES 2
 #endif
+// SPLIT: workgroup (task0 + blockIdx / nsplit, chunk blockIdx % nsplit) sweeps query tiles [nt*chunk/nsplit, nt*(chunk+1)/nsplit)
+// and leaves unscaled fp32 dK [128][64], dV [128][64] in `part`; attn_dkv_merge_kernel adds the chunks.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                              const float* __restrict__ LSE2, const float* __restrict__ DELTA,
                                                              bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, TStride sq, TStride sk,
                                                              TStride sv, TStride sdo, TStride sdk, TStride sdv, int S, int H, int n_kt,
-                                                             float kscale /* scale / (scale*log2e) = ln 2: Q is pre-scaled */) {
+                                                             float kscale /* scale / (scale*log2e) = ln 2: Q is pre-scaled */, int task0,
+                                                             int nsplit, float* __restrict__ part) {
     // Q[3], dO[3] tile rings.  The 8 padding columns (64..71) of every row carry the row's softmax statistics as three
     // bf16 pieces (-lse in the Q tile, -delta in the dO tile); one extra MFMA k-step against a (1,1,1,0,...) operand folds
     // them into the S and dP accumulators, so P = exp2(acc) and dS = P * acc with no per-score subtract.
     // Software pipeline (as in the forward): the scores of the NEXT tile's first q-block are made at the end of this
     // tile, between the two dV/dK products, so every stretch of the loop body has both MFMA and VALU work in it.
     __shared__ __attribute__((aligned(16))) bf16_t lds[6 * TILE_ELEMS + 16];
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
+    const int chunk = SPLIT ? (int)blockIdx.x % nsplit : 0;
     const int bh = vid / n_kt, kt = vid % n_kt;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
@@ -826,7 +867,9 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
-    const int nt = (S + TILE - 1) / TILE;
+    const int nt_all = (S + TILE - 1) / TILE;
+    const int tb = SPLIT ? nt_all * chunk / nsplit : 0;              // this workgroup's query tiles: [tb, nt)
+    const int nt = SPLIT ? nt_all * (chunk + 1) / nsplit : nt_all;
     bf16_t* const qring = lds;
     bf16_t* const doring = lds + 3 * TILE_ELEMS;
     u32x4_t qr[2], dor[2];
@@ -850,10 +893,10 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     const rsrc_t qrs = tile_rsrc(Qb, sq.s, S), dors = tile_rsrc(dOb, sdo.s, S);
     const uint32_t qoff = tile_lane_byte_offset(sq.s), dooff = tile_lane_byte_offset(sdo.s);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {   // tiles 0 and 1 (a tile past the end reads zeros)
-        tile_load_buf(qrs, sq.s, i * TILE, qoff, qr);
-        tile_load_buf(dors, sdo.s, i * TILE, dooff, dor);
-        stat_load(i);
+    for (int i = 0; i < 2; ++i) {   // tiles tb and tb + 1 (a tile past the end reads zeros)
+        tile_load_buf(qrs, sq.s, (tb + i) * TILE, qoff, qr);
+        tile_load_buf(dors, sdo.s, (tb + i) * TILE, dooff, dor);
+        stat_load(tb + i);
         tile_store(qring + i * TILE_ELEMS, qr);
         tile_store(doring + i * TILE_ELEMS, dor);
         stat_store(i);
@@ -933,10 +976,24 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
         slot = slot1;
         __syncthreads();
     };
-    const bool ragged = (S & (TILE - 1)) != 0;
+    const bool ragged = (S & (TILE - 1)) != 0 && nt == nt_all;   // the ragged tile, if any, is the global last one
     const int nfull = ragged ? nt - 1 : nt;
-    for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+    for (int t = tb; t < nfull; ++t) tile_body(t, std::false_type{});
     if (ragged) tile_body(nt - 1, std::true_type{});
+    if (SPLIT) {
+        float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * (2 * WG_ROWS * HD);
+        const int r = wave * 32 + (lane & 31);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t wk = {dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]};
+                const f32x4_t wv = {dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]};
+                *reinterpret_cast<f32x4_t*>(pb + r * HD + db * 32 + 8 * g + 4 * hi) = wk;
+                *reinterpret_cast<f32x4_t*>(pb + WG_ROWS * HD + r * HD + db * 32 + 8 * g + 4 * hi) = wv;
+            }
+        return;
+    }
     const int k = k0 + (lane & 31);
     if (k < S) {
         bf16_t* kp = dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s);
@@ -954,6 +1011,25 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                 *reinterpret_cast<u32x2_t*>(vp + db * 32 + 8 * g + 4 * hi) = w;
             }
     }
+}
+
+// sum the query-range chunks of the split dK/dV tasks: one wave per key row, lane = d
+__global__ __launch_bounds__(256) void attn_dkv_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_kt, bf16_t* __restrict__ dK,
+                                                               bf16_t* __restrict__ dV, TStride sdk, TStride sdv, int S, int H, float kscale) {
+    const int lane = threadIdx.x & 63;
+    const int r = ((int)blockIdx.x % (WG_ROWS / 4)) * 4 + (threadIdx.x >> 6), tl = (int)blockIdx.x / (WG_ROWS / 4);
+    const int vid = task0 + tl, bh = vid / n_kt, kt = vid % n_kt;
+    const int key = kt * WG_ROWS + r;
+    if (key >= S) return;
+    const float* pb = part + (size_t)tl * nsplit * (2 * WG_ROWS * HD) + r * HD + lane;
+    float ak = 0.f, av = 0.f;
+    for (int c = 0; c < nsplit; ++c) {
+        ak += pb[(size_t)c * (2 * WG_ROWS * HD)];
+        av += pb[(size_t)c * (2 * WG_ROWS * HD) + WG_ROWS * HD];
+    }
+    const int b = bh / H, h = bh % H;
+    dK[(size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)key * sdk.s + lane] = f32_to_bf16(ak * kscale);
+    dV[(size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)key * sdv.s + lane] = f32_to_bf16(av);
 }
 
 // =====================================================================================================
@@ -1319,37 +1395,123 @@ int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_str
     return VGPA_OK;
 }
 
-// step 2: dK, dV (workgroup per 128 keys)
+// step 2: dK, dV (workgroup per 128 keys).  With a workspace the leftover tasks of a mostly empty last scheduling round are
+// cut into query-range chunks (split_plan); split_mode as in vgpa_attn_fwd_ws.
+#define BWD_MAX_SPLIT 16
+#define DKV_PART_FLOATS (2 * WG_ROWS * HD)
+#define DQ_PART_FLOATS (DQ_QB * WG_ROWS * HD)
+static int32_t attn_bwd_dkv_impl(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dk,
+                                 void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                 const int64_t* do_strides, const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S,
+                                 int64_t head_dim, int32_t split_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !d_o || !lse2 || !delta || !dk || !dv || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dk_strides) ||
+        !SOK(dv_strides) || !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv) || (workspace && !al16(workspace)))
+        return VGPA_ERR_INVALID;
+    const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
+    const int64_t tasks = (int64_t)n_t * B * H;
+    const float kscale = 0.6931471805599453f;
+    int64_t n_main = tasks;
+    int nsplit = 1;
+    if (workspace) split_plan(tasks, (int)((S + TILE - 1) / TILE), split_mode, BWD_MAX_SPLIT, &n_main, &nsplit);
+    const int64_t n_tail = tasks - n_main;
+    if (n_tail > 0 && ws_bytes < (size_t)n_tail * nsplit * DKV_PART_FLOATS * sizeof(float)) {
+        if (split_mode >= 2) return VGPA_ERR_WORKSPACE;
+        n_main = tasks;
+    }
+    if (n_main > 0) {
+        VGPA_LAUNCH(attn_bwd_dkv_kernel<false>, dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                    mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, kscale, 0, 1, (float*)nullptr);
+        VGPA_CHECK_LAUNCH();
+    }
+    if (n_main < tasks) {
+        VGPA_LAUNCH(attn_bwd_dkv_kernel<true>, dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                    (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides),
+                    mk(do_strides), mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, kscale, (int)n_main, nsplit, (float*)workspace);
+        VGPA_CHECK_LAUNCH();
+        VGPA_LAUNCH(attn_dkv_merge_kernel, dim3((unsigned)(n_tail * (WG_ROWS / 4))), dim3(256), 0, stream, (const float*)workspace, nsplit, (int)n_main,
+                    n_t, (bf16_t*)dk, (bf16_t*)dv, mk(dk_strides), mk(dv_strides), (int)S, (int)H, kscale);
+        VGPA_CHECK_LAUNCH();
+    }
+    return VGPA_OK;
+}
+
+// step 3: dQ (workgroup per 128 * DQ_QB queries); split as above, along the key tiles
+static int32_t attn_bwd_dq_impl(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dq,
+                                const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                                const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode,
+                                void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !d_o || !lse2 || !delta || !dq || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dq_strides) ||
+        !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dq) || (workspace && !al16(workspace)))
+        return VGPA_ERR_INVALID;
+    const int n_t = (int)((S + DQ_QB * WG_ROWS - 1) / (DQ_QB * WG_ROWS));
+    const int64_t tasks = (int64_t)n_t * B * H;
+    int64_t n_main = tasks;
+    int nsplit = 1;
+    if (workspace) split_plan(tasks, (int)((S + TILE - 1) / TILE), split_mode, BWD_MAX_SPLIT, &n_main, &nsplit);
+    const int64_t n_tail = tasks - n_main;
+    if (n_tail > 0 && ws_bytes < (size_t)n_tail * nsplit * DQ_PART_FLOATS * sizeof(float)) {
+        if (split_mode >= 2) return VGPA_ERR_WORKSPACE;
+        n_main = tasks;
+    }
+    if (n_main > 0) {
+        VGPA_LAUNCH((attn_bwd_dq_kernel<DQ_QB, false>), dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                    (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                    mk(dq_strides), (int)S, (int)H, n_t, scale, 0, 1, (float*)nullptr);
+        VGPA_CHECK_LAUNCH();
+    }
+    if (n_main < tasks) {
+        VGPA_LAUNCH((attn_bwd_dq_kernel<DQ_QB, true>), dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                    (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                    mk(dq_strides), (int)S, (int)H, n_t, scale, (int)n_main, nsplit, (float*)workspace);
+        VGPA_CHECK_LAUNCH();
+        VGPA_LAUNCH(attn_dq_merge_kernel, dim3((unsigned)(n_tail * (DQ_QB * WG_ROWS / 4))), dim3(256), 0, stream, (const float*)workspace, nsplit,
+                    (int)n_main, n_t, DQ_QB * WG_ROWS, (bf16_t*)dq, mk(dq_strides), (int)S, (int)H, scale);
+        VGPA_CHECK_LAUNCH();
+    }
+    return VGPA_OK;
+}
+
 int32_t vgpa_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dk,
                           void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
                           const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
                           hipStream_t stream) {
-    if (!q || !k || !v || !d_o || !lse2 || !delta || !dk || !dv || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
-    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dk_strides) ||
-        !SOK(dv_strides) || !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv))
-        return VGPA_ERR_INVALID;
-    const int n_t = (int)((S + WG_ROWS - 1) / WG_ROWS);
-    VGPA_LAUNCH(attn_bwd_dkv_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides),
-                       mk(do_strides), mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, 0.6931471805599453f);
-    VGPA_CHECK_LAUNCH();
-    return VGPA_OK;
+    (void)scale;
+    return attn_bwd_dkv_impl(q, k, v, d_o, lse2, delta, dk, dv, q_strides, k_strides, v_strides, do_strides, dk_strides, dv_strides, B, H, S,
+                             head_dim, 0, nullptr, 0, stream);
 }
-
-// step 3: dQ (workgroup per 128 queries)
 int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dq,
                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
                          const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, hipStream_t stream) {
-    if (!q || !k || !v || !d_o || !lse2 || !delta || !dq || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
-    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dq_strides) ||
-        !al16(q) || !al16(k) || !al16(v) || !al16(d_o) || !al16(dq))
-        return VGPA_ERR_INVALID;
-    const int n_t = (int)((S + DQ_QB * WG_ROWS - 1) / (DQ_QB * WG_ROWS));
-    VGPA_LAUNCH((attn_bwd_dq_kernel<DQ_QB>), dim3((unsigned)((int64_t)n_t * B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides),
-                       mk(do_strides), mk(dq_strides), (int)S, (int)H, n_t, scale);
-    VGPA_CHECK_LAUNCH();
-    return VGPA_OK;
+    return attn_bwd_dq_impl(q, k, v, d_o, lse2, delta, dq, q_strides, k_strides, v_strides, do_strides, dq_strides, B, H, S, head_dim, scale, 0,
+                            nullptr, 0, stream);
+}
+
+// Workspace for the split forms below (shared by the two; they run one after the other on a stream).
+size_t vgpa_attn_bwd_split_workspace_bytes(int64_t B, int64_t H, int64_t S) {
+    const int64_t t_dkv = (S + WG_ROWS - 1) / WG_ROWS * B * H, t_dq = (S + DQ_QB * WG_ROWS - 1) / (DQ_QB * WG_ROWS) * B * H;
+    int64_t p_dkv = wg_slots(), p_dq = wg_slots();
+    if (t_dkv * BWD_MAX_SPLIT < p_dkv) p_dkv = t_dkv * BWD_MAX_SPLIT;
+    if (t_dq * BWD_MAX_SPLIT < p_dq) p_dq = t_dq * BWD_MAX_SPLIT;
+    const size_t a = (size_t)p_dkv * DKV_PART_FLOATS * sizeof(float), b = (size_t)p_dq * DQ_PART_FLOATS * sizeof(float);
+    return a > b ? a : b;
+}
+int32_t vgpa_attn_bwd_dkv_ws(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dk,
+                             void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                             const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
+                             int32_t split_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    (void)scale;
+    return attn_bwd_dkv_impl(q, k, v, d_o, lse2, delta, dk, dv, q_strides, k_strides, v_strides, do_strides, dk_strides, dv_strides, B, H, S,
+                             head_dim, split_mode, workspace, ws_bytes, stream);
+}
+int32_t vgpa_attn_bwd_dq_ws(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dq,
+                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                            const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode,
+                            void* workspace, size_t ws_bytes, hipStream_t stream) {
+    return attn_bwd_dq_impl(q, k, v, d_o, lse2, delta, dq, q_strides, k_strides, v_strides, do_strides, dq_strides, B, H, S, head_dim, scale,
+                            split_mode, workspace, ws_bytes, stream);
 }
 
 // fused backward: dK, dV (bf16 views) and dQ accumulated into dq_f32 -- fp32 [B,H,S,64] contiguous, ZEROED BY THE CALLER.

@@ -509,7 +509,7 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=-1):
     return o, lse
 
 
-def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False):
+def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False, split_mode=-1):
     """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.
     Algorithmic FLOPs (backward = 2 x forward): dK/dV kernel carries dV, dP, dK = 6 S^2 d; dQ kernel 2 S^2 d
     (the S = QK^T recomputes in both kernels and the second dP are overhead, not counted)."""
@@ -527,12 +527,15 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
             _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), st))
         dq.copy_(dq32)
         return
+    ws_bytes = _lib.query("vgpa_attn_bwd_split_workspace_bytes", B, H, S) if split_mode != 0 else 0
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
+    wsp = ws if ws_bytes else None
     _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
-        "vgpa_attn_bwd_dkv", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
-        _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), st))
+        "vgpa_attn_bwd_dkv_ws", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+        _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
     _timed("attn_bwd_dq_kernel", 2.0 * S * S * Dh * B * H, lambda: _lib.call(
-        "vgpa_attn_bwd_dq", q, k, v, do, lse, delta, dq, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
-        _bhs_strides(dq), B, H, S, Dh, float(scale), st))
+        "vgpa_attn_bwd_dq_ws", q, k, v, do, lse, delta, dq, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+        _bhs_strides(dq), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
 
 
 class _QKNormAttentionFn(torch.autograd.Function):
