@@ -481,6 +481,8 @@ LOG2E = 1.4426950408889634
 # It stays selectable (VGPA_ATTN_BWD=fused) and parity-tested.
 import os as _os
 ATTN_BWD_FUSED = _os.environ.get("VGPA_ATTN_BWD", "split") == "fused"
+# tail-round treatment of the attention launches (vgpa_attn_*_ws split_mode): -1 automatic (default), 0 off
+ATTN_SPLIT_MODE = int(_os.environ.get("VGPA_ATTN_SPLIT", "-1"))
 
 
 def prescale_q(q, scale=None):
@@ -490,7 +492,7 @@ def prescale_q(q, scale=None):
     return (q.float() * (scale * LOG2E)).to(q.dtype)
 
 
-def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=-1):
+def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None):
     """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32.
     split_mode: -1 lets the launcher cut the tasks of a mostly empty last scheduling round into key-range chunks,
     0 forbids it, k >= 2 forces k chunks for every task (tests)."""
@@ -501,6 +503,7 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=-1):
     o = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=q.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
+    split_mode = ATTN_SPLIT_MODE if split_mode is None else split_mode
     ws_bytes = _lib.query("vgpa_attn_fwd_workspace_bytes", B, H, S) if split_mode != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
     _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
@@ -509,7 +512,7 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=-1):
     return o, lse
 
 
-def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False, split_mode=-1):
+def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False, split_mode=None):
     """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.
     Algorithmic FLOPs (backward = 2 x forward): dK/dV kernel carries dV, dP, dK = 6 S^2 d; dQ kernel 2 S^2 d
     (the S = QK^T recomputes in both kernels and the second dP are overhead, not counted)."""
@@ -527,6 +530,7 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
             _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), st))
         dq.copy_(dq32)
         return
+    split_mode = ATTN_SPLIT_MODE if split_mode is None else split_mode
     ws_bytes = _lib.query("vgpa_attn_bwd_split_workspace_bytes", B, H, S) if split_mode != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
     wsp = ws if ws_bytes else None
