@@ -1,6 +1,7 @@
 """torch.autograd wrappers over the C-ABI HIP kernels.  PyTorch here is plumbing (device memory, streams,
 autograd graph); every op below runs a hand-written gfx950 kernel through `_lib.call` and raises if it cannot."""
 import ctypes
+import os as _os
 
 import torch
 
@@ -390,6 +391,52 @@ def lora_grad(u, v, s=1.0):
     return g
 
 
+# dX = dY W of a frozen projection: torch.autograd issues it as an "NN" GEMM, which hipBLASLt runs 4-25 % slower at these
+# shapes than the "TN" form x W^T (tools/gemm_bench.py: fused q,k,v 1.91 -> 1.44 ms, FF 2.24 -> 2.07 / 2.08 -> 1.89 ms).  The
+# base weights never change during LoRA training, so a transposed copy is kept next to each weight (11 GB for CogVideoX-5B,
+# made at the first backward) and dX is computed as dY (W^T)^T.  VGPA_WT_CACHE=0 turns it off.
+_WT_CACHE = _os.environ.get("VGPA_WT_CACHE", "1") == "1"
+
+
+def _transposed(W):
+    if not _WT_CACHE:
+        return None
+    c = getattr(W, "_vgpa_wt", None)
+    if c is None or c[0] != W._version or c[1].device != W.device or c[1].dtype != W.dtype:
+        c = (W._version, W.detach().t().contiguous())
+        W._vgpa_wt = c          # lives and dies with the weight tensor
+    return c[1]
+
+
+def _frozen_dx(dy2, W):
+    Wt = _transposed(W)
+    return dy2 @ W if Wt is None else torch.nn.functional.linear(dy2, Wt)
+
+
+class _FrozenLinearFn(torch.autograd.Function):
+    """y = x W^T + b with W, b frozen: backward is dX only, through the cached transposed weight."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        ctx.save_for_backward(W)
+        return torch.nn.functional.linear(x, W, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (W,) = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
+        return _frozen_dx(dy2, W).view(*dy.shape[:-1], W.shape[1]), None, None
+
+
+def frozen_linear(x, W, bias):
+    """F.linear for a projection whose weight / bias do not train (falls back to F.linear otherwise)."""
+    if W.requires_grad or (bias is not None and bias.requires_grad) or not (torch.is_grad_enabled() and x.requires_grad):
+        return torch.nn.functional.linear(x, W, bias)
+    return _FrozenLinearFn.apply(x, W, bias)
+
+
 class _LinearLoraFn(torch.autograd.Function):
     """y = x W^T + b, and for every output slice i that carries an adapter:  y_i += s_i * (x A_i^T) B_i^T
     (PEFT Linear.forward; adapters are fp32 parameters cast to the activation dtype at use).  W/b are frozen:
@@ -436,7 +483,7 @@ class _LinearLoraFn(torch.autograd.Function):
         if dy2.stride(1) != 1:
             dy2 = dy2.contiguous()
         Dn = dy2.shape[1] // n
-        dx = dy2 @ W
+        dx = _frozen_dx(dy2, W)
         M = dy2.shape[0]
         dT = torch.empty(M, len(act) * rp, dtype=dy2.dtype, device=dy2.device)
         grads = [None] * (2 * n)
@@ -455,7 +502,7 @@ class _LinearLoraFn(torch.autograd.Function):
 def linear_lora(x, W, bias, loras):
     """loras: list (one per equal output slice) of None or (A [r,in] fp32, B [out_i,r] fp32, scaling)."""
     if all(l is None for l in loras):
-        return torch.nn.functional.linear(x, W, bias)
+        return frozen_linear(x, W, bias)
     flat, sc = [], []
     for l in loras:
         if l is None:
@@ -479,7 +526,6 @@ LOG2E = 1.4426950408889634
 # "fused" = one kernel with dQ by fp32 atomics (5 products).  Measured on MI355X at the headline shape the fused form
 # is SLOWER (46.6 ms vs 26.5 ms per layer): its 60 GB of dQ atomics per launch run at ~2.6 TB/s (23.9 ms without them).
 # It stays selectable (VGPA_ATTN_BWD=fused) and parity-tested.
-import os as _os
 ATTN_BWD_FUSED = _os.environ.get("VGPA_ATTN_BWD", "split") == "fused"
 # tail-round treatment of the attention launches (vgpa_attn_*_ws split_mode): -1 automatic (default), 0 off
 ATTN_SPLIT_MODE = int(_os.environ.get("VGPA_ATTN_SPLIT", "-1"))

@@ -208,9 +208,9 @@ class CogVideoXBlock(nn.Module):
         applied to x_out -- each gated residual add is fused with the LayerNorm that consumes it."""
         a = self.attn1(n, text_len, rope)
         x, n2 = ops.residual_ln(x, a, gates1, _f32(self.norm2.norm.weight), _f32(self.norm2.norm.bias), mod2, text_len, self.eps)
-        u = F.linear(n2, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
+        u = ops.frozen_linear(n2, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
         g = ops.gelu_tanh(u)
-        f = F.linear(g, self.ff.net[2].weight, self.ff.net[2].bias)
+        f = ops.frozen_linear(g, self.ff.net[2].weight, self.ff.net[2].bias)
         return ops.residual_ln(x, f, gates2, nxt_w, nxt_b, nxt_mod, text_len, nxt_eps)
 
 
