@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
 // 64-row x 128-column block of Y: the four waves put their s*T*Bw^T sub-blocks into an fp32 LDS tile, then all 256
 // threads read-modify-write Y in 16-byte row-contiguous pieces (the 436 MB RMW of Y is the whole cost of this op).
 // =====================================================================================================
+#ifndef UP_COLS
 #define UP_COLS 128
+#endif
 #define UP_PITCH (UP_COLS + 4)   // fp32 words per LDS row (+4: conflict-free 16-byte writes down a column of rows)
 template <int KS>
 __global__ __launch_bounds__(256) void lora_up_add_kernel(bf16_t* __restrict__ Y, int64_t ldy, const bf16_t* __restrict__ T, int64_t ldt,
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(bf16_t* __restrict__ Y
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) tf[ks] = *reinterpret_cast<const bf16x8_t*>(T + mr * ldt + ks * 16 + hi * 8);   // B operand: col = row m
 #pragma unroll
-    for (int cbi = 0; cbi < 2; ++cbi) {
-        const int nl = cg * 64 + cbi * 32;                          // local column of this 32x32 block
+    for (int cbi = 0; cbi < UP_COLS / 64; ++cbi) {
+        const int nl = cg * (UP_COLS / 2) + cbi * 32;               // local column of this 32x32 block
         int nrow = n0 + nl + (lane & 31);
         nrow = nrow < N ? nrow : N - 1;
         f32x16_t acc;
@@ -154,11 +156,11 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(bf16_t* __restrict__ Y
         }
     }
     __syncthreads();
-    // 64 rows x 16 chunks of 8 columns = 1024 chunks, 4 per thread; 16 consecutive lanes cover 256 contiguous bytes of a row
+    // 64 rows x UP_COLS/8 chunks of 8 columns, UP_COLS/32 per thread; UP_COLS/8 consecutive lanes cover one row's contiguous bytes
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < UP_COLS / 32; ++j) {
         const int c = threadIdx.x + 256 * j;
-        const int row = c >> 4, col = (c & 15) * 8;
+        const int row = c / (UP_COLS / 8), col = (c % (UP_COLS / 8)) * 8;
         const int64_t m = m0 + row;
         if (m < M && n0 + col < N) {
             const float* tp = tile + row * UP_PITCH + col;
