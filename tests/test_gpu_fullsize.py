@@ -97,3 +97,25 @@ def test_layernorm_statistics_full_stream(ops):
     n = ops.ln_modulate(x, torch.ones(3072, device="cuda"), torch.zeros(3072, device="cuda"), None, 0, 1e-5).float()
     assert n.mean(-1).abs().max().item() < 2e-3
     assert (n.var(-1, unbiased=False) - 1).abs().max().item() < 5e-3
+
+
+def test_tail_round_split_at_the_headline_launch_shape(ops):
+    """2 x 48 heads x 17 776 tokens = 6720 forward / dQ tasks and 13 344 dK/dV tasks: the launchers cut the leftover 64 / 32
+    tasks into chunks (vgpa_attn_*_ws, automatic mode).  Same results as the single launches up to fp32 summation order."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q, k, v, do = (torch.randn(2, H, S, 64, generator=g, device="cuda").to(torch.bfloat16) for _ in range(4))
+    o0, lse0 = ops.attention_fwd_raw(q, k, v, split_mode=0)
+    o1, lse1 = ops.attention_fwd_raw(q, k, v, split_mode=-1)
+    diff = (o1.float() - o0.float()).abs()
+    assert (diff > 0).any() and diff.max().item() < 4e-3            # the split rows differ (rounding), and only by an ulp of |o| ~ 0.1
+    assert (lse1 - lse0).abs().max().item() < 1e-3
+    outs = []
+    ov = o0.view(2, S, H, 64).permute(0, 2, 1, 3)
+    for sm in (0, -1):
+        dq, dk, dv = (torch.empty(2, H, S, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+        ops.attention_bwd_raw(q, k, v, ov, do, lse0, dq, dk, dv, split_mode=sm)
+        outs.append((dq, dk, dv))
+    for a, b in zip(*outs):
+        scale = b.float().abs().max().item()
+        assert (a.float() - b.float()).abs().max().item() < 0.02 * scale + 1e-4
+        assert torch.isfinite(a).all()
