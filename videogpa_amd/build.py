@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libvgpa_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-munsafe-fp-atomics",
+         "-Wall", "-Wno-unused-function",
          "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC]
 
 
@@ -32,7 +33,9 @@ def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
     if force or _stale(obj, [src] + headers):
-        r = subprocess.run([HIPCC, *FLAGS, "-c", src, "-o", obj], capture_output=True, text=True)
+        # the MFMA kernels keep fp32 adds / multiplies unpacked: v_pk_*_f32 does not co-issue with the matrix pipe (attention.hip)
+        extra = ["-fno-slp-vectorize"] if os.path.basename(src) in ("attention.hip", "lora.hip") else []
+        r = subprocess.run([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         if r.stderr.strip():

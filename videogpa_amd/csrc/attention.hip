@@ -23,6 +23,14 @@
 
 #include "mfma_tiles.h"
 
+// fp32 adds / multiplies next to MFMAs are written one element at a time and this file is built with -fno-slp-vectorize:
+// a packed fp32 instruction (v_pk_add_f32, v_pk_mul_f32) does not co-issue with the matrix pipe -- tools/dot2_probe: 2
+// v_pk_add_f32 per MFMA stretch a 64 ns group of four MFMAs to 107 ns, 4 scalar v_add_f32 leave it at 68 ns -- and hipcc's
+// SLP vectoriser would pack adjacent scalar operations by itself.  (Not inline asm: the compiler must see these to place
+// the MFMA -> VALU hazard wait states.)
+__device__ __forceinline__ float nopack_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float nopack_mul(float a, float b) { return a * b; }
+
 // XCD-aware remap of the linear block id: consecutive virtual ids (same head) land on one XCD.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, j = bid >> 3;
@@ -329,10 +337,10 @@ __device__ __forceinline__ void exp_half(f32x16_t (&s)[QB], f32x2_t (&ps2)[QB]) 
     for (int j = 0; j < QB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const f32x2_t p = {__builtin_amdgcn_exp2f(s[j][r]), __builtin_amdgcn_exp2f(s[j][r + 1])};
-            s[j][r] = p[0];
-            s[j][r + 1] = p[1];
-            ps2[j] += p;
+            s[j][r] = __builtin_amdgcn_exp2f(s[j][r]);
+            s[j][r + 1] = __builtin_amdgcn_exp2f(s[j][r + 1]);
+            ps2[j][0] = nopack_add(ps2[j][0], s[j][r]);
+            ps2[j][1] = nopack_add(ps2[j][1], s[j][r + 1]);
         }
 }
 
@@ -739,13 +747,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
             for (int j = 0; j < QB; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f32x2_t p = {__builtin_amdgcn_exp2f(s[j][r]), __builtin_amdgcn_exp2f(s[j][r + 1])};
-                    f32x2_t d = {dp[j][r], dp[j][r + 1]};
-                    d = d * p;                                                                           // dS^T
-                    s[j][r] = d[0];
-                    s[j][r + 1] = d[1];
-                }
+                for (int r = 0; r < 16; ++r) s[j][r] = nopack_mul(dp[j][r], __builtin_amdgcn_exp2f(s[j][r]));   // dS^T = P * (dP - delta)
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 bf16x8_t dsf[QB];
@@ -928,14 +930,9 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                 if (row0 + acc_row(r, hi) >= S) s[r] = -INFINITY;
         }
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-            f32x2_t d = {dp[r], dp[r + 1]};
-            d = d * p;
-            s[r] = p[0];
-            s[r + 1] = p[1];
-            dp[r] = d[0];
-            dp[r + 1] = d[1];
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(s[r]);
+            dp[r] = nopack_mul(dp[r], s[r]);
         }
     };
     // dV^T[d,key] += dO^T P,  dK^T[d,key] += Q^T dS   for one q-block
