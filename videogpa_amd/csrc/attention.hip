@@ -439,8 +439,8 @@ __device__ __forceinline__ void safe_tile(const bf16_t* kl, const bf16_t* vl, in
 // nt*(chunk+1)/nsplit) and leaves its un-normalised O, m and l in `part`; attn_fwd_merge_kernel combines the chunks.
 // (blockIdx % nsplit is also the XCD the workgroup lands on for nsplit = 8: the workgroups of one XCD share one key range.)
 #define FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64], m[256], l[256]
-template <int QB, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int QB, int NW, bool SPLIT>
+__global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
                                                                  int S, int H, int n_qt, int task0, int nsplit, float* __restrict__ part) {
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
     const int bh = vid / n_qt, qt = vid % n_qt;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int q0 = (qt * 4 + wave) * (32 * QB);
+    const int q0 = (qt * NW + wave) * (32 * QB);
 
     const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
     const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
     const bool ragged = (S & (TILE - 1)) != 0 && nt == nt_all;       // the ragged tile, if any, is the global last one
     const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
     const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
-    u32x4_t kr[2], vr[2];
+    u32x4_t kr[8 / NW], vr[8 / NW];
     if (threadIdx.x == 0) redo_flag = 0;
     // prologue: K(tb..tb+2), V(tb..tb+1) -> LDS (rows past S read as zeros; their scores are masked or unused)
 #pragma unroll
@@ -1322,7 +1322,7 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
 #ifndef FWD_V1   // product path: the software-pipelined kernel; -DFWD_V1 builds the three-block kernel (diagnostic hooks live there)
-    if (FWD_NW == 4 && FWD_QB == 2) {
+    if (FWD_NW * FWD_QB == 8) {   // 256 query rows per task either way
         int64_t n_main = nblk;
         int nsplit = 1;
         if (workspace) split_plan(nblk, (int)((S + TILE - 1) / TILE), split_mode, FWD_MAX_SPLIT, &n_main, &nsplit);
@@ -1332,13 +1332,13 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
             n_main = nblk;   // automatic mode: fall back to the single launch
         }
         if (n_main > 0) {
-            VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB, false>), dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+            VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB, FWD_NW, false>), dim3((unsigned)n_main), dim3(64 * FWD_NW), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                         (const bf16_t*)v, (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, 0, 1,
                         (float*)nullptr);
             VGPA_CHECK_LAUNCH();
         }
         if (n_main < nblk) {
-            VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB, true>), dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q,
+            VGPA_LAUNCH((attn_fwd_pipe_kernel<FWD_QB, FWD_NW, true>), dim3((unsigned)(n_tail * nsplit)), dim3(64 * FWD_NW), 0, stream, (const bf16_t*)q,
                         (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S,
                         (int)H, n_qt, (int)n_main, nsplit, (float*)workspace);
             VGPA_CHECK_LAUNCH();
