@@ -7,12 +7,17 @@ parameters, flat-buffer gradient all-reduce (N>1), fused clip + AdamW.  Syntheti
 named shape, random-init weights of the named architecture (no network for checkpoints), all resident in HBM before
 the timed region.  Prints ONE JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4]
+
+`--gpus N` with N > 1 launches N ranks itself (one process per GPU under torch.distributed.run, RCCL); it can also be
+started under torchrun directly, in which case WORLD_SIZE must equal --gpus:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,7 +28,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0             # same guide: HBM3E ~8 TB/s
 TEXT_LEN = 226
+
+# BASELINE.json configs that fit a bench line (SURVEY section 8 sizes).  cfg2 is the headline the metric is quoted on.
+CONFIGS = {
+    "cfg2": dict(model="COGVIDEOX_5B", frames=13, height=60, width=90, checkpoint=False, cond=False,
+                 label="BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720"),
+    "cfg3": dict(model="COGVIDEOX_5B_I2V", frames=13, height=60, width=90, checkpoint=False, cond=True,
+                 label="BASELINE configs[2]: CogVideoX-5B-I2V (32 input channels, learned positional table), 49f x 480x720 + image-cond latent"),
+    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=True, cond=False,
+                 label="BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t=2), 81f x 768x1360 (21 latent frames, even-cropped to 20)"),
+}
 
 
 def build_model(cfg_kw, device, seed):
@@ -54,29 +70,64 @@ def flops_per_pair_step(S, D, L, r):
     return 2 * fwd + 2 * (fwd + L * f_lora) + 2 * L * (f_lin + 2 * f_attn + 2 * f_lora)
 
 
-def cpu_baseline(F_step):
-    """Bounded CPU sample of the same path with the oracle (kind 'port'): one CogVideoX-5B-geometry transformer block
-    forward (fp32, D=3072, 48 heads, text 226 + 4096 video tokens) on the host cores, scaled to a full pair-step by the
-    algorithmic-FLOP ratio."""
+def cpu_baseline(F_step, budget_s=100.0):
+    """The oracle (kind "port": diffusers / peft are not installed, so the reference's own step cannot run) timed on the
+    host cores on BASELINE configs[0] -- the reference's CPU-runnable case: CogVideoX-5B width (D=3072, 48 heads), 2
+    transformer blocks, 13f x 64 x 64 paired latents (S = 13 538 tokens), LoRA r=8, fp32: the FULL pair-step
+    (4 forwards + backward to the LoRA parameters), 1 untimed warm-up + up to 3 timed steps (median), stopping early
+    once `budget_s` of timed work is spent.  The headline-config figure is that time scaled by the algorithmic-FLOP
+    ratio of the two configs (flagged extrapolated)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cfg1_common as c1
     from oracle import cogvideox as ocv
-    torch.set_num_threads(os.cpu_count() or 1)
-    cfg = ocv.CogVideoXConfig(num_layers=1)
-    D, Sv, Lt = cfg.inner_dim, 4096, TEXT_LEN
-    sd = ocv.init_state_dict(cfg, seed=0)
-    g = torch.Generator().manual_seed(0)
-    hid = torch.randn(1, Sv, D, generator=g)
-    enc = torch.randn(1, Lt, D, generator=g)
-    temb = torch.randn(1, cfg.time_embed_dim, generator=g)
-    S = Sv + Lt
-    f_block = 24.0 * S * D * D + 4.0 * S * S * D
-    with torch.no_grad():
-        t0 = time.time()
-        ocv.block_forward(sd, cfg, 0, hid, enc, temb)
-        dt = time.time() - t0
-    est_step_s = dt * (F_step / f_block)
-    return {"value": 1.0 / est_step_s, "unit": "pair-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 forward of 1 CogVideoX-5B block at S={S} tokens took {dt:.2f} s ({f_block / dt / 1e9:.0f} GFLOP/s); "
-                      f"extrapolated to the {F_step:.3g}-FLOP pair-step by algorithmic-FLOP ratio"}
+    from oracle import scheduler as osch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = c1.config()
+    sd = {k: v.float() for k, v in c1.base_state_dict(cfg).items()}
+    lora0, r = c1.lora_state_dict(cfg, "r8")
+    x_win, x_lose, prompt, t, noise = (v.float() if v.is_floating_point() else v for v in c1.inputs())
+    abar = osch.alphas_cumprod()
+
+    def step():
+        lora = {k: v.clone().requires_grad_(True) for k, v in lora0.items()}
+        t0 = time.perf_counter()
+        out = ocv.dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt, t, noise, beta=1.0)
+        out["loss"].backward()
+        return time.perf_counter() - t0, float(out["loss"])
+
+    step()                                           # warm-up (thread pools, allocator)
+    times, loss = [], None
+    while len(times) < 3 and (not times or sum(times) < budget_s):
+        dt, loss = step()
+        times.append(dt)
+    med = statistics.median(times)
+    S1 = c1.TEXT_LEN + c1.FRAMES * (c1.HEIGHT // 2) * (c1.WIDTH // 2)
+    F1 = flops_per_pair_step(S1, cfg.inner_dim, cfg.num_layers, r)
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        model = "unknown"
+    return {"value": 1.0 / med, "unit": "pair-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 full pair-step (4 fwd + bwd) of BASELINE configs[0] (2 blocks, D=3072, S={S1}, r={r}): "
+                      f"{len(times)} timed steps after 1 warm-up, median {med:.2f} s (loss {loss:.6f}); {F1 / med / 1e9:.0f} GFLOP/s on {model}",
+            "config": "BASELINE configs[0]", "step_seconds": times, "cpu_model": model,
+            "headline_extrapolated": {"value": 1.0 / (med * F_step / F1), "unit": "pair-steps/s",
+                                      "note": f"configs[0] time x algorithmic-FLOP ratio {F_step / F1:.1f} (extrapolated, not measured)"}}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to run fewer ranks than asked")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = env.get("MASTER_PORT", "29511")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -84,19 +135,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is NOT the headline config")
-    ap.add_argument("--frames", type=int, default=13)
-    ap.add_argument("--height", type=int, default=60)
-    ap.add_argument("--width", type=int, default=90)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json configuration (cfg2 = the headline)")
+    ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is NOT a BASELINE config")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--rank-r", type=int, default=64)
-    ap.add_argument("--checkpoint", action="store_true", help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
+    ap.add_argument("--checkpoint", action="store_true", default=None, help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     force_dist = os.environ.get("VGPA_FORCE_DIST") == "1"       # exercise the RCCL path on a single GPU (debug)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -106,16 +164,22 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1 or force_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if rank == 0:
+            print(f"bench.py: RCCL process group up, {dist.get_world_size()} ranks", file=sys.stderr, flush=True)
 
-    from videogpa_amd import ops
+    from videogpa_amd import ops, transformer as vtr
     from videogpa_amd.trainer import CogVideoXDPOTrainer, DPOEngine
-    from videogpa_amd.transformer import COGVIDEOX_5B
 
-    cfg_kw = dict(COGVIDEOX_5B, num_layers=args.layers)
+    C = CONFIGS[args.config]
+    F_ = C["frames"] if args.frames is None else args.frames
+    H_ = C["height"] if args.height is None else args.height
+    W_ = C["width"] if args.width is None else args.width
+    ckpt = C["checkpoint"] if args.checkpoint is None else args.checkpoint
+    cfg_kw = dict(getattr(vtr, C["model"]), num_layers=args.layers)
     torch.manual_seed(0)                           # identical adapter init (PEFT kaiming-uniform A) on every rank
     model = build_model(cfg_kw, dev, seed=0)       # identical base weights on every rank
     trainer = CogVideoXDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2 * args.rank_r, "beta": 1.0, "accumulate_grad_batches": 1,
-                                   "enable_gradient_checkpointing": args.checkpoint}, transformer=model)
+                                   "enable_gradient_checkpointing": ckpt, "seed": 1234}, transformer=model)
     # LoRA B ~ N(0, 1e-3) so the step is beyond the trivial B=0 point
     gB = torch.Generator(device=dev).manual_seed(1)
     with torch.no_grad():
@@ -125,14 +189,17 @@ def main():
     trainer.train()
     engine = DPOEngine(trainer)
 
-    # synthetic preference pair, resident in HBM (seed 1234 + rank)
+    # synthetic preference pair, resident in HBM (seed 1234 + rank): every rank has its own pair and its own (t, eps) stream
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    F_, H_, W_ = args.frames, args.height, args.width
     x_pair = (0.7 * torch.randn(1, 2, F_, 16, H_, W_, generator=g, device=dev)).to(torch.bfloat16)
     prompt = (0.2 * torch.randn(1, TEXT_LEN, 4096, generator=g, device=dev)).to(torch.bfloat16)
     batch = {"x_pair": x_pair, "prompt_emb": prompt}
+    if C["cond"]:
+        batch["image_latent"] = (0.7 * torch.randn(1, 1, 16, H_, W_, generator=g, device=dev)).to(torch.bfloat16)
 
-    S = TEXT_LEN + F_ * (H_ // 2) * (W_ // 2)
+    pt = cfg_kw.get("patch_size_t") or 1
+    Fe, He, We = (F_ - F_ % 2, H_ - H_ % 2, W_ - W_ % 2) if pt > 1 else (F_, H_, W_)     # the 1.5 step even-crops
+    S = TEXT_LEN + (Fe // pt) * (He // 2) * (We // 2)
     D = cfg_kw["num_attention_heads"] * 64
     F_step = flops_per_pair_step(S, D, args.layers, args.rank_r)
 
@@ -158,20 +225,20 @@ def main():
     dt = float(tt.item())
 
     if rank == 0:
-        headline = (args.layers, args.frames, args.height, args.width, args.rank_r, args.checkpoint) == (42, 13, 60, 90, 64, False)
+        named = (args.layers, F_, H_, W_, args.rank_r, ckpt) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"])
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
+        sync = logs["sync"].tolist()
         out = {
             "metric": "DPO preference-pair steps/sec, CogVideoX-5B 49f@480x720", "value": value, "unit": "pair-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720 -> "
-                                    if headline else "NOT the headline config (debug flags): CogVideoX-5B-shaped transformer, ")
+            "config": {"workload": (C["label"] + " -> " if named else "NOT a BASELINE config (debug flags): CogVideoX-5B-shaped transformer, ")
                                    + f"paired latents [1,2,{F_},16,{H_},{W_}], S={S} tokens, {args.layers} blocks, LoRA r={args.rank_r} on "
                                    "to_q/to_k/to_v/to_out.0, 1 pair/GPU/step, optimizer step every step; random-init weights"
-                                   + ("; per-block activation recompute" if args.checkpoint else ""),
-                       "layers": args.layers, "tokens": S, "pairs_per_gpu": 1, "parallelism": f"dp{world}"},
-            "loss": float(logs["train/loss"]),
+                                   + ("; per-block activation recompute" if ckpt else ""),
+                       "name": args.config, "layers": args.layers, "tokens": S, "pairs_per_gpu": 1, "parallelism": f"dp{world}"},
+            "loss": float(logs["train/loss"]), "loss_rank_mean": sync[0],
             "step_flops_algorithmic": F_step,
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
@@ -181,13 +248,32 @@ def main():
             ops.TIMER = None
             kernels = {}
             for name, s in summ.items():
-                tf = s["work_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
-                kernels[name] = {"launches": s["launches"], "avg_ms": s["avg_ms"], "total_ms_per_step": s["total_ms"] / args.steps,
-                                 "algorithmic_flops_per_launch": s["work_per_launch"], "achieved_tflops": tf}
+                rate = s["work_per_launch"] / (s["avg_ms"] * 1e-3)
+                k = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "total_ms_per_step": s["total_ms"] / args.steps}
+                if s["unit"] == "flop":
+                    k.update(bound="mfma", algorithmic_flops_per_launch=s["work_per_launch"], achieved_tflops=rate / 1e12,
+                             frac=rate / 1e12 / PEAK_BF16_DENSE_TFLOPS)
+                else:
+                    k.update(bound="hbm", algorithmic_bytes_per_launch=s["work_per_launch"], achieved_gbs=rate / 1e9,
+                             frac=rate / 1e9 / PEAK_HBM_GBS)
+                kernels[name] = k
+            # dominant kernel = largest share of the step among the hand-written kernels timed live (the hipBLASLt
+            # projections are the vendor's; their share is reported from rocprofv3 in profiles/)
             dom = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS,
-                               "unit": "TFLOP/s", "frac": kernels[dom]["achieved_tflops"] / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
-                               "avg_launch_ms": kernels[dom]["avg_ms"]}
+            kd = kernels[dom]
+            # traffic: HBM bytes per launch from the PMC pass of the same command (profiles/, collected per the guide's
+            # recipe: separate --pmc runs, FETCH_SIZE/WRITE_SIZE with the gfx950 corrections), when a summary is present
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+            if kd["bound"] == "mfma":
+                out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["achieved_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"]}
+            else:
+                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_gbs"], "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"]}
             out["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_step)

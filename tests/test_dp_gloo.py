@@ -54,10 +54,85 @@ def _worker(rank, world, port, out_dir):
         (_pair_loss(params, data[i:i + 1]).sum() / 2).backward()
     work = opt.all_reduce_grads()
     work.wait()
-    g = flat.grad / world
+    g = flat.grad.clone() / world
     torch.save({"grad": g.clone(), "idx": idx[:2], "views_ok": all(p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o for p, o in zip(params, flat.offsets))},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
+
+
+class _CpuStepAdamW(FlatAdamW):
+    """TEST-ONLY: the product optimizer runs its update as HIP kernels and refuses CPU tensors; to exercise the
+    data-parallel protocol (all-reduce of [grad | scalar tail], 1/world folded into the step, LR schedule, zero_grad)
+    under gloo on CPU, the update itself is restated here with torch ops (clip_grad_norm_ + AdamW semantics)."""
+
+    def _apply_update(self, lr, scale):
+        f = self.flat
+        g = f.grad * scale
+        if self.max_grad_norm and self.max_grad_norm > 0:
+            norm = g.norm()
+            self.total_norm.copy_(norm.reshape(1))
+            g = g * torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0)
+        b1, b2 = self.betas
+        f.flat.mul_(1 - lr * self.wd)
+        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        k = self.step_count
+        denom = (self.exp_avg_sq / (1 - b2 ** k)).sqrt_().add_(self.eps)
+        f.flat.addcdiv_(self.exp_avg / (1 - b1 ** k), denom, value=-lr)
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = _make_params(seed=rank)
+    flat = FlatParams(params)
+    dist.broadcast(flat.flat, src=0)
+    opt = _CpuStepAdamW(flat, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=1, total_steps=10)
+    data = _data(8)
+    synced = []
+    for step in range(3):                                      # three optimizer steps, one pair per rank per step
+        opt.zero_grad()
+        i = step * world + rank
+        loss = _pair_loss(params, data[i:i + 1]).sum()
+        loss.backward()
+        flat.tail[:3].add_(torch.stack([loss.detach(), loss.detach() * 2, (loss.detach() > 0).float()]))
+        flat.tail[3:4].add_(1.0)
+        opt.step(opt.all_reduce_grads())
+        synced.append((flat.tail[:3] / flat.tail[3:4]).clone())
+    torch.save({"param": flat.flat.clone(), "synced": torch.stack(synced)}, os.path.join(out_dir, f"train{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_three_optimizer_steps_match_single_process(tmp_path):
+    """Ranks step together: final parameters equal (bit-identical across ranks) and equal, to 1e-6, to ONE process running
+    torch.optim.AdamW + clip_grad_norm_ on the mean loss of the concatenated per-step batches; the logged scalars that
+    rode the all-reduce equal the mean over ranks."""
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"train{i}.pt") for i in range(world)]
+    assert torch.equal(r[0]["param"], r[1]["param"])
+    assert torch.equal(r[0]["synced"], r[1]["synced"])
+    params = _make_params(0)
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.01)
+    from videogpa_amd.optim import cosine_schedule_with_warmup
+    data = _data(8)
+    ref_losses = []
+    for step in range(3):
+        for gq in opt.param_groups:
+            gq["lr"] = 1e-2 * cosine_schedule_with_warmup(step, 1, 10)
+        opt.zero_grad()
+        losses = _pair_loss(params, data[step * world:(step + 1) * world])
+        losses.mean().backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        ref_losses.append(losses.mean().item())
+    flat = FlatParams(_make_params(0))
+    got = r[0]["param"]
+    for p, o in zip(params, flat.offsets):
+        assert torch.allclose(got[o:o + p.numel()].view_as(p), p.detach(), rtol=0, atol=1e-6)
+    assert torch.allclose(r[0]["synced"][:, 0], torch.tensor(ref_losses), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(r[0]["synced"][:, 1], 2 * torch.tensor(ref_losses), rtol=1e-5, atol=1e-6)
 
 
 def test_flat_allreduce_matches_single_process(tmp_path):

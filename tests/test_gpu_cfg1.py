@@ -1,0 +1,118 @@
+"""Full-width parity at BASELINE.json configs[0] geometry: D = 3072, 48 heads, 2 transformer blocks, 13f x 64 x 64 paired
+latents (S = 13 538 tokens), LoRA r = 8 (and r = 64: the rp = 64 / 192 kernels of the headline config).  The HIP
+pair-step (train/CogVideoX-5B/03_train.py:116-157 through CogVideoXDPOTrainer._shared_step, every kernel through the
+C-ABI) runs on the seeded inputs of tests/cfg1_common.py and is compared with the fp32 CPU-oracle results committed as
+tests/golden/cfg1_<variant>.pt (made by tests/golden/make_cfg1_golden.py in the build container).
+
+Tolerances (the HIP path computes in bf16, the oracle in fp32 on the same bf16-rounded weights / inputs):
+  loss                  |d| <= 1e-3 (north_star) -- measured ~1e-6
+  reward_margin, rewards|d| <= 2e-4 + 1 % relative
+  v_pred samples        |d| <= 3 % of the prediction range (bf16 activations through 2 blocks)
+  LoRA grads, per tensor: norm within 5 %, sampled entries within 5 % of the tensor's max |grad| (+ cosine >= 0.99)
+"""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cfg1_common as c1
+from oracle import cogvideox as ocv
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _hip_step(variant):
+    from videogpa_amd.lora import LoraConfig, get_peft_model
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    from videogpa_amd.transformer import COGVIDEOX_5B, CogVideoXTransformer3DModel
+    cfg = c1.config()
+    sd = c1.base_state_dict(cfg)
+    model = CogVideoXTransformer3DModel(**dict(COGVIDEOX_5B, num_layers=cfg.num_layers, sample_height=c1.HEIGHT, sample_width=c1.WIDTH))
+    model.load_state_dict(sd, strict=True)
+    del sd
+    model = model.to(device="cuda", dtype=torch.bfloat16)
+    lora, r = c1.lora_state_dict(cfg, variant)
+    pm = get_peft_model(model, LoraConfig(r=r, lora_alpha=2 * r, target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    own = pm.state_dict()
+    for k, v in lora.items():
+        own[k[:-len(".weight")] + ".default.weight"].copy_(v)
+    tr = CogVideoXDPOTrainer({"beta": 1.0}, transformer=pm)
+    tr.train()
+    x_win, x_lose, prompt, t, noise = c1.inputs()
+    captured = {}
+    orig = tr.transformer.forward
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        captured.setdefault("preds", []).append(out.sample.detach())
+        return out
+    tr.transformer.forward = spy
+    out = tr._shared_step({"x_win": x_win.cuda(), "x_lose": x_lose.cuda(), "prompt_emb": prompt.cuda()},
+                          timesteps=t.cuda(), noise=noise.cuda())
+    tr.transformer.forward = orig
+    out.loss.backward()
+    torch.cuda.synchronize()
+    v_ref, v_pol = captured["preds"]            # reference pass first (adapter off), then the policy pass; batch = (win, lose)
+    grads = {}
+    named = dict(pm.named_parameters())
+    for k in lora:
+        grads[k] = named[k[:-len(".weight")] + ".default.weight"].grad.detach().float().cpu()
+    return out, {"v_win": v_pol[0:1], "v_lose": v_pol[1:2], "v_win_ref": v_ref[0:1], "v_lose_ref": v_ref[1:2]}, grads
+
+
+@pytest.mark.parametrize("variant", ["r8", "r64"])
+def test_cfg1_pair_step_matches_oracle_golden(variant):
+    gold = torch.load(os.path.join(HERE, "golden", f"cfg1_{variant}.pt"), weights_only=False)
+    out, preds, grads = _hip_step(variant)
+    report = {"variant": variant, "loss_hip": out.loss.item(), "loss_oracle": float(gold["loss"])}
+
+    assert abs(out.loss.item() - float(gold["loss"])) < 1e-3, report
+    for name, got in (("reward_margin", out.reward_margin), ("winner_reward", out.winner_reward), ("loser_reward", out.loser_reward)):
+        ref = float(gold[name])
+        report[name] = (got.item(), ref)
+        assert abs(got.item() - ref) < 2e-4 + 0.01 * abs(ref), (name, got.item(), ref)
+
+    for k, v in preds.items():
+        v = v.float().cpu()
+        ref = gold[k + "_samples"].float()
+        idx = c1.sample_index(v.numel(), k)
+        got = v.flatten()[idx]
+        rng_ = ref.abs().max().item()
+        err = (got - ref).abs().max().item()
+        report[k + "_err_over_range"] = err / rng_
+        report[k + "_norm_rel"] = abs(v.double().norm().item() / float(gold[k + "_norm"]) - 1)
+        assert err < 0.03 * rng_, (k, err, rng_)
+        assert report[k + "_norm_rel"] < 0.01, (k, report[k + "_norm_rel"])
+
+    worst = {"norm_rel": 0.0, "sample_err_over_max": 0.0, "cos_min": 1.0}
+    assert set(grads) == set(gold["lora_grads"])
+    for k, g in grads.items():
+        ref = gold["lora_grads"][k]
+        idx = c1.sample_index(g.numel(), k)
+        got = g.flatten()[idx].double()
+        rs = ref["samples"].double()
+        amax = float(ref["absmax"])
+        nrel = abs(g.double().norm().item() / float(ref["norm"]) - 1)
+        serr = (got - rs).abs().max().item() / amax
+        cos = float((got * rs).sum() / (got.norm() * rs.norm()).clamp_min(1e-300))
+        worst["norm_rel"] = max(worst["norm_rel"], nrel)
+        worst["sample_err_over_max"] = max(worst["sample_err_over_max"], serr)
+        worst["cos_min"] = min(worst["cos_min"], cos)
+        assert math.isfinite(nrel) and nrel < 0.05, (k, nrel)
+        assert serr < 0.05, (k, serr)
+        assert cos > 0.99, (k, cos)
+    report["lora_grads_worst"] = worst
+    os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"cfg1_parity_{variant}.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print(json.dumps(report))

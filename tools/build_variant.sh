@@ -1,6 +1,8 @@
 #!/bin/bash
 # Build a variant libvgpa_hip.so with extra -D flags on attention.hip (for A/B runs inside ONE gpurun session):
-#   tools/build_variant.sh NAME [-DFOO ...]   ->  var/lib_NAME.so   (swap in with: cp var/lib_NAME.so videogpa_amd/csrc/libvgpa_hip.so)
+#   tools/build_variant.sh NAME [-DFOO ...]   ->  var/lib_NAME.so   (select with: VGPA_LIB=$PWD/var/lib_NAME.so python tools/attn_bench.py;
+#   the product library videogpa_amd/csrc/libvgpa_hip.so is never overwritten.  var/ is git-ignored; it travels to the GPU box
+#   only when .gpurunignore's `var/` line is commented out for an A/B session)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift

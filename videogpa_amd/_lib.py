@@ -11,7 +11,9 @@ import torch  # noqa: F401
 from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvgpa_hip.so")
+# VGPA_LIB=<path> selects another build of the SAME C-ABI (tools/build_variant.sh writes var/lib_NAME.so) for in-session A/B
+# measurements, so nothing ever has to be copied over the product library.
+LIB_PATH = os.environ.get("VGPA_LIB") or os.path.join(_HERE, "csrc", "libvgpa_hip.so")
 
 P, I64, I32, F32, SZ = c_void_p, c_int64, c_int32, c_float, c_size_t
 

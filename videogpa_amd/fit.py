@@ -14,7 +14,51 @@ from .loader import PairedPrefetcher
 from .trainer import DEFAULT_CONFIG, CogVideoXDPOTrainer, DPOEngine
 
 
-def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] = None, log=print) -> CogVideoXDPOTrainer:
+def save_checkpoint(engine: DPOEngine, path: str, val: Optional[Dict[str, float]] = None) -> None:
+    """Adapter (PEFT format) + optimizer state (flat Adam moments, step count) + trainer step: enough to resume.  The
+    reference's ModelCheckpoint pickles the whole LightningModule incl. the two frozen 5B copies (SURVEY B-13); the
+    frozen base is not state, so it is not written here."""
+    os.makedirs(path, exist_ok=True)
+    engine.trainer.transformer.save_pretrained(path)
+    sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in engine.opt.state_dict().items()}
+    sd.update(global_step=engine.trainer.global_step, micro=engine.micro, val=val)
+    tmp = os.path.join(path, "optimizer.pt.tmp")
+    torch.save(sd, tmp)
+    os.replace(tmp, os.path.join(path, "optimizer.pt"))
+
+
+def load_checkpoint(engine: DPOEngine, path: str) -> None:
+    sd = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
+    dev = engine.opt.flat.flat.device
+    engine.opt.load_state_dict({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()
+                                if k in ("exp_avg", "exp_avg_sq", "param", "step_count")})
+    engine.trainer.global_step = int(sd["global_step"])
+    engine.micro = int(sd["micro"])
+
+
+@torch.no_grad()
+def validate(trainer, dataset, val_idx, cfg, rank=0, world=1) -> Dict[str, float]:
+    """validation_step over the 2 % split (train/CogVideoX-5B/03_train.py:190-206), mean over pairs and ranks."""
+    local = val_idx[rank::world]
+    acc = torch.zeros(4, dtype=torch.float64, device="cuda")
+    if local:
+        loader = DataLoader(Subset(dataset, local), batch_size=cfg["batch_size"], shuffle=False, num_workers=0, collate_fn=collate_paired)
+        was = trainer.training
+        trainer.eval()
+        for batch in PairedPrefetcher(loader):
+            out = trainer.validation_step(batch)
+            b = batch["x_pair"].shape[0]
+            acc += torch.stack([out["val/loss"].double() * b, out["val/reward_margin"].double() * b,
+                                out["val/reward_accuracy"].double() * b, torch.tensor(float(b), dtype=torch.float64, device="cuda")])
+        trainer.train(was)
+    if dist.is_initialized() and world > 1:
+        dist.all_reduce(acc)
+    a = acc.tolist()
+    n = max(a[3], 1.0)
+    return {"val/loss": a[0] / n, "val/reward_margin": a[1] / n, "val/reward_accuracy": a[2] / n}
+
+
+def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] = None, log=print, image_encoder=None) -> CogVideoXDPOTrainer:
     cfg = dict(DEFAULT_CONFIG)
     cfg.update(config)
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -25,14 +69,21 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
     n = len(dataset)
     g = torch.Generator().manual_seed(42)
     perm = torch.randperm(n, generator=g).tolist()
+    if n == 0:
+        raise ValueError("DPODataset produced no preference pairs (check metric / min_gap / motion_threshold): nothing to train on")
     n_train = int(0.98 * n) if n > 1 else n
     train_idx = perm[:n_train] or perm
-    trainer = CogVideoXDPOTrainer(cfg, transformer=transformer).cuda()
+    val_idx = perm[n_train:]
+    trainer = CogVideoXDPOTrainer(cfg, transformer=transformer, image_encoder=image_encoder).cuda()
     trainer.train()
     engine = DPOEngine(trainer)
+    if cfg.get("resume_from"):
+        load_checkpoint(engine, cfg["resume_from"])
     step_target = cfg["max_steps"]
+    every = int(cfg.get("checkpoint_every_n_steps", 1000))          # ModelCheckpoint(every_n_train_steps=1000), 03_train.py:268-275
     epoch = 0
     t0 = time.time()
+    last_ckpt = trainer.global_step
     while trainer.global_step < step_target:
         local = [train_idx[i] for i in shard_indices(len(train_idx), rank, world, epoch=epoch)]
         loader = DataLoader(Subset(dataset, local), batch_size=cfg["batch_size"], shuffle=False, num_workers=cfg.get("num_workers", 4),
@@ -41,8 +92,17 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
             logs = engine.micro_step(batch)
             if rank == 0 and "lr" in logs and trainer.global_step % cfg.get("log_every_n_steps", 10) == 0:
                 sps = trainer.global_step * world * cfg["batch_size"] * cfg["accumulate_grad_batches"] / max(1e-9, time.time() - t0)
-                log(f"step {trainer.global_step}: loss {float(logs['train/loss']):.6f} margin {float(logs['train/reward_margin']):.3e} "
+                sync = logs["sync"].tolist()          # rank-mean of the step's scalars (rode the gradient all-reduce)
+                log(f"step {trainer.global_step}: loss {sync[0]:.6f} margin {sync[1]:.3e} acc {sync[2]:.2f} "
                     f"lr {logs['lr']:.3e} samples/s {sps:.3f} max_mem {torch.cuda.max_memory_reserved() / 2 ** 30:.1f} GB")
+            if "lr" in logs and every > 0 and trainer.global_step % every == 0 and trainer.global_step != last_ckpt:
+                last_ckpt = trainer.global_step
+                val = validate(trainer, dataset, val_idx, cfg, rank, world) if val_idx else None
+                if rank == 0:
+                    if val is not None:
+                        log(f"step {trainer.global_step}: " + " ".join(f"{k} {v:.6f}" for k, v in val.items()))
+                    if cfg.get("output_dir"):
+                        save_checkpoint(engine, os.path.join(cfg["output_dir"], "checkpoints", f"step={trainer.global_step}"), val)
             if trainer.global_step >= step_target:
                 break
         epoch += 1

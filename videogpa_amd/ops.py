@@ -35,29 +35,33 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def run(self, name, work, fn):
+    def run(self, name, work, fn, unit="flop"):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
-        self.records.setdefault(name, []).append((a, b, work))
+        self.records.setdefault(name, []).append((a, b, work, unit))
 
     def summary(self):
         out = {}
         for name, recs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "work_per_launch": recs[0][2]}
+            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            work = sum(r[2] for r in recs) / len(recs)      # launches of one kernel can differ in size (q,k,v vs out LoRA)
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "work_per_launch": work,
+                         "unit": recs[0][3]}
         return out
 
 
 TIMER = None   # set to a KernelTimer() to time launches
 
 
-def _timed(name, work, fn):
+def _timed(name, work, fn, unit="flop"):
+    """work = algorithmic FLOPs (unit "flop", MFMA-bound kernels) or algorithmic HBM bytes = unique reads + writes
+    (unit "byte", HBM-bound kernels) of the launch -- DESIGN.md section 4."""
     if TIMER is None:
         fn()
     else:
-        TIMER.run(name, work, fn)
+        TIMER.run(name, work, fn, unit)
 
 
 # --------------------------------------------------------------------------------------------- DPO loss
@@ -277,8 +281,9 @@ class _ResidualLNFn(torch.autograd.Function):
             gv, gt, gstride = gates[:, 0], gates[:, 1], gates.stride(0)
         else:
             x_new, gv, gt, gstride = None, None, None, 0
-        _lib.call("vgpa_residual_ln_fwd", x, y, gv, gt, gstride, ln_w, ln_b, sv, s1v, st, s1t, mstride, B, S, D, text_len, float(eps),
-                  x_new, n, mean, rstd, _stream())
+        _timed("residual_ln_fwd" if y is not None else "ln_modulate_fwd", (8.0 if y is not None else 4.0) * B * S * D,
+               lambda: _lib.call("vgpa_residual_ln_fwd", x, y, gv, gt, gstride, ln_w, ln_b, sv, s1v, st, s1t, mstride, B, S, D, text_len,
+                                 float(eps), x_new, n, mean, rstd, _stream()), "byte")
         xs = x if y is None else x_new
         ctx.save_for_backward(xs, mean, rstd, ln_w, mod, gates if y is not None else None)
         ctx.text_len = text_len
@@ -300,8 +305,10 @@ class _ResidualLNFn(torch.autograd.Function):
             gv, gt, gstride = gates[:, 0], gates[:, 1], gates.stride(0)
         else:
             dy, gv, gt, gstride = None, None, None, 0
-        _lib.call("vgpa_residual_ln_bwd", dn, xs, mean, rstd, ln_w, s1v, s1t, mstride, gv, gt, gstride, dres, B, S, D, ctx.text_len, dx, dy,
-                  _stream())
+        passes = 3 + (1 if dres is not None else 0) + (1 if ctx.has_y else 0)     # dn, x, dx (+ dres) (+ dy)
+        _timed("residual_ln_bwd" if ctx.has_y else "ln_modulate_bwd", 2.0 * passes * B * S * D,
+               lambda: _lib.call("vgpa_residual_ln_bwd", dn, xs, mean, rstd, ln_w, s1v, s1t, mstride, gv, gt, gstride, dres, B, S, D,
+                                 ctx.text_len, dx, dy, _stream()), "byte")
         return dx, dy, None, None, None, None, None, None
 
 
@@ -341,7 +348,7 @@ class _GeluTanhFn(torch.autograd.Function):
     def forward(ctx, u):
         _req(u, torch.bfloat16)
         out = torch.empty_like(u)
-        _lib.call("vgpa_gelu_tanh_fwd", u, u.numel(), out, _stream())
+        _timed("gelu_tanh_fwd", 4.0 * u.numel(), lambda: _lib.call("vgpa_gelu_tanh_fwd", u, u.numel(), out, _stream()), "byte")
         ctx.save_for_backward(u)
         return out
 
@@ -350,7 +357,7 @@ class _GeluTanhFn(torch.autograd.Function):
         (u,) = ctx.saved_tensors
         dy = dy.contiguous()
         du = torch.empty_like(u)
-        _lib.call("vgpa_gelu_tanh_bwd", u, dy, u.numel(), du, _stream())
+        _timed("gelu_tanh_bwd", 6.0 * u.numel(), lambda: _lib.call("vgpa_gelu_tanh_bwd", u, dy, u.numel(), du, _stream()), "byte")
         return du
 
 
@@ -371,15 +378,17 @@ def lora_down(x2, a_cat, out=None):
     M, K = x2.shape
     R = a_cat.shape[0]
     t = torch.empty(M, R, dtype=torch.bfloat16, device=x2.device) if out is None else out
-    _timed("lora_down_kernel", 2.0 * M * K, lambda: _lib.call("vgpa_lora_down", x2, x2.stride(0), a_cat, t, t.stride(0), M, K, R, _stream()))
+    _timed("lora_down_kernel", 2.0 * M * (K + R), lambda: _lib.call("vgpa_lora_down", x2, x2.stride(0), a_cat, t, t.stride(0), M, K, R, _stream()),
+           "byte")
     return t
 
 
 def lora_up_add(y2, t, bw, s, accumulate=True):
     """y2[M,N] (+)= s * t[M,rp] @ bw[N,rp]^T in place (y2 / t may be column slices)."""
     M, N = y2.shape
-    _timed("lora_up_add_kernel", 4.0 * M * N, lambda: _lib.call("vgpa_lora_up_add", y2, y2.stride(0), t, t.stride(0), bw, bw.stride(0), float(s),
-                                                                  M, N, t.shape[1], 1 if accumulate else 0, _stream()))
+    _timed("lora_up_add_kernel", (4.0 if accumulate else 2.0) * M * N + 2.0 * M * t.shape[1],
+           lambda: _lib.call("vgpa_lora_up_add", y2, y2.stride(0), t, t.stride(0), bw, bw.stride(0), float(s), M, N, t.shape[1],
+                             1 if accumulate else 0, _stream()), "byte")
 
 
 def lora_grad(u, v, s=1.0):
@@ -387,7 +396,8 @@ def lora_grad(u, v, s=1.0):
     M, P = u.shape
     Q = v.shape[1]
     g = torch.zeros(P, Q, dtype=torch.float32, device=u.device)
-    _timed("lora_grad_kernel", 2.0 * M * (P + Q), lambda: _lib.call("vgpa_lora_grad", u, u.stride(0), v, v.stride(0), g, Q, float(s), M, P, Q, _stream()))
+    _timed("lora_grad_kernel", 2.0 * M * (P + Q), lambda: _lib.call("vgpa_lora_grad", u, u.stride(0), v, v.stride(0), g, Q, float(s), M, P, Q, _stream()),
+           "byte")
     return g
 
 
@@ -568,7 +578,8 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
         q = prescale_q(q, scale)
     delta = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     st = _stream()
-    _lib.call("vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st)
+    _timed("attn_delta_kernel", 4.0 * B * H * S * Dh, lambda: _lib.call(
+        "vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st), "byte")
     if ATTN_BWD_FUSED:
         dq32 = torch.zeros(B, H, S, Dh, dtype=torch.float32, device=q.device)
         _timed("attn_bwd_fused_kernel", 8.0 * S * S * Dh * B * H, lambda: _lib.call(
@@ -601,8 +612,9 @@ class _QKNormAttentionFn(torch.autograd.Function):
         q_in, k_in, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,S,Dh] views
         qn = torch.empty(B, H, S, Dh, dtype=torch.bfloat16, device=qkv.device)
         kn = torch.empty_like(qn)
-        _lib.call("vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
-                  wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), _stream())
+        _timed("qknorm_rope_fwd", 8.0 * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
+            wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), _stream()), "byte")
         o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True)
         ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
         ctx.meta = (text_len, H, eps)
@@ -625,9 +637,10 @@ class _QKNormAttentionFn(torch.autograd.Function):
         ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
         dov = do.view(B, S, H, Dh).permute(0, 2, 1, 3)
         attention_bwd_raw(qn, kn, v, ov, dov, lse, dqn, dkn, dv, q_prescaled=True)
-        _lib.call("vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
-                  _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
-                  float(eps), _stream())
+        _timed("qknorm_rope_bwd", 12.0 * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
+            _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
+            float(eps), _stream()), "byte")
         return dqkv, None, None, None, None, None, None, None, None, None
 
 

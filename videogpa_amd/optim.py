@@ -26,6 +26,8 @@ def cosine_schedule_with_warmup(step, warmup_steps, total_steps, num_cycles=0.5)
 class FlatParams:
     """Re-homes `params` (fp32, requires_grad) into one flat buffer; .grad of each is a view of one flat grad."""
 
+    TAIL = 4   # (loss, reward_margin, reward_accuracy, micro-step count) summed over ranks by the gradient all-reduce
+
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
@@ -40,14 +42,18 @@ class FlatParams:
             n += (p.numel() + 3) // 4 * 4
         self.numel = n
         self.flat = torch.zeros(n, dtype=dt, device=dev)
-        self.grad = torch.zeros(n, dtype=dt, device=dev)
+        # gradient exchange buffer = [flat gradient | TAIL logged scalars]: the scalars the reference reduces with
+        # `self.log(..., sync_dist=True)` (train/CogVideoX-5B/03_train.py:164-173) ride the ONE all-reduce of the step
+        self.buf = torch.zeros(n + self.TAIL, dtype=dt, device=dev)
+        self.grad = self.buf[:n]
+        self.tail = self.buf[n:]
         for p, o in zip(self.params, self.offsets):
             self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + p.numel()].view_as(p)
             p.grad = self.grad[o:o + p.numel()].view_as(p)
 
     def zero_grad(self):
-        self.grad.zero_()
+        self.buf.zero_()
         for p, o in zip(self.params, self.offsets):   # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
@@ -83,7 +89,7 @@ class FlatAdamW:
         """SUM all-reduce of the flat gradient on a side stream; the 1/world mean is folded into the step."""
         if self.world() == 1 and os.environ.get("VGPA_FORCE_DIST") != "1":
             return None
-        g = self.flat.grad
+        g = self.flat.buf          # gradient + logged-scalar tail in one message
         if g.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
@@ -101,15 +107,28 @@ class FlatAdamW:
         scale = 1.0 / self.world()
         lr = self.lr
         self.step_count += 1
-        f = self.flat
-        if f.flat.is_cuda:
-            if self.max_grad_norm and self.max_grad_norm > 0:
-                ops.grad_norm(f.grad, scale, out=self.total_norm)
-            ops.adamw_step(f.flat, f.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                           self.step_count, scale, self.max_grad_norm or 0.0, self.total_norm)
-        else:
-            raise RuntimeError("FlatAdamW.step needs the HIP kernels (GPU tensors); there is no CPU fallback")
+        self._apply_update(lr, scale)
         return lr
+
+    def _apply_update(self, lr, scale):
+        """global-norm clip + AdamW on the flat buffers (two HIP launches, clip coefficient stays on the device)."""
+        f = self.flat
+        if not f.flat.is_cuda:
+            raise RuntimeError("FlatAdamW.step needs the HIP kernels (GPU tensors); there is no CPU fallback")
+        if self.max_grad_norm and self.max_grad_norm > 0:
+            ops.grad_norm(f.grad, scale, out=self.total_norm)
+        ops.adamw_step(f.flat, f.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                       self.step_count, scale, self.max_grad_norm or 0.0, self.total_norm)
+
+    # ------------------------------------------------------------------ resume state (fit.py checkpoints)
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step_count": self.step_count, "param": self.flat.flat}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.flat.flat.copy_(sd["param"])
+        self.step_count = int(sd["step_count"])
 
     def zero_grad(self):
         self.flat.zero_grad()

@@ -13,6 +13,7 @@ MI355X-first differences (results are unchanged):
   * activations stay resident (no per-block recompute) -- 288 GB HBM;
   * data parallel = one flat-buffer RCCL all-reduce of the LoRA gradients per optimizer step.
 """
+import os
 import time
 from typing import Any, Dict, Optional
 
@@ -36,16 +37,27 @@ DEFAULT_CONFIG: Dict[str, Any] = {
     "enable_gradient_checkpointing": False,   # reference: True (80 GB GPUs); 288 GB keeps activations instead
     "metric_name": "consistency_score", "min_gap": 0.05, "motion_threshold": 1e-3,
     "log_every_n_steps": 10,
+    "seed": 0,                                # (t, eps) stream = seed + rank: every rank draws its own
 }
 
 
 class CogVideoXDPOTrainer(nn.Module):
-    def __init__(self, config: Dict[str, Any], transformer: Optional[nn.Module] = None, scheduler=None, separate_ref: bool = False):
+    def __init__(self, config: Dict[str, Any], transformer: Optional[nn.Module] = None, scheduler=None, separate_ref: bool = False,
+                 image_encoder=None):
+        """image_encoder: I2V only -- callable `[B,3,1,H,W] image in the dataset's value range -> [B,C_lat,1,h,w]` standing
+        for `vae.encode(...).latent_dist.sample() * vae.config.scaling_factor` (train/CogVideoX-I2V-5B/03_train.py:124-125);
+        the VAE itself is a third-party network outside this path."""
         super().__init__()
         cfg = dict(DEFAULT_CONFIG)
         cfg.update(config)
         self.config = cfg
+        self.image_encoder = image_encoder
+        local_model = isinstance(cfg.get("model_path"), str) and os.path.isdir(cfg["model_path"])
         if transformer is None:
+            if not local_model:
+                raise FileNotFoundError(
+                    f"model_path {cfg['model_path']!r} is not a local directory: there is no hub access on this path; pass a local "
+                    "diffusers checkpoint directory (transformer/ + scheduler/) or a constructed `transformer`")
             transformer = CogVideoXTransformer3DModel.from_pretrained(cfg["model_path"], subfolder="transformer", torch_dtype=torch.bfloat16)
         if isinstance(transformer, PeftModel):
             self.transformer = transformer
@@ -61,10 +73,28 @@ class CogVideoXDPOTrainer(nn.Module):
             ref = copy.deepcopy(self.transformer)
             ref.requires_grad_(False).eval()
             self.ref_transformer = ref
-        self.scheduler = scheduler if scheduler is not None else CogVideoXDPMScheduler()
+        if scheduler is None:
+            # the reference reads the checkpoint's own scheduler_config (:113); the 5B defaults only stand in when
+            # there is no checkpoint directory (synthetic weights)
+            sched_dir = os.path.join(cfg["model_path"], "scheduler") if local_model else None
+            if sched_dir and os.path.isfile(os.path.join(sched_dir, "scheduler_config.json")):
+                scheduler = CogVideoXDPMScheduler.from_pretrained(cfg["model_path"], subfolder="scheduler")
+            else:
+                scheduler = CogVideoXDPMScheduler()
+        self.scheduler = scheduler
         self.loss_fn = create_loss_strategy(strategy="dpo", beta=cfg["beta"])
         self.start_time = None
         self.global_step = 0
+        self._rng = None
+
+    def rng(self, device):
+        """Per-rank generator of the (t, eps) stream: seed + rank, so data-parallel ranks draw different noise
+        (Lightning seeds every rank's global generator differently through the DistributedSampler/rank offset)."""
+        if self._rng is None or self._rng.device != device:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._rng = torch.Generator(device=device).manual_seed(int(self.config.get("seed", 0)) + rank)
+        return self._rng
 
     # ------------------------------------------------------------------ forward pieces
     def _ref_forward(self, hs, prompt, tt):
@@ -81,9 +111,9 @@ class CogVideoXDPOTrainer(nn.Module):
         B = x_pair.shape[0]
         dev = x_pair.device
         if timesteps is None:
-            timesteps = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=dev)
+            timesteps = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=dev, generator=self.rng(dev))
         if noise is None:
-            noise = torch.randn(x_pair[:, 0].shape, dtype=x_pair.dtype, device=dev)
+            noise = torch.randn(x_pair[:, 0].shape, dtype=x_pair.dtype, device=dev, generator=self.rng(dev))
         xt_pair, vt_pair = self.scheduler.noise_velocity_paired(x_pair.contiguous(), noise.contiguous(), timesteps)
         hs = xt_pair if cond_pair is None else torch.cat([xt_pair, cond_pair], dim=3)
         hs = hs.reshape(2 * B, *hs.shape[2:])
@@ -94,8 +124,11 @@ class CogVideoXDPOTrainer(nn.Module):
         v_pol = v_pol.reshape(B, 2, *v_pol.shape[1:])
         v_ref = v_ref.reshape(B, 2, *v_ref.shape[1:])
         lf = self.loss_fn
+        # bf16 predictions: the reference (bf16-mixed autocast) forms pred - target in bf16 before the fp32 square
+        # (train/loss.py:73-77) -- same rule as the drop-in DPOLoss module (videogpa_amd/loss.py)
         loss, margin, wr, lr, acc, _ = ops.dpo_loss_paired(v_pol.contiguous(), v_ref.contiguous(), vt_pair, beta=lf.beta,
-                                                            label_smoothing=lf.label_smoothing, loss_type=lf.loss_type)
+                                                            label_smoothing=lf.label_smoothing, loss_type=lf.loss_type,
+                                                            round_diff=(v_pol.dtype == torch.bfloat16))
         return LossOutput(loss=loss, reward_margin=margin.detach(), winner_reward=wr.detach(), loser_reward=lr.detach(), accuracy=acc.detach())
 
     @staticmethod
@@ -108,20 +141,71 @@ class CogVideoXDPOTrainer(nn.Module):
         cond = torch.cat([image_latent, pad], dim=1)
         return torch.stack([cond, cond], dim=1)
 
-    def _shared_step(self, batch, timesteps=None, noise=None) -> LossOutput:
-        """Reference-shaped entry: batch['x_win'/'x_lose'] [B,C,F,H,W], batch['prompt_emb'] (:116-157); an optional
-        batch['image_latent'] [B,1,C,H,W] (or [B,C,1,H,W]) switches to the I2V form (32 input channels)."""
+    # ------------------------------------------------------------------ model-variant rules of the reference's three step functions
+    def _base_config(self):
+        m = self.transformer
+        while not hasattr(m, "config") or not hasattr(m.config, "patch_size"):
+            m = m.get_base_model() if hasattr(m, "get_base_model") else m.base_model
+        return m.config
+
+    def _paired_latents(self, batch):
+        """-> x_pair [B,2,F,C,H,W] bf16.  T2V / I2V permute [B,C,F,H,W] -> [B,F,C,H,W] unconditionally
+        (train/CogVideoX-5B/03_train.py:120-121, CogVideoX-I2V-5B/03_train.py:116-117); CogVideoX1.5 (patch_size_t set) casts
+        to bf16, permutes only when dim 1 is the 16 latent channels and trims F, H, W to even sizes
+        (train/CogVideoX1.5-5B/03_train.py:122-142)."""
+        cfg = self._base_config()
+        v15 = cfg.patch_size_t is not None
         if "x_pair" in batch:
             x_pair = batch["x_pair"]
         else:
-            x_pair = torch.stack([batch["x_win"].permute(0, 2, 1, 3, 4), batch["x_lose"].permute(0, 2, 1, 3, 4)], dim=1)
-        cond_pair = None
-        if batch.get("image_latent") is not None:
-            il = batch["image_latent"]
-            if il.shape[1] != 1:
-                il = il.permute(0, 2, 1, 3, 4)
-            cond_pair = self.i2v_condition_pair(il.to(x_pair.dtype), x_pair.shape[2])
-        return self.shared_step_paired(x_pair.contiguous(), batch["prompt_emb"], timesteps, noise, cond_pair=cond_pair)
+            xw, xl = batch["x_win"], batch["x_lose"]
+            if not v15 or xw.shape[1] == 16:
+                xw, xl = xw.permute(0, 2, 1, 3, 4), xl.permute(0, 2, 1, 3, 4)
+            x_pair = torch.stack([xw, xl], dim=1)
+        if v15:
+            x_pair = x_pair.to(torch.bfloat16)
+            Fr, H, W = x_pair.shape[2], x_pair.shape[4], x_pair.shape[5]
+            nF, nH, nW = Fr - Fr % 2, H - H % 2, W - W % 2
+            if (nF, nH, nW) != (Fr, H, W):
+                x_pair = x_pair[:, :, :nF, :, :nH, :nW]
+        return x_pair.contiguous()
+
+    def _i2v_condition(self, batch, x_pair):
+        """Conditioning channels of the I2V model (train/CogVideoX-I2V-5B/03_train.py:119-130): batch['image_emb'] [B,3,h,w]
+        (what DPODataset emits from 02_encode's 'image_embeds') is resized to the pixel size of the latents (nearest, the
+        F.interpolate default, :123), encoded by the caller-supplied `image_encoder` (:124-125), zero-padded to F frames
+        (:127-128); without an image the condition is zeros (:130).  A pre-encoded batch['image_latent'] is also accepted."""
+        cfg = self._base_config()
+        B, _, Fr, C, H, W = x_pair.shape
+        if cfg.in_channels == C:
+            if batch.get("image_emb") is not None or batch.get("image_latent") is not None:
+                raise RuntimeError(f"batch carries an I2V image condition but the transformer takes {cfg.in_channels} input channels "
+                                   f"(the I2V model takes {2 * C})")
+            return None
+        if cfg.in_channels != 2 * C:
+            raise RuntimeError(f"transformer.in_channels = {cfg.in_channels}; expected {C} (T2V) or {2 * C} (I2V)")
+        il = batch.get("image_latent")
+        if il is None and batch.get("image_emb") is not None:
+            if self.image_encoder is None:
+                raise RuntimeError("batch['image_emb'] needs CogVideoXDPOTrainer(image_encoder=...): the callable standing for "
+                                   "vae.encode(x).latent_dist.sample() * scaling_factor (train/CogVideoX-I2V-5B/03_train.py:124-125)")
+            with torch.no_grad():
+                img = torch.nn.functional.interpolate(batch["image_emb"].to(x_pair.device), size=(H * 8, W * 8))
+                il = self.image_encoder(img.unsqueeze(2))                       # [B,C,1,h,w]
+        if il is None:
+            return x_pair.new_zeros(B, 2, Fr, C, H, W)
+        if il.shape[1] != 1:
+            il = il.permute(0, 2, 1, 3, 4)                                       # -> [B,1,C,h,w] (:126)
+        if il.shape[2:] != (C, H, W):
+            raise RuntimeError(f"image latent {tuple(il.shape)} does not match the video latents [B,1,{C},{H},{W}]")
+        return self.i2v_condition_pair(il.to(x_pair.dtype), Fr)
+
+    def _shared_step(self, batch, timesteps=None, noise=None) -> LossOutput:
+        """Reference-shaped entry for all three CogVideoX step functions: batch['x_win'/'x_lose'] [B,C,F,H,W] (or the paired
+        'x_pair' [B,2,F,C,H,W]), batch['prompt_emb'], optional batch['image_emb'] / ['image_latent'] (I2V)."""
+        x_pair = self._paired_latents(batch)
+        cond_pair = self._i2v_condition(batch, x_pair)
+        return self.shared_step_paired(x_pair, batch["prompt_emb"].to(x_pair.dtype), timesteps, noise, cond_pair=cond_pair)
 
     def training_step(self, batch, batch_idx=0):
         if self.start_time is None:
@@ -160,10 +244,19 @@ class DPOEngine:
     def micro_step(self, batch) -> Dict[str, Any]:
         loss, logs = self.trainer.training_step(batch, self.micro)
         (loss / self.accum).backward()
+        # the three scalars the reference logs with sync_dist=True (train/CogVideoX-5B/03_train.py:164-173) go into the tail
+        # of the gradient buffer and are reduced by the SAME all-reduce: no extra collective, no host sync
+        tail = self.opt.flat.tail
+        tail[:3].add_(torch.stack([logs["train/loss"].float(), logs["train/reward_margin"].float(),
+                                   logs["train/reward_accuracy"].float()]))
+        tail[3:4].add_(1.0)
         self.micro += 1
         if self.micro % self.accum == 0:
             pending = self.opt.all_reduce_grads()
             logs["lr"] = self.opt.step(pending)
+            # mean over ranks and micro-steps; a device tensor (read it only when logging)
+            logs["sync"] = (tail[:3] / tail[3:4]).clone()
+            logs["sync_keys"] = ("train/loss", "train/reward_margin", "train/reward_accuracy")
             self.opt.zero_grad()
             self.trainer.global_step += 1
         return logs
