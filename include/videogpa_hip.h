@@ -179,7 +179,8 @@ int32_t vgpa_adamw_step(float* param, const float* grad, float* exp_avg, float* 
  * of utils/pointcloud_utils.py:47-73 as a per-point predicate.  pc/colors fp32 [N,3], conf fp32 [N] or NULL,
  * K fp32 [T,3,3], E fp32 [T,e_rows,4] (e_rows 3 or 4).  canvas u8 [T,H,W,3] and/or out_f fp32 [T,3,H,W]. */
 size_t vgpa_project_points_workspace_bytes(int64_t T, int64_t H, int64_t W);
-int32_t vgpa_project_points(const float* pc, const float* colors, const float* conf, float conf_thr, const float* K,
+int32_t vgpa_project_points(const float* pc, const float* colors, const float* conf, float conf_thr,
+                            const float* conf_thr_dev /* device fp32[1] or NULL: overrides conf_thr */, const float* K,
                             const float* E, int32_t e_rows, int64_t N, int64_t T, int64_t H, int64_t W, uint8_t* canvas,
                             float* out_f, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* MSEMetric.compute, metrics/mse.py:14-54.  dtype 0 f32 / 2 u8; layout 0 [T,C,H,W] / 1 [T,H,W,C]; is_tensor selects
@@ -193,6 +194,34 @@ int32_t vgpa_motion_score(const float* E, int32_t e_rows, int64_t T, float* out,
 /* kornia find_fundamental (8-point) + sampson_epipolar_distance as used by metrics/epipolar.py:197-213 */
 int32_t vgpa_epipolar_sampson(const float* p1, const float* p2, const int64_t* offsets, int64_t n_pairs, float* err_out,
                               float* F_out, vgpa_stream_t stream);
+
+/* Confidence cut of get_colored_pointcloud, utils/pointcloud_utils.py:44-73: thr_out[0] (device) = k-th largest valid
+ * confidence, k = max(1, ceil(n_valid * (1 - conf_thres / 100))); -inf for conf_thres <= 0 or no valid point.  On-device
+ * radix select (replaces torch.topk + .item()). */
+size_t vgpa_conf_threshold_workspace_bytes(void);
+int32_t vgpa_conf_threshold(const float* conf, int64_t N, float conf_thres, float* thr_out, void* workspace, size_t ws_bytes,
+                            vgpa_stream_t stream);
+/* MSEMetric / PSNRMetric.compute incl. the bilinear-resize branch, metrics/mse.py:14-29,56-80: rep [T,C,H2,W2] is resized to
+ * gt's [H,W] (F.interpolate bilinear, align_corners=False).  psnr 0: mse; 1: 10 log10(1/mse), 100 when mse == 0. */
+size_t vgpa_frame_metric_workspace_bytes(void);
+int32_t vgpa_frame_metric(const void* gt, int32_t gt_dtype, int32_t gt_layout, int32_t gt_is_tensor, const void* rep,
+                          int32_t rep_dtype, int32_t rep_layout, int32_t rep_is_tensor, int64_t T, int64_t C, int64_t H,
+                          int64_t W, int64_t H2, int64_t W2, int32_t psnr, float* out, void* workspace, size_t ws_bytes,
+                          vgpa_stream_t stream);
+/* MVCSMetric.compute, metrics/mvcs.py:12-114.  depth fp32 [T,H,W]; K fp32 [T,k_dim,k_dim] (k_dim 3|4); E fp32
+ * [T,e_rows(3|4),4] world-to-camera; out[0] = exp(-mean over valid consecutive pairs of the masked depth MSE). */
+size_t vgpa_mvcs_workspace_bytes(int64_t T);
+int32_t vgpa_mvcs(const float* depth, const float* K, int32_t k_dim, const float* E, int32_t e_rows, int64_t T, int64_t H,
+                  int64_t W, float* out, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* DA3 world points, pipelines/process_video.py:151-156 (affine_inverse + unproject_depth,
+ * depth_anything_3/utils/geometry.py:54-59,434-497).  depth fp32 [T,H,W], K fp32 [T,3,3], E fp32 [T,e_rows,4] -> world
+ * fp32 [T,H,W,3]. */
+int32_t vgpa_unproject_depth(const float* depth, const float* K, const float* E, int32_t e_rows, int64_t T, int64_t H,
+                             int64_t W, float* world, vgpa_stream_t stream);
+/* pose_encoding_to_extri_intri("absT_quaR_FoV"), vggt/utils/pose_enc.py:62-124: pe fp32 [n,9] -> ext fp32 [n,3,4],
+ * intr fp32 [n,3,3] or NULL. */
+int32_t vgpa_pose_decode(const float* pose_enc, int64_t n, float image_h, float image_w, float* ext, float* intr,
+                         vgpa_stream_t stream);
 
 #ifdef __cplusplus
 }

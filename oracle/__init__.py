@@ -8,13 +8,20 @@ the product package `videogpa_amd` never does (tests/test_layout.py enforces
 that) and fails loudly when its HIP library is missing.
 
 Pinning status (see DESIGN.md section "Oracle"):
-  * dpo.py, dataset.py, scorer.project_points / motion score / MSE / PSNR,
-    pose-encoding helpers: PINNED -- checked bit-for-bit against the importable
-    reference modules (train/loss.py, train/dataset.py,
-    utils/projection_utils.py, metrics/consistency_score.py, metrics/mse.py)
-    via tests/golden/*.pt generated by tests/golden/make_golden.py.
-  * cogvideox.py (diffusers CogVideoXTransformer3DModel), lora.py (PEFT),
-    scheduler.py (diffusers CogVideoXDPMScheduler), scorer.find_fundamental /
+  * dpo.py, dataset.py, scorer.{project_points, batch_reproject, motion_score,
+    mse (+ resize branch), psnr, pointcloud_filter, mvcs, quat_to_mat,
+    pose_encoding_to_extri_intri, affine_inverse, unproject_depth}: PINNED --
+    checked against outputs of the importable reference modules (train/loss.py,
+    train/dataset.py, utils/projection_utils.py, utils/pointcloud_utils.py,
+    metrics/consistency_score.py, metrics/mse.py, metrics/mvcs.py,
+    vggt/utils/pose_enc.py, depth_anything_3/utils/geometry.py) stored in
+    tests/golden/{dpo_loss,scorer,scorer2}.pt + dataset_pairs.json by
+    tests/golden/make_golden.py; tests/test_oracle_golden.py is the check
+    (integer / index results bit-exact, fp32 results to the tolerance stated
+    per test).
+  * cogvideox.py (diffusers CogVideoXTransformer3DModel + the PEFT LoRA linear),
+    scheduler.py (diffusers CogVideoXDPMScheduler: add_noise / get_velocity /
+    set_timesteps / step), scorer.find_fundamental /
     sampson (kornia): PARITY UNPINNED -- those third-party packages
     (diffusers>=0.31.0, peft>=0.12.0, kornia>=0.7.3, requirements.txt:20,24,33)
     are not vendored in the reference and not installed here; the restatement

@@ -181,6 +181,119 @@ def golden_scorer():
     print("scorer.pt written")
 
 
+def golden_scorer2():
+    """Second scorer fixture (tests/golden/scorer2.pt): the confidence filter (utils/pointcloud_utils.py:10-80), PSNR and
+    the size-mismatch branch of MSE (metrics/mse.py:24-25,56-80), MVCS (metrics/mvcs.py:12-114), VGGT's pose-encoding
+    decoder (vggt/utils/pose_enc.py:62-124) and the DA3 unprojection (depth_anything_3/utils/geometry.py:54-59,434-497;
+    pipelines/process_video.py:151-156) -- all run by importing the reference modules on CPU."""
+    import importlib.util
+    _stub("cv2")
+    piq = _stub("piq"); piq.ssim = None
+    _stub("lpips")
+    ply = _stub("plyfile"); ply.PlyData = object; ply.PlyElement = object
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    if "metrics" not in sys.modules:
+        _stub("metrics")
+    load("metrics.base", os.path.join(REF, "metrics/base.py"))
+    mse = load("metrics.mse", os.path.join(REF, "metrics/mse.py"))
+    mvcs = load("metrics.mvcs", os.path.join(REF, "metrics/mvcs.py"))
+    pcu = load("ref_pointcloud_utils", os.path.join(REF, "utils/pointcloud_utils.py"))
+    from vggt.utils.pose_enc import pose_encoding_to_extri_intri
+    from depth_anything_3.utils.geometry import affine_inverse, unproject_depth
+
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(4242)
+    out = {"pointcloud": [], "psnr": [], "mse_resize": [], "mvcs": [], "pose_enc": [], "da3_unproject": []}
+
+    # ---- confidence filter
+    T, h, w = 3, 9, 11
+    for mode, thres in (("depth", 0), ("depth", 30), ("depth", 90), ("pointmap", 50), ("depth", 100)):
+        pts = torch.randn(T, h, w, 3, generator=g)
+        conf = torch.rand(T, h, w, generator=g) * 3
+        conf.view(-1)[::17] = float("nan")
+        conf.view(-1)[5::23] = float("inf")
+        conf.view(-1)[7::13] = 1e-6
+        conf.view(-1)[3::29] = conf.view(-1)[2]          # ties
+        imgs = torch.rand(T, 3, h, w, generator=g)
+        preds = {"images": imgs}
+        if mode == "pointmap":
+            preds.update(world_points=pts, world_points_conf=conf)
+        else:
+            preds.update(world_points_from_depth=pts, depth_conf=conf)
+        v, c = pcu.get_colored_pointcloud(preds, mode=mode, conf_thres=thres)
+        out["pointcloud"].append({"mode": mode, "conf_thres": thres, "points": pts, "conf": conf, "images": imgs,
+                                  "vertices": v.clone(), "colors": c.clone()})
+
+    # ---- PSNR / resized MSE
+    psnr = mse.PSNRMetric(device="cpu")
+    m = mse.MSEMetric()
+    a = torch.rand(2, 3, 12, 16, generator=g)
+    b = (a + 0.05 * torch.randn(2, 3, 12, 16, generator=g)).clamp(0, 1)
+    small = torch.rand(2, 3, 7, 9, generator=g) * 2 - 1
+    big = torch.rand(2, 3, 20, 31, generator=g)
+    u8 = (torch.rand(2, 12, 16, 3, generator=g) * 255).to(torch.uint8)
+    for gt, rep in ((a, b), (a, a.clone()), (a, small), (u8, big), (u8.numpy(), small)):
+        out["psnr"].append({"gt": gt, "rep": rep, "val": psnr.compute(gt=gt, rep=rep)})
+    for gt, rep in ((a, small), (u8, big), (small, a)):
+        out["mse_resize"].append({"gt": gt, "rep": rep, "val": m.compute(gt=gt, rep=rep)})
+
+    # ---- MVCS: a smooth scene seen by slowly moving cameras (+ depth noise), three input layouts
+    def scene(T, H, W, noise, seed):
+        gg = torch.Generator().manual_seed(seed)
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        K = torch.tensor([[W * 0.9, 0.0, W / 2], [0.0, W * 0.95, H / 2], [0.0, 0.0, 1.0]]).repeat(T, 1, 1)
+        K[:, 0, 0] += torch.arange(T) * 0.5
+        E = torch.eye(4).repeat(T, 1, 1)
+        depths = torch.empty(T, H, W)
+        for i in range(T):
+            ang = 0.02 * i
+            E[i, :3, :3] = torch.tensor([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=torch.float32)
+            E[i, :3, 3] = torch.tensor([0.03 * i, -0.01 * i, 0.02 * i])
+            depths[i] = 2.0 + 0.3 * torch.sin(xs / W * 3 + 0.1 * i) + 0.2 * torch.cos(ys / H * 2) + noise * torch.randn(H, W, generator=gg)
+        return depths, K, E
+
+    mv = mvcs.MVCSMetric(device="cpu")
+    for ci, (T_, H_, W_, noise) in enumerate(((4, 24, 32, 0.01), (3, 17, 23, 0.05), (5, 20, 20, 0.0), (1, 8, 8, 0.0))):
+        d, K, E = scene(T_, H_, W_, noise, 100 + ci)
+        if ci == 0:
+            dd, KK, EE = d.unsqueeze(-1), K, E[:, :3]
+        elif ci == 1:
+            dd, KK, EE = d.unsqueeze(1), torch.eye(4).repeat(T_, 1, 1), E
+            KK[:, :3, :3] = K
+        else:
+            dd, KK, EE = d.numpy(), K, E
+        if ci == 2:
+            dd = dd.copy()
+            dd[1, :5] = -1.0                       # negative depths: projected z <= 0 -> masked out
+        val = mv.compute(gt=None, rep=None, depths=dd, intrinsics=KK, extrinsics=EE)
+        out["mvcs"].append({"depths": dd if torch.is_tensor(dd) else torch.from_numpy(dd), "depths_is_numpy": not torch.is_tensor(dd),
+                            "intrinsics": KK, "extrinsics": EE, "val": float(val)})
+
+    # ---- pose-encoding decoder
+    pe = torch.randn(2, 5, 9, generator=g)
+    pe[..., 7:] = 0.6 + 0.3 * torch.rand(2, 5, 2, generator=g)
+    ex, intr = pose_encoding_to_extri_intri(pe, image_size_hw=(294, 518))
+    out["pose_enc"].append({"pose_enc": pe, "image_size_hw": (294, 518), "extrinsics": ex, "intrinsics": intr})
+
+    # ---- DA3: affine_inverse + unproject_depth as pipelines/process_video.py:151-156 calls them
+    d, K, E = scene(3, 10, 14, 0.02, 7)
+    c2w = affine_inverse(E)
+    wp = unproject_depth(d.unsqueeze(0).unsqueeze(-1), K.unsqueeze(0), c2w.unsqueeze(0)).squeeze(0)
+    out["da3_unproject"].append({"depths": d, "intrinsics": K, "extrinsics": E, "c2w": c2w, "world_points": wp})
+
+    torch.save(out, os.path.join(HERE, "scorer2.pt"))
+    print("scorer2.pt written:", {k: len(v) for k, v in out.items()})
+
+
 def golden_adapter_config_keys():
     """Key set PEFT wrote for the released adapters (checkpoints/VideoGPA-T2V-lora/adapter_config.json)."""
     cfg = json.load(open(os.path.join(REF, "checkpoints/VideoGPA-T2V-lora/adapter_config.json")))
@@ -192,3 +305,4 @@ if __name__ == "__main__":
     golden_dpo_loss()
     golden_dataset()
     golden_scorer()
+    golden_scorer2()

@@ -6,7 +6,7 @@ tests/golden/cfg1_<variant>.pt (made by tests/golden/make_cfg1_golden.py in the 
 
 Tolerances (the HIP path computes in bf16, the oracle in fp32 on the same bf16-rounded weights / inputs):
   loss                  |d| <= 1e-3 (north_star) -- measured ~1e-6
-  reward_margin, rewards|d| <= 2e-4 + 1 % relative
+  rewards (= -mean err) |d| <= 2e-4 + 1 % relative; reward_margin (their difference, 1e-3 of the rewards) |d| <= 1e-3
   v_pred samples        |d| <= 3 % of the prediction range (bf16 activations through 2 blocks)
   LoRA grads, per tensor: norm within 5 %, sampled entries within 5 % of the tensor's max |grad| (+ cosine >= 0.99)
 """
@@ -75,12 +75,18 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
     gold = torch.load(os.path.join(HERE, "golden", f"cfg1_{variant}.pt"), weights_only=False)
     out, preds, grads = _hip_step(variant)
     report = {"variant": variant, "loss_hip": out.loss.item(), "loss_oracle": float(gold["loss"])}
+    fails = []      # every comparison is made and written to gpurun_out/ before the first assert fires
 
-    assert abs(out.loss.item() - float(gold["loss"])) < 1e-3, report
+    def check(ok, what):
+        if not ok:
+            fails.append(what)
+
+    check(abs(out.loss.item() - float(gold["loss"])) < 1e-3, ("loss", out.loss.item(), float(gold["loss"])))
     for name, got in (("reward_margin", out.reward_margin), ("winner_reward", out.winner_reward), ("loser_reward", out.loser_reward)):
         ref = float(gold[name])
         report[name] = (got.item(), ref)
-        assert abs(got.item() - ref) < 2e-4 + 0.01 * abs(ref), (name, got.item(), ref)
+        tol = 1e-3 if name == "reward_margin" else 2e-4 + 0.01 * abs(ref)
+        check(abs(got.item() - ref) < tol, (name, got.item(), ref))
 
     for k, v in preds.items():
         v = v.float().cpu()
@@ -91,10 +97,11 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
         err = (got - ref).abs().max().item()
         report[k + "_err_over_range"] = err / rng_
         report[k + "_norm_rel"] = abs(v.double().norm().item() / float(gold[k + "_norm"]) - 1)
-        assert err < 0.03 * rng_, (k, err, rng_)
-        assert report[k + "_norm_rel"] < 0.01, (k, report[k + "_norm_rel"])
+        check(err < 0.03 * rng_, (k, err, rng_))
+        check(report[k + "_norm_rel"] < 0.01, (k, report[k + "_norm_rel"]))
 
     worst = {"norm_rel": 0.0, "sample_err_over_max": 0.0, "cos_min": 1.0}
+    per_tensor = {}
     assert set(grads) == set(gold["lora_grads"])
     for k, g in grads.items():
         ref = gold["lora_grads"][k]
@@ -105,14 +112,18 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
         nrel = abs(g.double().norm().item() / float(ref["norm"]) - 1)
         serr = (got - rs).abs().max().item() / amax
         cos = float((got * rs).sum() / (got.norm() * rs.norm()).clamp_min(1e-300))
+        per_tensor[k.replace("base_model.model.transformer_blocks.", "")] = (round(nrel, 5), round(serr, 5), round(cos, 6))
         worst["norm_rel"] = max(worst["norm_rel"], nrel)
         worst["sample_err_over_max"] = max(worst["sample_err_over_max"], serr)
         worst["cos_min"] = min(worst["cos_min"], cos)
-        assert math.isfinite(nrel) and nrel < 0.05, (k, nrel)
-        assert serr < 0.05, (k, serr)
-        assert cos > 0.99, (k, cos)
+        check(math.isfinite(nrel) and nrel < 0.05, (k, "norm", nrel))
+        check(serr < 0.05, (k, "sample", serr))
+        check(cos > 0.99, (k, "cos", cos))
     report["lora_grads_worst"] = worst
+    report["lora_grads_per_tensor(norm_rel, sample_err/max, cos)"] = per_tensor
+    report["failed_checks"] = [str(f) for f in fails]
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"cfg1_parity_{variant}.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
+    assert not fails, fails

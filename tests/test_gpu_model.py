@@ -317,20 +317,22 @@ def test_generate_denoise_loop_matches_cpu_restatement():
     sch = CogVideoXDPMScheduler(timestep_spacing="trailing")
     out = denoise(merged, sch, pos.cuda(), neg.cuda(), latent_frames=Fr, height=Hh, width=Ww, num_inference_steps=steps,
                   guidance_scale=6.0, latents=lat0.cuda(), step_noise=noise.cuda())
-    # CPU fp64 loop
-    ref_s = CogVideoXDPMScheduler(timestep_spacing="trailing")
-    ref_s.set_timesteps(steps)
-    assert ref_s.timesteps.tolist() == [999, 832, 666, 499, 332, 166]
+    # CPU fp64 loop: transformer AND scheduler from the oracle (oracle.scheduler.dpm_step is an independent restatement)
+    abar = osch.alphas_cumprod()
+    ref_ts = osch.trailing_timesteps(steps)
+    assert ref_ts.tolist() == [999, 832, 666, 499, 332, 166]
+    sch.set_timesteps(steps)
+    assert sch.timesteps.tolist() == ref_ts.tolist()
     cos, sin = ocv.rope_3d_tables(Fr, Hh // 2, Ww // 2, 64)
     c2, s2 = rope_3d_tables(Fr, Hh // 2, Ww // 2, 64, device="cpu")
     assert torch.equal(cos, c2) and torch.equal(sin, s2)
     lat = lat0.double()
     old = None
     emb = torch.cat([neg, pos]).double()
-    for i, t in enumerate(ref_s.timesteps):
+    for i, t in enumerate(ref_ts):
         v = ocv.forward(sdm, cfg, torch.cat([lat, lat]), emb, t.expand(2), image_rotary_emb=(cos.double(), sin.double()))
         v = v[:1] + 6.0 * (v[1:] - v[:1])
-        lat, old = ref_s.step(v, old, t, ref_s.timesteps[i - 1] if i > 0 else None, lat, noise=noise[i].double())
+        lat, old = osch.dpm_step(abar, v, old, t, ref_ts[i - 1] if i > 0 else None, lat, steps, noise[i].double())
         lat = lat.to(torch.bfloat16).double()     # the pipeline casts latents back to the prompt dtype every step
     err = (out.double().cpu() - lat).abs().max().item()
     assert err < 0.06 * lat.abs().max().item(), (err, lat.abs().max().item())

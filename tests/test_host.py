@@ -143,3 +143,28 @@ def test_scheduler_table_and_config():
     assert s.config.num_train_timesteps == 1000
     a = s.alphas_cumprod
     assert float(a[-1]) == 0.0 and abs(float(a[0]) - (1 - 0.00085)) < 1e-9 and bool((a[1:] <= a[:-1]).all())
+
+
+def test_dpm_sampler_step_matches_oracle_restatement():
+    """CogVideoXDPMScheduler.set_timesteps / step (host-side float64 math, generate path) vs the oracle's independent
+    (alpha, sigma, lambda) restatement, incl. the zero-terminal-SNR first step and the first-order fallback after it."""
+    import torch
+    from oracle import scheduler as osch
+    from videogpa_amd.scheduler import CogVideoXDPMScheduler
+    abar = osch.alphas_cumprod()
+    for steps in (6, 50):
+        s = CogVideoXDPMScheduler()
+        s.set_timesteps(steps)
+        assert torch.equal(abar, s.alphas_cumprod)
+        ts = osch.trailing_timesteps(steps)
+        assert ts.tolist() == s.timesteps.tolist()
+        g = torch.Generator().manual_seed(steps)
+        x = torch.randn(1, 2, 4, 4, 4, generator=g, dtype=torch.float64)
+        xo, old, oldo = x.clone(), None, None
+        for i, t in enumerate(ts):
+            v = torch.randn(x.shape, generator=g, dtype=torch.float64)
+            n = torch.randn(2, *x.shape, generator=g, dtype=torch.float64)
+            back = ts[i - 1] if i > 0 else None
+            x, old = s.step(v, old, t, back, x, noise=n)
+            xo, oldo = osch.dpm_step(abar, v, oldo, t, back, xo, steps, n)
+            assert torch.allclose(x, xo, rtol=0, atol=1e-12) and torch.allclose(old, oldo, rtol=0, atol=1e-12)

@@ -62,3 +62,46 @@ def test_motion_and_mse_match_reference(golden_dir):
         assert scorer.motion_score(c["E"].numpy()) == c["score"]
     for c in gold["mse"]:
         assert scorer.mse(c["gt"], c["rep"]) == c["val"]
+
+
+# ---------------------------------------------------------------- scorer2.pt: filter, PSNR, resized MSE, MVCS, pose encoding, DA3 unprojection
+def _g2(golden_dir):
+    return torch.load(os.path.join(golden_dir, "scorer2.pt"), weights_only=False)
+
+
+def test_pointcloud_filter_matches_reference(golden_dir):
+    for c in _g2(golden_dir)["pointcloud"]:
+        v, col = scorer.pointcloud_filter(c["points"], c["conf"], c["images"], c["conf_thres"])
+        assert torch.equal(v, c["vertices"]) and torch.equal(col, c["colors"]), (c["mode"], c["conf_thres"])     # index work: bit-exact
+
+
+def test_psnr_and_resized_mse_match_reference(golden_dir):
+    g = _g2(golden_dir)
+    for c in g["psnr"]:
+        got = scorer.psnr(c["gt"], c["rep"])
+        assert abs(got - c["val"]) <= 2e-5 * max(1.0, abs(c["val"])), (got, c["val"])       # fp32 bilinear weights / log10
+    for c in g["mse_resize"]:
+        got = scorer.mse_any_size(c["gt"], c["rep"])
+        assert abs(got - c["val"]) <= 2e-6 * max(1.0, abs(c["val"])), (got, c["val"])
+
+
+def test_mvcs_matches_reference(golden_dir):
+    cases = _g2(golden_dir)["mvcs"]
+    assert len(cases) == 4
+    for c in cases:
+        d = c["depths"].numpy()
+        got = scorer.mvcs(d, c["intrinsics"].numpy(), c["extrinsics"].numpy())
+        # fp32 chain (3x3 inverse, relative pose, bilinear sampling) in a different summation order: 1e-5 relative
+        assert abs(got - c["val"]) <= 1e-5 * max(1.0, abs(c["val"])), (got, c["val"])
+    assert cases[-1]["val"] == 0.0 and scorer.mvcs(cases[-1]["depths"].numpy(), cases[-1]["intrinsics"].numpy(), cases[-1]["extrinsics"].numpy()) == 0.0
+
+
+def test_pose_encoding_and_unprojection_match_reference(golden_dir):
+    g = _g2(golden_dir)
+    for c in g["pose_enc"]:
+        ext, K = scorer.pose_encoding_to_extri_intri(c["pose_enc"], c["image_size_hw"])
+        assert torch.equal(ext, c["extrinsics"]) and torch.equal(K, c["intrinsics"])          # same torch ops in the same order
+    for c in g["da3_unproject"]:
+        assert torch.equal(scorer.affine_inverse(c["extrinsics"]), c["c2w"])
+        wp = scorer.unproject_depth(c["depths"], c["intrinsics"], c["c2w"])
+        assert torch.allclose(wp, c["world_points"], rtol=1e-5, atol=1e-6)

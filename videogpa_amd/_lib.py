@@ -52,7 +52,15 @@ SIGNATURES = {
     "vgpa_lora_up_add": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, I32, P]),
     "vgpa_lora_grad": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P]),
     "vgpa_project_points_workspace_bytes": (SZ, [I64, I64, I64]),
-    "vgpa_project_points": (I32, [P, P, P, F32, P, P, I32, I64, I64, I64, I64, P, P, P, SZ, P]),
+    "vgpa_project_points": (I32, [P, P, P, F32, P, P, P, I32, I64, I64, I64, I64, P, P, P, SZ, P]),
+    "vgpa_conf_threshold_workspace_bytes": (SZ, []),
+    "vgpa_conf_threshold": (I32, [P, I64, F32, P, P, SZ, P]),
+    "vgpa_frame_metric_workspace_bytes": (SZ, []),
+    "vgpa_frame_metric": (I32, [P, I32, I32, I32, P, I32, I32, I32, I64, I64, I64, I64, I64, I64, I32, P, P, SZ, P]),
+    "vgpa_mvcs_workspace_bytes": (SZ, [I64]),
+    "vgpa_mvcs": (I32, [P, P, I32, P, I32, I64, I64, I64, P, P, SZ, P]),
+    "vgpa_unproject_depth": (I32, [P, P, P, I32, I64, I64, I64, P, P]),
+    "vgpa_pose_decode": (I32, [P, I64, F32, F32, P, P, P]),
     "vgpa_frame_mse_workspace_bytes": (SZ, []),
     "vgpa_frame_mse": (I32, [P, I32, I32, I32, P, I32, I32, I32, I64, I64, I64, I64, P, P, SZ, P]),
     "vgpa_motion_score": (I32, [P, I32, I64, P, P]),

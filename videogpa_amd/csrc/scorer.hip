@@ -28,7 +28,8 @@ __device__ __forceinline__ float f32_unordered(uint32_t u) {
 }
 
 __global__ __launch_bounds__(SC_THREADS) void project_zbuf_kernel(const float* __restrict__ pc, const float* __restrict__ colors,
-                                                                    const float* __restrict__ conf, float conf_thr,
+                                                                    const float* __restrict__ conf, float conf_thr_val,
+                                                                    const float* __restrict__ conf_thr_dev,
                                                                     const float* __restrict__ Kmat, const float* __restrict__ Emat,
                                                                     int e_stride, int64_t N, int H, int W,
                                                                     unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ cmax) {
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(SC_THREADS) void project_zbuf_kernel(const float* _
         for (int j = 0; j < 3; ++j) { R[i][j] = E[i * 4 + j]; Km[i][j] = K[i * 3 + j]; }
         tr[i] = E[i * 4 + 3];
     }
+    const float conf_thr = conf_thr_dev ? conf_thr_dev[0] : conf_thr_val;   // device-resident cut (vgpa_conf_threshold): no host sync
     uint32_t lmax = 0;  // ordered-uint of -NaN-free minimum
     for (int64_t i = (int64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < N; i += (int64_t)gridDim.x * SC_THREADS) {
         if (conf) {
@@ -334,10 +336,11 @@ extern "C" {
 size_t vgpa_project_points_workspace_bytes(int64_t T, int64_t H, int64_t W) { return (size_t)T * H * W * 8 + (size_t)T * 4; }
 
 // Render T views of one coloured cloud.  pc/colors fp32 [N,3]; conf fp32 [N] or NULL (points with non-finite conf,
-// conf <= 1e-5 or conf < conf_thr are skipped); K fp32 [T,3,3]; E fp32 [T, e_rows(3|4), 4].
+// conf <= 1e-5 or conf < threshold are skipped; threshold = conf_thr_dev[0] when that device pointer is given, else the
+// by-value conf_thr); K fp32 [T,3,3]; E fp32 [T, e_rows(3|4), 4].
 // Outputs (either may be NULL): canvas u8 [T,H,W,3]; out_f fp32 [T,3,H,W] in [-1,1].
-int32_t vgpa_project_points(const float* pc, const float* colors, const float* conf, float conf_thr, const float* K, const float* E,
-                            int32_t e_rows, int64_t N, int64_t T, int64_t H, int64_t W, uint8_t* canvas, float* out_f, void* workspace,
+int32_t vgpa_project_points(const float* pc, const float* colors, const float* conf, float conf_thr, const float* conf_thr_dev,
+                            const float* K, const float* E, int32_t e_rows, int64_t N, int64_t T, int64_t H, int64_t W, uint8_t* canvas, float* out_f, void* workspace,
                             size_t ws_bytes, hipStream_t stream) {
     if (!K || !E || !workspace || (N > 0 && (!pc || !colors)) || (e_rows != 3 && e_rows != 4) || N < 0 || N > 0xFFFFFFFFll || T <= 0 ||
         T > 65535 || H <= 0 || W <= 0 || (!canvas && !out_f))
@@ -348,7 +351,7 @@ int32_t vgpa_project_points(const float* pc, const float* colors, const float* c
     if (hipMemsetAsync(zbuf, 0xFF, (size_t)T * H * W * 8, stream) != hipSuccess) return VGPA_ERR_LAUNCH;
     if (hipMemsetAsync(cmax, 0, (size_t)T * 4, stream) != hipSuccess) return VGPA_ERR_LAUNCH;
     if (N > 0) {
-        VGPA_LAUNCH(project_zbuf_kernel, dim3(sc_grid(N, 2048), (unsigned)T), dim3(SC_THREADS), 0, stream, pc, colors, conf, conf_thr, K, E,
+        VGPA_LAUNCH(project_zbuf_kernel, dim3(sc_grid(N, 2048), (unsigned)T), dim3(SC_THREADS), 0, stream, pc, colors, conf, conf_thr, conf_thr_dev, K, E,
                     (int)e_rows * 4, N, (int)H, (int)W, zbuf, cmax);
         VGPA_CHECK_LAUNCH();
     }

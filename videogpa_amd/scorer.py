@@ -21,7 +21,8 @@ def _dev_f32(x, device="cuda"):
 
 
 def project_views(pc, colors, intrinsics, extrinsics, H, W, conf=None, conf_thr=float("-inf"), want_canvas=True, want_float=True):
-    """All T views in one launch pair.  -> (canvas u8 [T,H,W,3] | None, frames fp32 [T,3,H,W] in [-1,1] | None)."""
+    """All T views in one launch pair.  -> (canvas u8 [T,H,W,3] | None, frames fp32 [T,3,H,W] in [-1,1] | None).
+    conf_thr: python float, or a device fp32 tensor of one element (from `confidence_threshold`: stays on the GPU)."""
     pc, colors = _dev_f32(pc).reshape(-1, 3), _dev_f32(colors).reshape(-1, 3)
     K, E = _dev_f32(intrinsics), _dev_f32(extrinsics)
     if K.dim() == 2:
@@ -37,8 +38,11 @@ def project_views(pc, colors, intrinsics, extrinsics, H, W, conf=None, conf_thr=
     cf = None if conf is None else _dev_f32(conf).reshape(-1)
     ws_bytes = _lib.query("vgpa_project_points_workspace_bytes", T, H, W)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.call("vgpa_project_points", pc if N else None, colors if N else None, cf, float(conf_thr), K, E, e_rows, N, T, H, W, canvas, out_f,
-              ws, ws_bytes, _stream())
+    thr_dev = conf_thr if torch.is_tensor(conf_thr) else None
+    if thr_dev is not None:
+        _req(thr_dev, torch.float32)
+    _lib.call("vgpa_project_points", pc if N else None, colors if N else None, cf, 0.0 if thr_dev is not None else float(conf_thr), thr_dev,
+              K, E, e_rows, N, T, H, W, canvas, out_f, ws, ws_bytes, _stream())
     return canvas, out_f
 
 
@@ -60,17 +64,34 @@ def batch_reproject(pc, colors, intrinsics, extrinsics, H, W, save_path=None):
 
 
 def confidence_threshold(conf, conf_thres):
-    """The top-(1 - conf_thres/100) confidence cut of utils/pointcloud_utils.py:55-73 (-> float threshold)."""
+    """The top-(100 - conf_thres) % confidence cut of utils/pointcloud_utils.py:55-73 -> device fp32 tensor [1] holding the
+    k-th largest valid confidence (-inf when nothing is cut).  On-device radix select: no sort, no host round trip."""
     vals = _dev_f32(conf).reshape(-1)
-    valid = torch.isfinite(vals) & (vals > 1e-5)
-    if conf_thres <= 0:
-        return float("-inf")
-    n = int(valid.sum().item())
-    if n == 0:
-        return float("-inf")
-    keep = max(0.0, min(1.0, 1.0 - conf_thres / 100.0))
-    k = max(1, int(np.ceil(n * keep)))
-    return float(torch.topk(vals[valid], k)[0][-1].item())
+    thr = torch.empty(1, dtype=torch.float32, device=vals.device)
+    if vals.numel() == 0:
+        return thr.fill_(float("-inf"))
+    ws_bytes = _lib.query("vgpa_conf_threshold_workspace_bytes")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=vals.device)
+    _lib.call("vgpa_conf_threshold", vals, vals.numel(), float(conf_thres), thr, ws, ws_bytes, _stream())
+    return thr
+
+
+def get_colored_pointcloud(predictions, mode="pointmap", conf_thres=50):
+    """Drop-in for utils/pointcloud_utils.py:10-80 -> (vertices [N,3], colors [N,3] in 0..255), compacted on the device.
+    (`reproject_predictions` below is the fused form that never materialises the filtered cloud.)"""
+    if "pointmap" in mode.lower() and "world_points" in predictions:
+        points, conf = predictions["world_points"], predictions.get("world_points_conf")
+    else:
+        points, conf = predictions["world_points_from_depth"], predictions.get("depth_conf")
+    points = _dev_f32(points)
+    conf = torch.ones_like(points[..., 0]) if conf is None else _dev_f32(conf)
+    images = _dev_f32(predictions["images"])
+    colors = (images.permute(0, 2, 3, 1) if (images.dim() == 4 and images.shape[1] == 3) else images).reshape(-1, 3) * 255
+    vals = conf.reshape(-1)
+    mask = torch.isfinite(vals) & (vals > 1e-5)
+    if conf_thres > 0:
+        mask = mask & (vals >= confidence_threshold(vals, conf_thres))
+    return points.reshape(-1, 3)[mask], colors[mask]
 
 
 def reproject_predictions(points, conf, images, intrinsics, extrinsics, H, W, conf_thres=0.0):
@@ -120,25 +141,88 @@ def _img_desc(x):
     return t, (2 if t.dtype == torch.uint8 else 0), layout, int(is_tensor), T, C, H, W
 
 
+def _frame_metric(gt, rep, psnr):
+    g, gd, gl, gt_t, T, C, H, W = _img_desc(gt)
+    r, rd, rl, rt_t, T2, C2, H2, W2 = _img_desc(rep)
+    if (T, C) != (T2, C2):
+        raise ValueError("gt and rep disagree in frames / channels")
+    out = torch.empty(1, dtype=torch.float32, device=g.device)
+    ws_bytes = _lib.query("vgpa_frame_metric_workspace_bytes")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+    # rep of another spatial size is resized bilinearly to gt's inside the kernel (metrics/mse.py:24-25,65-66)
+    _lib.call("vgpa_frame_metric", g, gd, gl, gt_t, r, rd, rl, rt_t, T, C, H, W, H2, W2, 1 if psnr else 0, out, ws, ws_bytes, _stream())
+    return out[0]
+
+
 class MSEMetric(Metric):
     def __init__(self):
         super().__init__(name="mse")
 
     def compute_device(self, *, gt, rep):
-        g, gd, gl, gt_t, T, C, H, W = _img_desc(gt)
-        r, rd, rl, rt_t, T2, C2, H2, W2 = _img_desc(rep)
-        if (H, W) != (H2, W2):
-            raise NotImplementedError("gt / rep of different spatial size (bilinear resize) is not on the on-device path")
-        if (T, C) != (T2, C2):
-            raise ValueError("gt and rep disagree in frames / channels")
-        out = torch.empty(1, dtype=torch.float32, device=g.device)
-        ws_bytes = _lib.query("vgpa_frame_mse_workspace_bytes")
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
-        _lib.call("vgpa_frame_mse", g, gd, gl, gt_t, r, rd, rl, rt_t, T, C, H, W, out, ws, ws_bytes, _stream())
-        return out[0]
+        return _frame_metric(gt, rep, psnr=False)
 
     def compute(self, *, gt, rep, **kwargs) -> float:
         return float(self.compute_device(gt=gt, rep=rep).item())
+
+
+class PSNRMetric(Metric):
+    """metrics/mse.py:56-80: 10 log10(1 / mse) on [0,1] frames, 100.0 for identical inputs."""
+
+    def __init__(self, device="cuda"):
+        super().__init__(name="psnr")
+        self.device = device
+
+    def compute(self, *, gt, rep, **kwargs) -> float:
+        return float(_frame_metric(gt, rep, psnr=True).item())
+
+
+class MVCSMetric(Metric):
+    """Multi-view depth-consistency score (metrics/mvcs.py:12-114): every pixel of view i is back-projected with its depth,
+    moved into view i+1 and compared with the depth sampled there; exp(-mean masked squared error over the pairs)."""
+
+    def __init__(self, device="cuda"):
+        super().__init__(name="MVCS")
+        self.device = device
+
+    def compute_device(self, *, depths, intrinsics, extrinsics):
+        d = _dev_f32(depths)
+        if d.dim() == 4:
+            d = d.squeeze(1) if d.shape[1] == 1 else (d.squeeze(3) if d.shape[3] == 1 else d)
+        d = d.contiguous()
+        K, E = _dev_f32(intrinsics), _dev_f32(extrinsics)
+        T, H, W = d.shape
+        out = torch.empty(1, dtype=torch.float32, device=d.device)
+        ws_bytes = _lib.query("vgpa_mvcs_workspace_bytes", T)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=d.device)
+        _lib.call("vgpa_mvcs", d, K, K.shape[-1], E, E.shape[-2], T, H, W, out, ws, ws_bytes, _stream())
+        return out[0]
+
+    def compute(self, *, gt=None, rep=None, depths, intrinsics, extrinsics, **kwargs) -> float:
+        return float(self.compute_device(depths=depths, intrinsics=intrinsics, extrinsics=extrinsics).item())
+
+
+def pose_encoding_to_extri_intri(pose_encoding, image_size_hw=None, pose_encoding_type="absT_quaR_FoV", build_intrinsics=True):
+    """vggt/utils/pose_enc.py:62-124 on device: [...,9] -> ([...,3,4], [...,3,3] | None)."""
+    if pose_encoding_type != "absT_quaR_FoV":
+        raise NotImplementedError
+    pe = _dev_f32(pose_encoding)
+    lead = pe.shape[:-1]
+    n = pe.numel() // 9
+    ext = torch.empty(*lead, 3, 4, dtype=torch.float32, device=pe.device)
+    intr = torch.empty(*lead, 3, 3, dtype=torch.float32, device=pe.device) if build_intrinsics else None
+    Hh, Ww = image_size_hw if build_intrinsics else (0, 0)
+    _lib.call("vgpa_pose_decode", pe, n, float(Hh), float(Ww), ext, intr, _stream())
+    return ext, intr
+
+
+def unproject_depth_to_world(depths, intrinsics, extrinsics):
+    """DA3 branch of the reference (pipelines/process_video.py:151-156): c2w = affine_inverse(w2c), world points of every
+    pixel = c2w [K^-1 (x, y, 1) depth].  depths [T,H,W], K [T,3,3], E [T,3|4,4] -> [T,H,W,3]."""
+    d, K, E = _dev_f32(depths), _dev_f32(intrinsics), _dev_f32(extrinsics)
+    T, H, W = d.shape
+    world = torch.empty(T, H, W, 3, dtype=torch.float32, device=d.device)
+    _lib.call("vgpa_unproject_depth", d, K, E, E.shape[-2], T, H, W, world, _stream())
+    return world
 
 
 class Consistency_Score(Metric):
