@@ -81,8 +81,8 @@ def cpu_baseline(F_step, budget_s=100.0):
     import cfg1_common as c1
     from oracle import cogvideox as ocv
     from oracle import scheduler as osch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads, probe = _pick_cpu_threads()
+    torch.set_num_threads(threads)
     cfg = c1.config()
     sd = {k: v.float() for k, v in c1.base_state_dict(cfg).items()}
     lora0, r = c1.lora_state_dict(cfg, "r8")
@@ -96,7 +96,9 @@ def cpu_baseline(F_step, budget_s=100.0):
         out["loss"].backward()
         return time.perf_counter() - t0, float(out["loss"])
 
-    step()                                           # warm-up (thread pools, allocator)
+    # warm-up = the same code path on a 1-frame version of the inputs (thread pools, allocator, oneDNN primitive caches)
+    _x = (x_win[:, :, :1], x_lose[:, :, :1], noise[:, :1])
+    ocv.dpo_pair_step(sd, cfg, {k: v.clone().requires_grad_(True) for k, v in lora0.items()}, abar, _x[0], _x[1], prompt, t, _x[2])["loss"].backward()
     times, loss = [], None
     while len(times) < 3 and (not times or sum(times) < budget_s):
         dt, loss = step()
@@ -111,10 +113,33 @@ def cpu_baseline(F_step, budget_s=100.0):
         model = "unknown"
     return {"value": 1.0 / med, "unit": "pair-steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle fp32 full pair-step (4 fwd + bwd) of BASELINE configs[0] (2 blocks, D=3072, S={S1}, r={r}): "
-                      f"{len(times)} timed steps after 1 warm-up, median {med:.2f} s (loss {loss:.6f}); {F1 / med / 1e9:.0f} GFLOP/s on {model}",
+                      f"{len(times)} timed step(s) after a 1-frame warm-up, median {med:.2f} s (loss {loss:.6f}); {F1 / med / 1e9:.0f} GFLOP/s on "
+                      f"{model} with {threads} of {os.cpu_count()} hardware threads (the fastest of {probe})",
             "config": "BASELINE configs[0]", "step_seconds": times, "cpu_model": model,
             "headline_extrapolated": {"value": 1.0 / (med * F_step / F1), "unit": "pair-steps/s",
                                       "note": f"configs[0] time x algorithmic-FLOP ratio {F_step / F1:.1f} (extrapolated, not measured)"}}
+
+
+def _pick_cpu_threads():
+    """torch's CPU kernels do not scale to every hardware thread of a big host (256 threads ran the oracle 7x slower than 16
+    on the MI355X box): time a small matmul + attention probe at a few thread counts and keep the fastest."""
+    import torch.nn.functional as F
+    cores = os.cpu_count() or 1
+    g = torch.Generator().manual_seed(0)
+    x, W = torch.randn(2048, 3072, generator=g), torch.randn(3072, 3072, generator=g)
+    q = torch.randn(1, 16, 2048, 64, generator=g)
+    cands = sorted({c for c in (cores, cores // 2, cores // 4, 64, 32, 16, 8) if 1 <= c <= cores}, reverse=True)
+    best, seen = None, {}
+    for n in cands:
+        torch.set_num_threads(n)
+        F.linear(x, W); F.scaled_dot_product_attention(q, q, q)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            F.linear(x, W); F.scaled_dot_product_attention(q, q, q)
+        seen[n] = round(time.perf_counter() - t0, 4)
+        if best is None or seen[n] < seen[best]:
+            best = n
+    return best, seen
 
 
 def self_launch(n):

@@ -126,7 +126,7 @@ def init_lora(cfg: CogVideoXConfig, r=64, seed=1, b_std=0.0, dtype=torch.float32
 
 def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0, max_period=10000):
     half = dim // 2
-    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / (half - freq_shift)
     emb = t[:, None].float() * torch.exp(exponent)[None, :]
     emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
     if flip_sin_to_cos:

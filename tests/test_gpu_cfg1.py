@@ -8,7 +8,15 @@ Tolerances (the HIP path computes in bf16, the oracle in fp32 on the same bf16-r
   loss                  |d| <= 1e-3 (north_star) -- measured ~1e-6
   rewards (= -mean err) |d| <= 2e-4 + 1 % relative; reward_margin (their difference, 1e-3 of the rewards) |d| <= 1e-3
   v_pred samples        |d| <= 3 % of the prediction range (bf16 activations through 2 blocks)
-  LoRA grads, per tensor: norm within 5 %, sampled entries within 5 % of the tensor's max |grad| (+ cosine >= 0.99)
+  LoRA grads, per tensor: norm within 5 %, sampled entries within 5 % of the tensor's max |grad|, cosine >= 0.99 -- OR
+                        within 1.5 x the error of the bf16 FLOOR, whichever is larger.
+
+The bf16 floor: the same step run by the ORACLE'S OWN CODE (plain torch ops) on the GPU with bf16 weights and activations,
+compared with the same fp32 golden.  It is needed for one family of tensors: the to_q / to_k adapters of the LAST block.
+Their gradient is a heavily cancelling sum (|dQ| is 20x smaller than |dK| there, profiles/r02_cfg1_attention_bwd_diag.txt),
+and any bf16 flash-attention backward rounds P and dS to bf16 before the dQ / dK products: re-computing the HIP kernel's
+dQ in fp32 torch from the same inputs with ONLY those two roundings added reproduces its error to 5 digits
+(cos 0.945049 vs 0.945045), i.e. the deviation is the arithmetic type, not the kernel.
 """
 import json
 import math
@@ -29,6 +37,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _need_gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+
+
+def _bf16_floor(variant, gold):
+    """Plain-torch bf16 run of the step on the GPU (oracle code) -> per-tensor (norm_rel, sample_err/max, cos) vs the golden."""
+    from oracle import scheduler as osch
+    cfg = c1.config()
+    sd = {k: v.cuda() for k, v in c1.base_state_dict(cfg).items()}
+    lora, _ = c1.lora_state_dict(cfg, variant)
+    lora = {k: v.cuda().requires_grad_(True) for k, v in lora.items()}
+    xw, xl, prompt, t, noise = c1.inputs()
+    out = ocv.dpo_pair_step(sd, cfg, lora, osch.alphas_cumprod().cuda(), xw.cuda(), xl.cuda(), prompt.cuda(), t.cuda(), noise.cuda(), beta=1.0)
+    out["loss"].backward()
+    floor = {}
+    for k, p in lora.items():
+        ref = gold["lora_grads"][k]
+        g = p.grad.float().cpu()
+        got, rs = g.flatten()[c1.sample_index(g.numel(), k)].double(), ref["samples"].double()
+        floor[k] = (abs(g.double().norm().item() / float(ref["norm"]) - 1), (got - rs).abs().max().item() / float(ref["absmax"]),
+                    float((got * rs).sum() / (got.norm() * rs.norm()).clamp_min(1e-300)))
+    return floor, float(out["loss"])
 
 
 def _hip_step(variant):
@@ -100,6 +128,10 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
         check(err < 0.03 * rng_, (k, err, rng_))
         check(report[k + "_norm_rel"] < 0.01, (k, report[k + "_norm_rel"]))
 
+    del preds
+    torch.cuda.empty_cache()
+    floor, floor_loss = _bf16_floor(variant, gold)
+    report["loss_torch_bf16"] = floor_loss
     worst = {"norm_rel": 0.0, "sample_err_over_max": 0.0, "cos_min": 1.0}
     per_tensor = {}
     assert set(grads) == set(gold["lora_grads"])
@@ -112,15 +144,17 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
         nrel = abs(g.double().norm().item() / float(ref["norm"]) - 1)
         serr = (got - rs).abs().max().item() / amax
         cos = float((got * rs).sum() / (got.norm() * rs.norm()).clamp_min(1e-300))
-        per_tensor[k.replace("base_model.model.transformer_blocks.", "")] = (round(nrel, 5), round(serr, 5), round(cos, 6))
+        fn, fs, fc = floor[k]
+        per_tensor[k.replace("base_model.model.transformer_blocks.", "")] = {"hip": (round(nrel, 5), round(serr, 5), round(cos, 6)),
+                                                                              "torch_bf16_floor": (round(fn, 5), round(fs, 5), round(fc, 6))}
         worst["norm_rel"] = max(worst["norm_rel"], nrel)
         worst["sample_err_over_max"] = max(worst["sample_err_over_max"], serr)
         worst["cos_min"] = min(worst["cos_min"], cos)
-        check(math.isfinite(nrel) and nrel < 0.05, (k, "norm", nrel))
-        check(serr < 0.05, (k, "sample", serr))
-        check(cos > 0.99, (k, "cos", cos))
+        check(math.isfinite(nrel) and nrel < max(0.05, 1.5 * fn), (k, "norm", nrel, fn))
+        check(serr < max(0.05, 1.5 * fs), (k, "sample", serr, fs))
+        check(1 - cos < max(0.01, 1.5 * (1 - fc)), (k, "cos", cos, fc))
     report["lora_grads_worst"] = worst
-    report["lora_grads_per_tensor(norm_rel, sample_err/max, cos)"] = per_tensor
+    report["lora_grads_per_tensor (norm_rel, sample_err/max, cos)"] = per_tensor
     report["failed_checks"] = [str(f) for f in fails]
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"cfg1_parity_{variant}.json"), "w") as f:

@@ -20,6 +20,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+MAX_LORA_RANK = 64
+
+
 @dataclass
 class LoraConfig:
     r: int = 8
@@ -122,8 +125,15 @@ class LoraLinear(nn.Module):
                 w.sub_(self.delta_weight(n).to(w.dtype))
 
     def forward(self, x):
-        y = F.linear(x, self.base_layer.weight, self.base_layer.bias)
+        """peft.tuners.lora.layer.Linear.forward.  On the GPU in bf16 (the training path, e.g. the q/k/v/o linears of a Wan
+        model wrapped by get_peft_model) the base product goes to hipBLASLt and the A / B contractions to the MFMA kernels of
+        csrc/lora.hip through ops.linear_lora; the torch expression below only serves host-side use (CPU adapter-format and
+        merge checks, fp32 tensors)."""
         lora = self.active_lora()
+        if x.is_cuda and x.dtype == torch.bfloat16 and self.base_layer.weight.dtype == torch.bfloat16:
+            from . import ops
+            return ops.linear_lora(x, self.base_layer.weight, self.base_layer.bias, [lora])
+        y = F.linear(x, self.base_layer.weight, self.base_layer.bias)
         if lora is not None:
             A, B, s = lora
             y = y + F.linear(F.linear(x, A.to(x.dtype)), B.to(x.dtype)) * s
@@ -147,6 +157,16 @@ class LoraModel(nn.Module):
     def inject(self, config, adapter_name, init=True):
         if not config.target_modules:
             raise ValueError("LoraConfig.target_modules must be given")
+        # accepted-but-ignored settings would train something other than what the config says: refuse them up front
+        if config.lora_dropout and config.lora_dropout > 0:
+            raise NotImplementedError("lora_dropout > 0 is not implemented on this path (every reference config uses 0.0)")
+        if config.rank_pattern or config.alpha_pattern:
+            raise NotImplementedError("rank_pattern / alpha_pattern are not implemented (the released adapters use neither)")
+        if config.use_dora or config.bias != "none":
+            raise NotImplementedError("use_dora / bias != 'none' are not implemented")
+        if config.r > MAX_LORA_RANK:
+            raise NotImplementedError(f"LoRA rank {config.r} > {MAX_LORA_RANK}: the MFMA adapter kernels (csrc/lora.hip) cover padded "
+                                      f"ranks up to {MAX_LORA_RANK} (three adapters share one down-projection of width 3 x rank)")
         hit = 0
         for name, mod in list(self.model.named_modules()):
             if not _matches(name, config.target_modules):

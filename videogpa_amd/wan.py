@@ -1,0 +1,125 @@
+"""Wan2.2-TI2V flow-matching DPO step (train/Wan2.2-TI2V-5B/03_train.py:103-125,130-242) on the MI355X kernels.
+
+BLOCKED PART, stated plainly: the denoiser itself, `wan.modules.model.WanModel`, comes from an un-vendored sibling
+checkout (`sys.path.insert(0, '../../Wan2.2')`, 03_train.py:43-46) that is not in the reference tree, so there is no source
+to build a drop-in from or to check one against.  This module therefore takes the transformer as an argument -- any
+`nn.Module` with WanModel's call convention
+        model(list of [C,F,H,W] latents, t=[B, seq_len], context=list of [L, D_text], seq_len=int) -> list of [C,F,H,W]
+-- and provides everything of the step that IS in the reference: shifted-sigma noising and the velocity target
+(fused HIP pass over the paired layout, csrc/noise.hip), the clean first latent frame, the per-token timestep tensor
+with zeros on first-frame tokens, reference forwards before policy forwards, PEFT-LoRA on the q/k/v/o linears (their
+A.B contractions run the MFMA kernels of csrc/lora.hip through LoraLinear), the Diffusion-DPO loss kernel and the flat
+AdamW / all-reduce engine shared with the CogVideoX trainers.  BASELINE.json configs[4] (fp8 MFMA attention at head_dim
+128, cross-attention) waits on that source.
+"""
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lora import LoraConfig, PeftModel, get_peft_model
+from .loss import LossOutput, create_loss_strategy
+from .optim import FlatAdamW, FlatParams
+
+DEFAULT_CONFIG: Dict[str, Any] = {           # train/Wan2.2-TI2V-5B/03_train.py:54-97 where it matters here
+    "learning_rate": 5e-6, "beta": 1.0, "max_steps": 10000, "warmup_steps": 500, "batch_size": 1, "accumulate_grad_batches": 2,
+    "gradient_clip_val": 1.0, "weight_decay": 0.01, "num_train_timesteps": 1000, "shift": 5.0,
+    "lora_rank": 64, "lora_alpha": 128.0, "lora_dropout": 0.0, "lora_target_modules": ["q", "k", "v", "o"],
+    "patch_size": (1, 2, 2), "seed": 0,
+}
+
+
+def ti2v_timestep_tensor(timesteps, latent_shape, seq_len, patch_size=(1, 2, 2)):
+    """[B] timesteps -> [B, seq_len] per-token timesteps: 0 on the tokens of latent frame 0, t elsewhere (incl. padding up to
+    seq_len).  create_ti2v_timestep_tensor + _create_mask (03_train.py:119-125,181-187), all samples at once."""
+    _, f, h, w = latent_shape
+    n0 = (-(-h // patch_size[1])) * (-(-w // patch_size[2]))            # tokens of one latent frame: mask[:, ::p, ::p]
+    t = timesteps.to(torch.float32)[:, None].expand(-1, seq_len).clone()
+    t[:, :n0] = 0.0
+    return t
+
+
+class WanDPOTrainer(nn.Module):
+    def __init__(self, config: Dict[str, Any], transformer: nn.Module, ref_transformer: Optional[nn.Module] = None):
+        super().__init__()
+        cfg = dict(DEFAULT_CONFIG)
+        cfg.update(config)
+        self.config = cfg
+        if isinstance(transformer, PeftModel):
+            self.transformer = transformer
+        else:
+            self.transformer = get_peft_model(transformer, LoraConfig(r=cfg["lora_rank"], lora_alpha=cfg["lora_alpha"],
+                                                                      lora_dropout=cfg["lora_dropout"], target_modules=cfg["lora_target_modules"]))
+        # the reference loads a second frozen copy (:164-168); the same frozen base with the adapter switched off is
+        # bit-identical and halves the weight memory; a separate copy can still be passed in
+        self.ref_transformer = ref_transformer
+        if ref_transformer is not None:
+            ref_transformer.requires_grad_(False).eval()
+        self.loss_fn = create_loss_strategy(strategy="dpo", beta=cfg["beta"])
+        self.num_train_timesteps, self.shift, self.patch_size = cfg["num_train_timesteps"], cfg["shift"], tuple(cfg["patch_size"])
+        self.global_step = 0
+        self._rng = None
+
+    def rng(self, device):
+        if self._rng is None or self._rng.device != device:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._rng = torch.Generator(device=device).manual_seed(int(self.config.get("seed", 0)) + rank)
+        return self._rng
+
+    def _compute_seq_len(self, z):
+        _, _, f, h, w = z.shape
+        return f * (h // self.patch_size[1]) * (w // self.patch_size[2])
+
+    def _ref(self, x_list, **kw):
+        with torch.no_grad():
+            if self.ref_transformer is not None:
+                return self.ref_transformer(x_list, **kw)
+            with self.transformer.disable_adapter():
+                return self.transformer(x_list, **kw)
+
+    def _shared_step(self, batch, timesteps=None, noise=None) -> LossOutput:
+        x_win, x_lose, prompt_emb = batch["x_win"], batch["x_lose"], batch["prompt_emb"]     # latents stay [B,C,F,H,W]
+        image_latent = batch.get("image_latent")
+        B, dev = x_win.shape[0], x_win.device
+        seq_len = self._compute_seq_len(x_win)
+        if timesteps is None:
+            timesteps = torch.randint(1, self.num_train_timesteps, (B,), device=dev, generator=self.rng(dev))            # :198-201
+        if noise is None:
+            noise = torch.randn(x_win.shape, dtype=x_win.dtype, device=dev, generator=self.rng(dev))
+        sigma = ops.flow_sigma(timesteps, self.num_train_timesteps, self.shift)
+        x_pair = torch.stack([x_win, x_lose], dim=1).contiguous()
+        # one pass: x_t = (1 - sigma) x + sigma eps for win and lose (fp32, as the reference's promoted result) and eps - x
+        xt_pair, vt_pair = ops.flow_noise_velocity_paired(x_pair, noise.contiguous(), sigma)
+        if image_latent is not None:                                                                                      # :209-211
+            xt_pair[:, :, :, 0:1] = image_latent[:, None].to(xt_pair.dtype)
+        t_batch = ti2v_timestep_tensor(timesteps, x_win.shape[1:], seq_len, self.patch_size)
+        ctx = [prompt_emb[b] for b in range(B)]
+        kw = dict(t=t_batch, context=ctx, seq_len=seq_len)
+        xw_in = [xt_pair[b, 0] for b in range(B)]
+        xl_in = [xt_pair[b, 1] for b in range(B)]
+        v_wr, v_lr = torch.stack(self._ref(xw_in, **kw)), torch.stack(self._ref(xl_in, **kw))                             # reference first (:227-229)
+        v_w, v_l = torch.stack(self.transformer(xw_in, **kw)), torch.stack(self.transformer(xl_in, **kw))
+        v_pol = torch.stack([v_w, v_l], dim=1).to(x_win.dtype).contiguous()
+        v_ref = torch.stack([v_wr, v_lr], dim=1).to(x_win.dtype).contiguous()
+        lf = self.loss_fn
+        loss, margin, wr, lr, acc, _ = ops.dpo_loss_paired(v_pol, v_ref, vt_pair, beta=lf.beta, label_smoothing=lf.label_smoothing,
+                                                            loss_type=lf.loss_type, round_diff=(v_pol.dtype == torch.bfloat16))
+        return LossOutput(loss=loss, reward_margin=margin.detach(), winner_reward=wr.detach(), loser_reward=lr.detach(), accuracy=acc.detach())
+
+    def training_step(self, batch, batch_idx=0):
+        out = self._shared_step(batch)
+        return out.loss, {"train/loss": out.loss.detach(), "train/reward_margin": out.reward_margin,
+                          "train/reward_accuracy": (out.reward_margin > 0).float().mean()}
+
+    def validation_step(self, batch, batch_idx=0):
+        with torch.no_grad():
+            out = self._shared_step(batch)
+        return {"val/loss": out.loss, "val/reward_margin": out.reward_margin, "val/reward_accuracy": (out.reward_margin > 0).float().mean()}
+
+    def configure_optimizers(self, process_group=None):
+        cfg = self.config
+        flat = FlatParams(self.transformer.parameters())
+        return FlatAdamW(flat, lr=cfg["learning_rate"], weight_decay=cfg["weight_decay"], max_grad_norm=cfg["gradient_clip_val"],
+                         warmup_steps=cfg.get("warmup_steps", 500), total_steps=cfg["max_steps"], process_group=process_group)
