@@ -73,12 +73,15 @@ int32_t vgpa_ln_modulate_bwd(const void* dy, const void* x, const float* mean, c
 int32_t vgpa_residual_ln_fwd(const void* x, const void* y, const float* gate_v, const float* gate_t, int64_t gate_stride,
                              const float* ln_w, const float* ln_b, const float* shift_v, const float* scale1p_v,
                              const float* shift_t, const float* scale1p_t, int64_t mod_stride, int64_t B, int64_t S, int64_t D,
-                             int64_t text_len, float eps, void* x_new, void* n_out, float* mean, float* rstd,
-                             vgpa_stream_t stream);
+                             int64_t text_len, float eps, void* x_new, void* n_out,
+                             int64_t n_stride /* row stride of n_out in elements, >= D: n may be the head of a wider [rows, D+R]
+                                                 buffer whose tail carries LoRA down-projections */,
+                             float* mean, float* rstd, vgpa_stream_t stream);
 int32_t vgpa_residual_ln_bwd(const void* dn, const void* x_new, const float* mean, const float* rstd, const float* ln_w,
                              const float* scale1p_v, const float* scale1p_t, int64_t mod_stride, const float* gate_v,
                              const float* gate_t, int64_t gate_stride, const void* dres, int64_t B, int64_t S, int64_t D,
-                             int64_t text_len, void* dx, void* dy, vgpa_stream_t stream);
+                             int64_t text_len, void* dx, void* dy, int64_t dy_stride /* row stride of dy, >= D */,
+                             vgpa_stream_t stream);
 /* out = x + gate[range] * y (x NULL: out = gate * y, the backward of the y branch) */
 int32_t vgpa_gate_residual(const void* x, const void* y, const float* gate_v, const float* gate_t, int64_t mod_stride,
                            int64_t B, int64_t S, int64_t D, int64_t text_len, void* out, vgpa_stream_t stream);

@@ -26,8 +26,8 @@ SIGNATURES = {
     "vgpa_flow_noise_velocity_paired": (I32, [P, P, P, I64, I64, I32, I32, P, P, P]),
     "vgpa_ln_modulate_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P, P, P, P]),
     "vgpa_ln_modulate_bwd": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P]),
-    "vgpa_residual_ln_fwd": (I32, [P, P, P, P, I64, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P, P, P, P, P]),
-    "vgpa_residual_ln_bwd": (I32, [P, P, P, P, P, P, P, I64, P, P, I64, P, I64, I64, I64, I64, P, P, P]),
+    "vgpa_residual_ln_fwd": (I32, [P, P, P, P, I64, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P, P, I64, P, P, P]),
+    "vgpa_residual_ln_bwd": (I32, [P, P, P, P, P, P, P, I64, P, P, I64, P, I64, I64, I64, I64, P, P, I64, P]),
     "vgpa_gate_residual": (I32, [P, P, P, P, I64, I64, I64, I64, I64, P, P]),
     "vgpa_gelu_tanh_fwd": (I32, [P, I64, P, P]),
     "vgpa_gelu_tanh_bwd": (I32, [P, P, I64, P, P]),

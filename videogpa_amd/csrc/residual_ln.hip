@@ -54,7 +54,7 @@ __device__ __forceinline__ void params_global(const RLParams& P, int b, bool is_
 template <int NV, bool HAS_Y>
 __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, RLParams P,
                                                                          int text_len, int S, int D, int64_t rows, float eps,
-                                                                         bf16_t* __restrict__ x_new, bf16_t* __restrict__ n_out,
+                                                                         bf16_t* __restrict__ x_new, bf16_t* __restrict__ n_out, int64_t n_stride,
                                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     extern __shared__ __attribute__((aligned(16))) float sp[];   // [3][D]: alpha, beta, gate of the home range
     float* s_alpha = sp; float* s_beta = sp + D; float* s_gate = sp + 2 * D;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_fwd_kernel(const bf
                 if (home) { ld8(s_alpha + i0, a); ld8(s_beta + i0, be); } else params_global(P, b, is_text, i0, a, be, nullptr);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * a[j] + be[j];
-                *reinterpret_cast<u32x4_t*>(n_out + (size_t)row * D + i0) = pack8(o);
+                *reinterpret_cast<u32x4_t*>(n_out + (size_t)row * n_stride + i0) = pack8(o);
             }
         }
     }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_bwd_kernel(const bf
                                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                                          RLParams P, int text_len, int S, int D, int64_t rows,
                                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                                                         bf16_t* __restrict__ dy) {
+                                                                         bf16_t* __restrict__ dy, int64_t dy_stride) {
     extern __shared__ __attribute__((aligned(16))) float sp[];   // [2][D]: alpha, gate
     float* s_alpha = sp; float* s_gate = sp + D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_bwd_kernel(const bf
                 if (HAS_DY) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = gt[j] * o[j];
-                    *reinterpret_cast<u32x4_t*>(dy + (size_t)row * D + i0) = pack8(o);
+                    *reinterpret_cast<u32x4_t*>(dy + (size_t)row * dy_stride + i0) = pack8(o);
                 }
             }
         }
@@ -226,11 +226,13 @@ extern "C" {
 
 // x_new = x + gate[range]*y ; n = LN(x_new)*alpha + beta.  y (and gates, x_new) may be NULL: n = LN-modulate(x) only.
 // Modulation pointers may all be NULL (plain LayerNorm).  mean/rstd: fp32 [B,S] (both or neither).
+// n_stride: row stride of n_out in elements (>= D, multiple of 8): the consumer GEMM reads n as the first D columns of a wider
+// [rows, D + R] buffer whose tail carries the LoRA down-projections (the adapters ride the projection as extra K).
 int32_t vgpa_residual_ln_fwd(const void* x, const void* y, const float* gate_v, const float* gate_t, int64_t gate_stride, const float* ln_w,
                              const float* ln_b, const float* shift_v, const float* scale1p_v, const float* shift_t, const float* scale1p_t,
                              int64_t mod_stride, int64_t B, int64_t S, int64_t D, int64_t text_len, float eps, void* x_new, void* n_out,
-                             float* mean, float* rstd, hipStream_t stream) {
-    if (!x || !ln_w || !ln_b || !n_out) return VGPA_ERR_INVALID;
+                             int64_t n_stride, float* mean, float* rstd, hipStream_t stream) {
+    if (!x || !ln_w || !ln_b || !n_out || n_stride < D || n_stride % 8 != 0) return VGPA_ERR_INVALID;
     if (B <= 0 || S <= 0 || D <= 0 || D % 8 != 0 || D > 4096 || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
     if (y && (!gate_v || !x_new || (text_len > 0 && !gate_t))) return VGPA_ERR_INVALID;
     if (shift_v && (!scale1p_v || (text_len > 0 && (!shift_t || !scale1p_t)))) return VGPA_ERR_INVALID;
@@ -240,7 +242,7 @@ int32_t vgpa_residual_ln_fwd(const void* x, const void* y, const float* gate_v, 
     const dim3 grid((unsigned)((rows + RL_ROWS - 1) / RL_ROWS));
     const size_t shmem = (size_t)3 * D * sizeof(float);
 #define FWD_ARGS grid, dim3(64 * RL_WAVES), shmem, stream, (const bf16_t*)x, (const bf16_t*)y, P, (int)text_len, (int)S, (int)D, rows, eps, \
-                 (bf16_t*)x_new, (bf16_t*)n_out, mean, rstd
+                 (bf16_t*)x_new, (bf16_t*)n_out, n_stride, mean, rstd
     if (y) { RL_DISPATCH(D, VGPA_LAUNCH((residual_ln_fwd_kernel<NV, true>), FWD_ARGS)); }
     else { RL_DISPATCH(D, VGPA_LAUNCH((residual_ln_fwd_kernel<NV, false>), FWD_ARGS)); }
 #undef FWD_ARGS
@@ -249,10 +251,12 @@ int32_t vgpa_residual_ln_fwd(const void* x, const void* y, const float* gate_v, 
 }
 
 // dx = (dres ? dres : 0) + LN-backward(dn) ; dy = gate[range]*dx (dy, gates may be NULL).  x_new is the LN input.
+// dy_stride: row stride of dy in elements (>= D, multiple of 8; see n_stride above).
 int32_t vgpa_residual_ln_bwd(const void* dn, const void* x_new, const float* mean, const float* rstd, const float* ln_w, const float* scale1p_v,
                              const float* scale1p_t, int64_t mod_stride, const float* gate_v, const float* gate_t, int64_t gate_stride,
-                             const void* dres, int64_t B, int64_t S, int64_t D, int64_t text_len, void* dx, void* dy, hipStream_t stream) {
-    if (!dn || !x_new || !mean || !rstd || !ln_w || !dx) return VGPA_ERR_INVALID;
+                             const void* dres, int64_t B, int64_t S, int64_t D, int64_t text_len, void* dx, void* dy, int64_t dy_stride,
+                             hipStream_t stream) {
+    if (!dn || !x_new || !mean || !rstd || !ln_w || !dx || (dy && (dy_stride < D || dy_stride % 8 != 0))) return VGPA_ERR_INVALID;
     if (B <= 0 || S <= 0 || D <= 0 || D % 8 != 0 || D > 4096 || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
     if (dy && (!gate_v || (text_len > 0 && !gate_t))) return VGPA_ERR_INVALID;
     if (scale1p_v && text_len > 0 && !scale1p_t) return VGPA_ERR_INVALID;
@@ -261,7 +265,7 @@ int32_t vgpa_residual_ln_bwd(const void* dn, const void* x_new, const float* mea
     const dim3 grid((unsigned)((rows + RL_ROWS - 1) / RL_ROWS));
     const size_t shmem = (size_t)2 * D * sizeof(float);
 #define BWD_ARGS grid, dim3(64 * RL_WAVES), shmem, stream, (const bf16_t*)dn, (const bf16_t*)x_new, mean, rstd, P, (int)text_len, (int)S, (int)D, \
-                 rows, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dy
+                 rows, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dy, dy_stride
     if (dres && dy) { RL_DISPATCH(D, VGPA_LAUNCH((residual_ln_bwd_kernel<NV, true, true>), BWD_ARGS)); }
     else if (dres) { RL_DISPATCH(D, VGPA_LAUNCH((residual_ln_bwd_kernel<NV, true, false>), BWD_ARGS)); }
     else if (dy) { RL_DISPATCH(D, VGPA_LAUNCH((residual_ln_bwd_kernel<NV, false, true>), BWD_ARGS)); }

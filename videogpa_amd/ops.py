@@ -248,8 +248,8 @@ class _LNModulateFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
-def ln_modulate(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
-    return _ResidualLNFn.apply(x, None, None, ln_w, ln_b, mod, text_len, eps)[1]
+def ln_modulate(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5, n_pad=0):
+    return _ResidualLNFn.apply(x, None, None, ln_w, ln_b, mod, text_len, eps, n_pad, 0)[1]
 
 
 def ln_modulate_v1(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
@@ -268,10 +268,12 @@ class _ResidualLNFn(torch.autograd.Function):
     LN backward and the gate multiply.  y / gates may be None: plain LN-modulate of x (x_new is then x itself)."""
 
     @staticmethod
-    def forward(ctx, x, y, gates, ln_w, ln_b, mod, text_len, eps):
+    def forward(ctx, x, y, gates, ln_w, ln_b, mod, text_len, eps, n_pad, dy_pad):
+        """n_pad: n is returned as the first D columns of a fresh [B,S,D+n_pad] buffer (its consumer, linear_lora_ext, puts the
+        LoRA down-projections into the tail and runs ONE GEMM over K = D+n_pad); dy_pad: the same for the gradient of y."""
         _req(x, torch.bfloat16), _req(ln_w, torch.float32), _req(ln_b, torch.float32)
         B, S, D = x.shape
-        n = torch.empty_like(x)
+        n = torch.empty(B, S, D + n_pad, dtype=x.dtype, device=x.device)[..., :D] if n_pad else torch.empty_like(x)
         mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         sv, s1v, st, s1t, mstride = _mod_ptrs(mod)
@@ -283,11 +285,12 @@ class _ResidualLNFn(torch.autograd.Function):
             x_new, gv, gt, gstride = None, None, None, 0
         _timed("residual_ln_fwd" if y is not None else "ln_modulate_fwd", (8.0 if y is not None else 4.0) * B * S * D,
                lambda: _lib.call("vgpa_residual_ln_fwd", x, y, gv, gt, gstride, ln_w, ln_b, sv, s1v, st, s1t, mstride, B, S, D, text_len,
-                                 float(eps), x_new, n, mean, rstd, _stream()), "byte")
+                                 float(eps), x_new, n, D + n_pad, mean, rstd, _stream()), "byte")
         xs = x if y is None else x_new
         ctx.save_for_backward(xs, mean, rstd, ln_w, mod, gates if y is not None else None)
         ctx.text_len = text_len
         ctx.has_y = y is not None
+        ctx.dy_pad = dy_pad
         return x_new, n          # x_new is None when there is no y (plain LN-modulate)
 
     @staticmethod
@@ -300,21 +303,22 @@ class _ResidualLNFn(torch.autograd.Function):
         dres = None if dx_new is None else dx_new.contiguous()
         dx = torch.empty_like(xs)
         _, s1v, _, s1t, mstride = _mod_ptrs(mod)
+        dyp = ctx.dy_pad
         if ctx.has_y:
-            dy = torch.empty_like(xs)
+            dy = torch.empty(B, S, D + dyp, dtype=xs.dtype, device=xs.device)[..., :D] if dyp else torch.empty_like(xs)
             gv, gt, gstride = gates[:, 0], gates[:, 1], gates.stride(0)
         else:
             dy, gv, gt, gstride = None, None, None, 0
         passes = 3 + (1 if dres is not None else 0) + (1 if ctx.has_y else 0)     # dn, x, dx (+ dres) (+ dy)
         _timed("residual_ln_bwd" if ctx.has_y else "ln_modulate_bwd", 2.0 * passes * B * S * D,
                lambda: _lib.call("vgpa_residual_ln_bwd", dn, xs, mean, rstd, ln_w, s1v, s1t, mstride, gv, gt, gstride, dres, B, S, D,
-                                 ctx.text_len, dx, dy, _stream()), "byte")
-        return dx, dy, None, None, None, None, None, None
+                                 ctx.text_len, dx, dy, D + dyp, _stream()), "byte")
+        return dx, dy, None, None, None, None, None, None, None, None
 
 
-def residual_ln(x, y, gates, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
+def residual_ln(x, y, gates, ln_w, ln_b, mod=None, text_len=0, eps=1e-5, n_pad=0, dy_pad=0):
     """-> (x + gate*y, LN-modulate of that).  One HIP pass forward, one backward."""
-    return _ResidualLNFn.apply(x, y, gates, ln_w, ln_b, mod, text_len, eps)
+    return _ResidualLNFn.apply(x, y, gates, ln_w, ln_b, mod, text_len, eps, n_pad, dy_pad)
 
 
 class _GateResidualFn(torch.autograd.Function):
