@@ -502,3 +502,38 @@ def test_flow_matching_noise_velocity_bit_exact(ops):
         assert ref_xt.dtype == torch.float32 and xt.dtype == torch.float32
         assert torch.equal(xt[:, p].cpu(), ref_xt)
         assert torch.equal(v[:, p].cpu(), eps - x[:, p])
+
+
+def test_linear_lora_ext_padded_zero_copy_and_reference_pass(ops):
+    """The K-extension layout: LN output produced as the head of a [.., K+R] buffer is used in place (no copy), the adapter-off
+    pass (zero tail) equals the adapter-on pass with B = 0 BIT FOR BIT (policy == reference at initialisation -> loss = ln 2), and
+    the padded gradient buffers of residual_ln / qknorm_attention are recognised."""
+    g = torch.Generator().manual_seed(9)
+    Bt, S, K, N, r = 2, 50, 128, 256, 8
+    rp = 16
+    x = dev(torch.randn(Bt, S, K, generator=g).to(torch.bfloat16))
+    w, b = dev(1 + 0.1 * torch.randn(K, generator=g)), dev(0.1 * torch.randn(K, generator=g))
+    n = ops.ln_modulate(x, w, b, None, 0, 1e-5, n_pad=rp)
+    assert n.shape == (Bt, S, K) and n.stride() == (S * (K + rp), K + rp, 1)
+    base = ops._padded_base(n.reshape(-1, K), K + rp)
+    assert base is not None and base.data_ptr() == n.data_ptr()
+    n_plain = ops.ln_modulate(x, w, b, None, 0, 1e-5)
+    assert torch.equal(n, n_plain)
+    W = dev((torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16))
+    bias = dev(torch.randn(N, generator=g).to(torch.bfloat16))
+    A = dev(torch.randn(r, K, generator=g) / K ** 0.5)
+    B0 = torch.zeros(N, r, device="cuda")
+    B1 = dev(torch.randn(N, r, generator=g) * 0.3)
+    ext = ops.LoraExt()
+    y_off = ops.linear_lora_ext(n, W, bias, ext, [(A, B1, 2.0)], enabled=False)
+    ext0 = ops.LoraExt()
+    y_b0 = ops.linear_lora_ext(n, W, bias, ext0, [(A, B0, 2.0)], enabled=True)
+    assert torch.equal(y_off, y_b0)
+    y_on = ops.linear_lora_ext(n, W, bias, ext, [(A, B1, 2.0)], enabled=True)
+    ref = F.linear(n.double().cpu(), W.double().cpu(), bias.double().cpu()) + 2.0 * F.linear(
+        F.linear(n.double().cpu(), A.to(torch.bfloat16).double().cpu()), B1.to(torch.bfloat16).double().cpu())
+    assert (y_on.double().cpu() - ref).abs().max().item() < 0.02 * ref.abs().max().item()
+    # adapter values changed in place through raw pointers (the AdamW kernel): refreshed after bump_adapter_epoch()
+    B1.data.mul_(0.0)
+    ops.bump_adapter_epoch()
+    assert torch.equal(ops.linear_lora_ext(n, W, bias, ext, [(A, B1, 2.0)], enabled=True), y_b0)

@@ -132,7 +132,16 @@ class LoraLinear(nn.Module):
         lora = self.active_lora()
         if x.is_cuda and x.dtype == torch.bfloat16 and self.base_layer.weight.dtype == torch.bfloat16:
             from . import ops
-            return ops.linear_lora(x, self.base_layer.weight, self.base_layer.bias, [lora])
+            W, b = self.base_layer.weight, self.base_layer.bias
+            if self.merged or len(self.active_adapters) != 1:
+                return ops.frozen_linear(x, W, b)
+            n = self.active_adapters[0]
+            if getattr(self, "_ext", None) is None:
+                self._ext = ops.LoraExt()
+            # adapter switched off (frozen-reference pass): the SAME extended GEMM with a zero LoRA tail, so policy and reference
+            # share the base partial sums bit for bit (ops.LoraExt)
+            return ops.linear_lora_ext(x, W, b, self._ext, [(self.lora_A[n].weight, self.lora_B[n].weight, self.scaling[n])],
+                                       enabled=not self.disable_adapters)
         y = F.linear(x, self.base_layer.weight, self.base_layer.bias)
         if lora is not None:
             A, B, s = lora

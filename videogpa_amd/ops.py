@@ -451,81 +451,147 @@ def frozen_linear(x, W, bias):
     return _FrozenLinearFn.apply(x, W, bias)
 
 
-class _LinearLoraFn(torch.autograd.Function):
-    """y = x W^T + b, and for every output slice i that carries an adapter:  y_i += s_i * (x A_i^T) B_i^T
-    (PEFT Linear.forward; adapters are fp32 parameters cast to the activation dtype at use).  W/b are frozen:
-    backward produces dx and the adapter gradients only.  The dense projection goes to hipBLASLt; every LoRA
-    contraction runs the hand-written MFMA kernels of csrc/lora.hip, in place on column slices of y / dx, with one
-    shared down-projection for all adapters that read the same input (q, k, v)."""
+# The fused AdamW kernel writes adapter values through raw pointers (no autograd version bump): FlatAdamW.step calls
+# bump_adapter_epoch() so that the bf16 copies below are refreshed exactly once per optimizer step.
+ADAPTER_EPOCH = 0
+
+
+def bump_adapter_epoch():
+    global ADAPTER_EPOCH
+    ADAPTER_EPOCH += 1
+
+
+def _padded_base(t2, width):
+    """If the 2-D tensor `t2` [M, K] is the head of a contiguous [M, width] buffer (made by residual_ln / attention /
+    QK-norm backward with a pad), return that buffer as [M, width]; else None."""
+    b = t2._base
+    if b is None or b.shape[-1] != width or not b.is_contiguous() or b.data_ptr() != t2.data_ptr() or b.numel() != t2.shape[0] * width:
+        return None
+    return b.view(-1, width)
+
+
+class LoraExt:
+    """Operands of one LoRA-carrying projection with the adapters riding the dense GEMM as extra K:
+
+        forward :  y  = [x | T] [W | blockdiag(s_i B_i)]^T + b        T  = x A_cat^T            (lora_down)
+        backward:  dx = [dy | dT] [W^T | A_cat^T]^T                    dT_i = dy_i (s_i B_i)     (lora_down)
+
+    so the rank-r update costs (K + R) / K of one hipBLASLt GEMM instead of a read-modify-write pass over the [M, N] output
+    (the former lora_up_add kernel: 437 MB per launch at 2.3 TB/s), and it is added in the fp32 accumulator instead of after
+    a bf16 rounding of y.  The frozen-reference pass runs the SAME GEMM with a zero tail, so policy and reference share every
+    base partial sum bit for bit (loss = ln 2 exactly at B = 0).  bf16 operand copies are cached here and refreshed once per
+    optimizer step."""
+
+    def __init__(self):
+        self.fkey = self.akey = None
+
+    def refresh(self, W, n_slices, loras):
+        act = [i for i, l in enumerate(loras) if l is not None]
+        r = loras[act[0]][0].shape[0]
+        rp = _pad_rank(r)
+        R = len(act) * rp
+        N, K = W.shape
+        Dn = N // n_slices
+        dt, dev = W.dtype, W.device
+        fkey = (W.data_ptr(), W._version, tuple(act), rp, N, K)
+        if self.fkey != fkey:
+            self.W_ext = torch.zeros(N, K + R, dtype=dt, device=dev)
+            self.W_ext[:, :K] = W.detach()
+            self.Wt_ext = torch.zeros(K, N + R, dtype=dt, device=dev)
+            self.Wt_ext[:, :N] = W.detach().t()
+            self.A_cat = torch.zeros(R, K, dtype=dt, device=dev)
+            self.sBt = torch.zeros(len(act), rp, Dn, dtype=dt, device=dev)
+            self.fkey, self.akey = fkey, None
+            self.act, self.r, self.rp, self.R, self.N, self.K, self.Dn = act, r, rp, R, N, K, Dn
+        akey = (ADAPTER_EPOCH,) + tuple((loras[i][0].data_ptr(), loras[i][0]._version, loras[i][1]._version, float(loras[i][2])) for i in act)
+        if self.akey != akey:
+            with torch.no_grad():
+                for j, i in enumerate(act):
+                    A, Bm, sc = loras[i]
+                    if A.shape[0] != r:
+                        raise RuntimeError("adapters on one projection must share a rank")
+                    self.A_cat[j * rp:j * rp + r] = A.to(dt)
+                    sB = (Bm.to(dt).float() * sc).to(dt)                     # PEFT casts the adapter to the activation dtype first
+                    self.W_ext[i * Dn:(i + 1) * Dn, K + j * rp:K + j * rp + r] = sB
+                    self.sBt[j, :r] = sB.t()
+                self.Wt_ext[:, N:] = self.A_cat.t()
+            self.akey = akey
+        return self
+
+
+class _LinearLoraExtFn(torch.autograd.Function):
+    """y = x W^T + b (+ LoRA when `enabled`), W / b frozen; see LoraExt.  x / dy are used in place when they are the heads of
+    padded buffers (produced by ops.residual_ln / qknorm_attention with n_pad / o_pad / grad pads), copied into one otherwise."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, n_slices, scalings, *AB):
-        if W.requires_grad or (bias is not None and bias.requires_grad):
-            raise RuntimeError("videogpa_amd: base weights are frozen on this path (LoRA-only training, as in the reference)")
-        K = x.shape[-1]
+    def forward(ctx, x, bias, ext, enabled, scalings, *AB):
+        K, R, N = ext.K, ext.R, ext.N
         x2 = x.reshape(-1, K)
-        y = torch.nn.functional.linear(x2, W, bias)
-        Dn = y.shape[1] // n_slices
-        act = [i for i in range(n_slices) if AB[2 * i] is not None]
-        r = AB[2 * act[0]].shape[0]
-        rp = _pad_rank(r)
-        dt = x.dtype
-        a_cat = torch.zeros(len(act) * rp, K, dtype=dt, device=x.device)
-        bws = []
-        for j, i in enumerate(act):
-            A, Bm = AB[2 * i], AB[2 * i + 1]
-            if A.shape[0] != r:
-                raise RuntimeError("adapters on one projection must share a rank")
-            a_cat[j * rp:j * rp + r] = A.to(dt)
-            bw = torch.zeros(Dn, rp, dtype=dt, device=x.device)
-            bw[:, :r] = Bm.to(dt)
-            bws.append(bw)
-        t = lora_down(x2, a_cat)
-        for j, i in enumerate(act):
-            lora_up_add(y[:, i * Dn:(i + 1) * Dn], t[:, j * rp:(j + 1) * rp], bws[j], scalings[i])
-        ctx.save_for_backward(x2, W, a_cat, t, *bws)
-        ctx.meta = (n_slices, scalings, x.shape, act, r, rp)
-        return y.view(*x.shape[:-1], y.shape[1])
+        M = x2.shape[0]
+        x_ext = _padded_base(x2, K + R)
+        if x_ext is None:
+            x_ext = torch.empty(M, K + R, dtype=x.dtype, device=x.device)
+            x_ext[:, :K].copy_(x2)
+        xv, tv = x_ext[:, :K], x_ext[:, K:]
+        if enabled:
+            lora_down(xv, ext.A_cat, out=tv)
+        else:
+            tv.zero_()
+        y = torch.nn.functional.linear(x_ext, ext.W_ext, bias)
+        ctx.save_for_backward(x_ext)
+        ctx.ext, ctx.enabled, ctx.xshape, ctx.scalings = ext, enabled, x.shape, scalings
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        n, scalings, xshape, act, r, rp = ctx.meta
-        sv = ctx.saved_tensors            # read once: activation checkpointing unpacks saved tensors a single time
-        x2, W, a_cat, t = sv[:4]
-        bws = sv[4:]
-        dy2 = dy.reshape(-1, dy.shape[-1])
-        if dy2.stride(1) != 1:
-            dy2 = dy2.contiguous()
-        Dn = dy2.shape[1] // n
-        dx = _frozen_dx(dy2, W)
+        ext, enabled = ctx.ext, ctx.enabled
+        (x_ext,) = ctx.saved_tensors
+        K, R, N, Dn, rp, r, act = ext.K, ext.R, ext.N, ext.Dn, ext.rp, ext.r, ext.act
+        dy2 = dy.reshape(-1, N)
         M = dy2.shape[0]
-        dT = torch.empty(M, len(act) * rp, dtype=dy2.dtype, device=dy2.device)
-        grads = [None] * (2 * n)
-        for j, i in enumerate(act):
-            dyi = dy2[:, i * Dn:(i + 1) * Dn]
-            s = scalings[i]
-            lora_down(dyi, (bws[j] * s).t().contiguous(), out=dT[:, j * rp:(j + 1) * rp])       # dT_i = s * dy_i B_i
-            grads[2 * i + 1] = lora_grad(dyi, t[:, j * rp:(j + 1) * rp], s)[:, :r]               # dB_i = s * dy_i^T T_i
-        dA = lora_grad(dT, x2)                                                                     # dA = dT^T x (all adapters at once)
-        for j, i in enumerate(act):
-            grads[2 * i] = dA[j * rp:j * rp + r]
-        lora_up_add(dx, dT, a_cat.t().contiguous(), 1.0)                                           # dx += dT A
-        return (dx.view(xshape), None, None, None, None, *grads)
+        dy_ext = _padded_base(dy2, N + R) if dy2.stride(1) == 1 else None
+        if dy_ext is None:
+            dy_ext = torch.empty(M, N + R, dtype=dy.dtype, device=dy.device)
+            dy_ext[:, :N].copy_(dy2)
+        if enabled:
+            for j, i in enumerate(act):
+                lora_down(dy_ext[:, i * Dn:(i + 1) * Dn], ext.sBt[j], out=dy_ext[:, N + j * rp:N + (j + 1) * rp])      # dT_i = dy_i (s B_i)
+        else:
+            dy_ext[:, N:].zero_()
+        dx = torch.nn.functional.linear(dy_ext, ext.Wt_ext)                                                           # dy W + dT A
+        out_grads = [None] * len(ctx.needs_input_grad[5:])
+        if enabled:
+            for j, i in enumerate(act):
+                # dB_i = s dy_i^T T_i (T_i = x A_i^T sits in the tail of x_ext); the scale is applied to the fp32 result
+                out_grads[2 * i + 1] = lora_grad(dy_ext[:, i * Dn:(i + 1) * Dn], x_ext[:, K + j * rp:K + (j + 1) * rp], ctx.scalings[j])[:, :r]
+            dA = lora_grad(dy_ext[:, N:], x_ext[:, :K])                                                               # dT^T x, all adapters at once
+            for j, i in enumerate(act):
+                out_grads[2 * i] = dA[j * rp:j * rp + r]
+        return (dx.view(ctx.xshape), None, None, None, None, *out_grads)
 
 
-def linear_lora(x, W, bias, loras):
+def linear_lora_ext(x, W, bias, ext, loras, enabled=True):
+    """loras: list (one per equal output slice) of None or (A [r,in] fp32, B [out_i,r] fp32, scaling) -- the adapters that EXIST
+    on this projection; `enabled` False = the reference pass (same GEMM, zero LoRA tail)."""
+    if W.requires_grad or (bias is not None and bias.requires_grad):
+        raise RuntimeError("videogpa_amd: base weights are frozen on this path (LoRA-only training, as in the reference)")
+    ext.refresh(W, len(loras), loras)
+    flat = []
+    for l in loras:
+        flat += [None, None] if l is None else [l[0], l[1]]
+    return _LinearLoraExtFn.apply(x, bias, ext, bool(enabled), tuple(float(loras[i][2]) for i in ext.act), *flat)
+
+
+def linear_lora(x, W, bias, loras, ext=None):
     """loras: list (one per equal output slice) of None or (A [r,in] fp32, B [out_i,r] fp32, scaling)."""
     if all(l is None for l in loras):
         return frozen_linear(x, W, bias)
-    flat, sc = [], []
-    for l in loras:
-        if l is None:
-            flat += [None, None]
-            sc.append(0.0)
-        else:
-            flat += [l[0], l[1]]
-            sc.append(float(l[2]))
-    return _LinearLoraFn.apply(x, W, bias, len(loras), tuple(sc), *flat)
+    if ext is None:
+        ext = getattr(W, "_vgpa_lora_ext", None)
+        if ext is None:
+            ext = LoraExt()
+            W._vgpa_lora_ext = ext          # lives with the frozen weight
+    return linear_lora_ext(x, W, bias, ext, loras, True)
 
 
 # --------------------------------------------------------------------------------------------- attention
@@ -552,17 +618,20 @@ def prescale_q(q, scale=None):
     return (q.float() * (scale * LOG2E)).to(q.dtype)
 
 
-def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None):
+def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o_pad=0):
     """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32.
     split_mode: -1 lets the launcher cut the tasks of a mostly empty last scheduling round into key-range chunks,
-    0 forbids it, k >= 2 forces k chunks for every task (tests)."""
+    0 forbids it, k >= 2 forces k chunks for every task (tests).  o_pad: o is the head of a [B,S,H*64+o_pad] buffer (the
+    output projection's LoRA tail, see LoraExt)."""
     B, H, S, Dh = q.shape
     scale = Dh ** -0.5 if scale is None else scale
     if not q_prescaled:
         q = prescale_q(q, scale)
-    o = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=q.device)
+    o = torch.empty(B, S, H * Dh + o_pad, dtype=torch.bfloat16, device=q.device)
+    if o_pad:
+        o = o[..., :H * Dh]
     lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
-    ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
+    ov = o.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
     split_mode = ATTN_SPLIT_MODE if split_mode is None else split_mode
     ws_bytes = _lib.query("vgpa_attn_fwd_workspace_bytes", B, H, S) if split_mode != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
@@ -608,7 +677,9 @@ class _QKNormAttentionFn(torch.autograd.Function):
     QK-norm (+ optional 3D RoPE on tokens >= text_len) -> flash attention; backward returns dqkv in the same layout."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps):
+    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad):
+        """o_pad / grad_pad: the attention output / the gradient of qkv are returned as heads of buffers that much wider (the
+        LoRA tails of the projections on either side, see LoraExt)."""
         _req(qkv, torch.bfloat16)
         B, S, W = qkv.shape
         Dh = W // (3 * H)
@@ -619,35 +690,35 @@ class _QKNormAttentionFn(torch.autograd.Function):
         _timed("qknorm_rope_fwd", 8.0 * B * H * S * Dh, lambda: _lib.call(
             "vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
             wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), _stream()), "byte")
-        o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True)
+        o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad)
         ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
-        ctx.meta = (text_len, H, eps)
+        ctx.meta = (text_len, H, eps, grad_pad)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin = ctx.saved_tensors
-        text_len, H, eps = ctx.meta
+        text_len, H, eps, grad_pad = ctx.meta
         B, S, W = qkv.shape
         Dh = W // (3 * H)
         do = do.contiguous()
         qkv5 = qkv.view(B, S, 3, H, Dh)
         q_in, k_in, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        dqkv = torch.empty_like(qkv)
-        d5 = dqkv.view(B, S, 3, H, Dh)
+        dqkv = torch.empty(B, S, W + grad_pad, dtype=qkv.dtype, device=qkv.device)[..., :W] if grad_pad else torch.empty_like(qkv)
+        d5 = dqkv.unflatten(-1, (3, H, Dh))
         dq_in, dk_in, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         dqn = torch.empty_like(qn)
         dkn = torch.empty_like(kn)
-        ov = o.view(B, S, H, Dh).permute(0, 2, 1, 3)
+        ov = o.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
         dov = do.view(B, S, H, Dh).permute(0, 2, 1, 3)
         attention_bwd_raw(qn, kn, v, ov, dov, lse, dqn, dkn, dv, q_prescaled=True)
         _timed("qknorm_rope_bwd", 12.0 * B * H * S * Dh, lambda: _lib.call(
             "vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
             _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
             float(eps), _stream()), "byte")
-        return dqkv, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None
 
 
-def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6):
+def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0):
     cos, sin = (None, None) if rope is None else rope
-    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps)
+    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad)

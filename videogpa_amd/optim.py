@@ -108,6 +108,7 @@ class FlatAdamW:
         lr = self.lr
         self.step_count += 1
         self._apply_update(lr, scale)
+        ops.bump_adapter_epoch()      # the kernel wrote the adapters through raw pointers: refresh their cached bf16 copies (ops.LoraExt)
         return lr
 
     def _apply_update(self, lr, scale):
@@ -129,6 +130,7 @@ class FlatAdamW:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.flat.flat.copy_(sd["param"])
         self.step_count = int(sd["step_count"])
+        ops.bump_adapter_epoch()
 
     def zero_grad(self):
         self.flat.zero_grad()

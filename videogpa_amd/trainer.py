@@ -239,6 +239,7 @@ class DPOEngine:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             dist.broadcast(self.opt.flat.flat, src=0, group=process_group)
+        ops.bump_adapter_epoch()          # parameters were re-homed into the flat buffer (and possibly overwritten by rank 0's)
         self.opt.zero_grad()
 
     def micro_step(self, batch) -> Dict[str, Any]:

@@ -61,7 +61,12 @@ class Transformer3DModelOutput(SimpleNamespace):
 
 
 def _f32(t):
-    return t.detach().float().contiguous()
+    """fp32 copy of a (frozen) norm / modulation parameter for the kernels, cached on the parameter while it is unchanged."""
+    c = getattr(t, "_vgpa_f32", None)
+    if c is None or c[0] != t._version or c[1].device != t.device:
+        c = (t._version, t.detach().float().contiguous())
+        t._vgpa_f32 = c
+    return c[1]
 
 
 class CogVideoXPatchEmbed(nn.Module):
@@ -153,6 +158,17 @@ def _parts(mod):
     return mod.weight, mod.bias, None
 
 
+def _adapter(mod):
+    """((A, B, scaling) | None, enabled): the adapter that EXISTS on a wrapped linear (also while `disable_adapter()` is in
+    force -- the frozen-reference pass runs the same extended GEMM with a zero LoRA tail, see ops.LoraExt) and whether it is on."""
+    if not hasattr(mod, "base_layer") or mod.merged or not mod.active_adapters:
+        return None, False
+    if len(mod.active_adapters) != 1:
+        raise NotImplementedError("one active adapter at a time")
+    n = mod.active_adapters[0]
+    return (mod.lora_A[n].weight, mod.lora_B[n].weight, mod.scaling[n]), not mod.disable_adapters
+
+
 class Attention(nn.Module):
     def __init__(self, dim, heads, head_dim, bias, qk_eps=1e-6):
         super().__init__()
@@ -165,6 +181,7 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([nn.Linear(dim, dim, bias=True), nn.Dropout(0.0)])
         self.qk_eps = qk_eps
         self._fused = None
+        self._qkv_ext = self._out_ext = None
 
     def fused_qkv(self):
         """[3D, D] weight / [3D] bias, cached while the three base weights are unchanged (frozen base)."""
@@ -177,13 +194,40 @@ class Attention(nn.Module):
             self._fused = (key, W, b)
         return self._fused[1], self._fused[2]
 
+    def _lora_state(self):
+        """(adapters of q/k/v, adapter of to_out, enabled).  All wrapped linears of one attention share the on / off state."""
+        qa = [_adapter(m) for m in (self.to_q, self.to_k, self.to_v)]
+        oa = _adapter(self.to_out[0])
+        on = [e for a, e in qa + [oa] if a is not None]
+        return [a for a, _ in qa], oa[0], (bool(on) and all(on))
+
+    def pads(self):
+        """(in_pad, out_pad): widths of the LoRA tails after this attention's input n (q/k/v adapters) and after its output
+        (to_out adapter) -- what the producers of those tensors append so that the projections run as ONE extended GEMM."""
+        qa, oa, _ = self._lora_state()
+        act = [a for a in qa if a is not None]
+        in_pad = len(act) * ops._pad_rank(act[0][0].shape[0]) if act else 0
+        out_pad = ops._pad_rank(oa[0].shape[0]) if oa is not None else 0
+        return in_pad, out_pad
+
     def forward(self, n, text_len, rope):
         W, b = self.fused_qkv()
-        qkv = ops.linear_lora(n, W, b, [_parts(m)[2] for m in (self.to_q, self.to_k, self.to_v)])
+        qa, oa, on = self._lora_state()
+        in_pad, out_pad = self.pads()
+        if in_pad:
+            if self._qkv_ext is None:
+                self._qkv_ext = ops.LoraExt()
+            qkv = ops.linear_lora_ext(n, W, b, self._qkv_ext, qa, enabled=on)
+        else:
+            qkv = ops.frozen_linear(n, W, b)
         a = ops.qknorm_attention(qkv, _f32(self.norm_q.weight), _f32(self.norm_q.bias), _f32(self.norm_k.weight), _f32(self.norm_k.bias),
-                                 self.heads, text_len, rope, self.qk_eps)
-        wo, bo, lo = _parts(self.to_out[0])
-        return ops.linear_lora(a, wo, bo, [lo])
+                                 self.heads, text_len, rope, self.qk_eps, o_pad=out_pad, grad_pad=in_pad)
+        wo, bo, _ = _parts(self.to_out[0])
+        if out_pad:
+            if self._out_ext is None:
+                self._out_ext = ops.LoraExt()
+            return ops.linear_lora_ext(a, wo, bo, self._out_ext, [oa], enabled=on)
+        return ops.frozen_linear(a, wo, bo)
 
 
 class CogVideoXBlock(nn.Module):
@@ -202,16 +246,18 @@ class CogVideoXBlock(nn.Module):
     def norm1_params(self):
         return _f32(self.norm1.norm.weight), _f32(self.norm1.norm.bias)
 
-    def forward(self, x, n, gates1, mod2, gates2, text_len, rope, nxt_w, nxt_b, nxt_mod, nxt_eps):
+    def forward(self, x, n, gates1, mod2, gates2, text_len, rope, nxt_w, nxt_b, nxt_mod, nxt_eps, nxt_pad=0):
         """x: residual stream; n = norm1(x) already modulated (produced by the previous block's fused residual+LN pass).
         Returns (x_out, n_next) where n_next is the NEXT normalisation (next block's norm1, or the model's norm_final)
-        applied to x_out -- each gated residual add is fused with the LayerNorm that consumes it."""
+        applied to x_out -- each gated residual add is fused with the LayerNorm that consumes it.  nxt_pad: LoRA tail width the
+        next block's q/k/v projection wants behind n_next (Attention.pads)."""
         a = self.attn1(n, text_len, rope)
-        x, n2 = ops.residual_ln(x, a, gates1, _f32(self.norm2.norm.weight), _f32(self.norm2.norm.bias), mod2, text_len, self.eps)
+        x, n2 = ops.residual_ln(x, a, gates1, _f32(self.norm2.norm.weight), _f32(self.norm2.norm.bias), mod2, text_len, self.eps,
+                                dy_pad=self.attn1.pads()[1])
         u = ops.frozen_linear(n2, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
         g = ops.gelu_tanh(u)
         f = ops.frozen_linear(g, self.ff.net[2].weight, self.ff.net[2].bias)
-        return ops.residual_ln(x, f, gates2, nxt_w, nxt_b, nxt_mod, text_len, nxt_eps)
+        return ops.residual_ln(x, f, gates2, nxt_w, nxt_b, nxt_mod, text_len, nxt_eps, n_pad=nxt_pad)
 
 
 def timestep_sincos(t, dim, flip_sin_to_cos=True, freq_shift=0, max_period=10000):
@@ -329,14 +375,14 @@ class CogVideoXTransformer3DModel(nn.Module):
         blocks = self.transformer_blocks
         mods = [blk.modulations(emb) for blk in blocks]
         w0, b0 = blocks[0].norm1_params()
-        n = ops.ln_modulate(x, w0, b0, mods[0][0][0], Lt, cfg.norm_eps)
+        n = ops.ln_modulate(x, w0, b0, mods[0][0][0], Lt, cfg.norm_eps, n_pad=blocks[0].attn1.pads()[0])
         for i, blk in enumerate(blocks):
             (_, gates1), (mod2, gates2) = mods[i]
             if i + 1 < len(blocks):
-                (nw, nb), nmod = blocks[i + 1].norm1_params(), mods[i + 1][0][0]
+                (nw, nb), nmod, npad = blocks[i + 1].norm1_params(), mods[i + 1][0][0], blocks[i + 1].attn1.pads()[0]
             else:
-                (nw, nb), nmod = (_f32(self.norm_final.weight), _f32(self.norm_final.bias)), None
-            args = (x, n, gates1, mod2, gates2, Lt, rope, nw, nb, nmod, cfg.norm_eps)
+                (nw, nb), nmod, npad = (_f32(self.norm_final.weight), _f32(self.norm_final.bias)), None, 0
+            args = (x, n, gates1, mod2, gates2, Lt, rope, nw, nb, nmod, cfg.norm_eps, npad)
             if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
                 x, n = torch.utils.checkpoint.checkpoint(blk, *args, use_reentrant=False)
             else:
