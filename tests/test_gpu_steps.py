@@ -204,3 +204,41 @@ def test_wan_ti2v_step_logic_matches_oracle():
         err = (gp[n].double().cpu() - gr[n]).abs().max().item()
         assert err < 0.06 * gr[n].abs().max().item() + 1e-6, (n, err, gr[n].abs().max().item())
     assert math.isfinite(out.loss.item())
+
+
+def test_attention_processor_seam_matches_oracle_block_attention():
+    """diffusers' `attn.set_processor(P)` seam: P(attn, hidden_states, encoder_hidden_states, image_rotary_emb=...)
+    -> (hidden_states, encoder_hidden_states), text tokens first, LoRA wrappers honoured; against the oracle's attention half
+    of a block (oracle.cogvideox.block_forward capture)."""
+    from videogpa_amd.attn_processor import MI355XCogVideoXAttnProcessor, install
+    cfg, sd64, lora64, pm = _model(b_std=0.05, seed=2)
+    assert install(pm) == cfg.num_layers
+    blk = pm.transformer_blocks[0]
+    P = blk.attn1.processor
+    g = torch.Generator().manual_seed(8)
+    B, Sv, Lt, D = 2, 3 * 4 * 6, 6, cfg.inner_dim
+    hid = torch.randn(B, Sv, D, generator=g).to(torch.bfloat16)
+    enc = torch.randn(B, Lt, D, generator=g).to(torch.bfloat16)
+    cos, sin = ocv.rope_3d_tables(3, 4, 6, 64)
+    for rope in (None, (cos, sin)):
+        h_out, e_out = P(blk.attn1, hid.cuda(), enc.cuda(), image_rotary_emb=None if rope is None else (rope[0].cuda(), rope[1].cuda()))
+        assert h_out.shape == (B, Sv, D) and e_out.shape == (B, Lt, D)
+        # oracle: q, k, v -> QK-norm -> RoPE -> SDPA -> to_out on cat([enc, hid]) with the same adapters
+        b = "transformer_blocks.0."
+        x = torch.cat([enc, hid], dim=1).double()
+        q = ocv._lora_linear(x, sd64, lora64, b + "attn1.to_q", 2.0)
+        k = ocv._lora_linear(x, sd64, lora64, b + "attn1.to_k", 2.0)
+        v = ocv._lora_linear(x, sd64, lora64, b + "attn1.to_v", 2.0)
+        H = cfg.num_attention_heads
+        q, k, v = (t.view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+        q = ocv.layer_norm(q, sd64[b + "attn1.norm_q.weight"], sd64[b + "attn1.norm_q.bias"], cfg.qk_norm_eps)
+        k = ocv.layer_norm(k, sd64[b + "attn1.norm_k.weight"], sd64[b + "attn1.norm_k.bias"], cfg.qk_norm_eps)
+        if rope is not None:
+            q = torch.cat([q[:, :, :Lt], ocv.apply_rotary_emb(q[:, :, Lt:], cos.double(), sin.double())], dim=2)
+            k = torch.cat([k[:, :, :Lt], ocv.apply_rotary_emb(k[:, :, Lt:], cos.double(), sin.double())], dim=2)
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, -1, D)
+        o = ocv._lora_linear(o, sd64, lora64, b + "attn1.to_out.0", 2.0)
+        got = torch.cat([e_out, h_out], dim=1).double().cpu()
+        assert (got - o).abs().max().item() < 0.03 * o.abs().max().item()
+    with pytest.raises(NotImplementedError):
+        P(blk.attn1, hid.cuda(), enc.cuda(), attention_mask=torch.ones(1))

@@ -169,6 +169,68 @@ def _adapter(mod):
     return (mod.lora_A[n].weight, mod.lora_B[n].weight, mod.scaling[n]), not mod.disable_adapters
 
 
+class AttentionCore:
+    """The MI355X attention path over any module that carries diffusers' attention attributes (`to_q`, `to_k`, `to_v`, `norm_q`,
+    `norm_k`, `to_out[0]`, `heads`): fused-QKV GEMM with the LoRA adapters riding as extra K, QK-norm + RoPE + flash attention
+    kernels, output projection.  Used by this package's `Attention` module and by the diffusers-processor seam
+    (videogpa_amd/attn_processor.py); holds the caches that belong to one attention layer."""
+
+    def __init__(self, mod, qk_eps=None):
+        self.mod = mod
+        self.qk_eps = qk_eps if qk_eps is not None else getattr(mod.norm_q, "eps", 1e-6)
+        self._fused = None
+        self._qkv_ext = self._out_ext = None
+
+    def fused_qkv(self):
+        """[3D, D] weight / [3D] bias, cached while the three base weights are unchanged (frozen base)."""
+        m = self.mod
+        ws = [_parts(x)[0] for x in (m.to_q, m.to_k, m.to_v)]
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        if self._fused is None or self._fused[0] != key:
+            bs = [_parts(x)[1] for x in (m.to_q, m.to_k, m.to_v)]
+            W = torch.cat([w.detach() for w in ws], dim=0)
+            b = torch.cat([x.detach() for x in bs], dim=0) if bs[0] is not None else None
+            self._fused = (key, W, b)
+        return self._fused[1], self._fused[2]
+
+    def lora_state(self):
+        """(adapters of q/k/v, adapter of to_out, enabled).  All wrapped linears of one attention share the on / off state."""
+        m = self.mod
+        qa = [_adapter(x) for x in (m.to_q, m.to_k, m.to_v)]
+        oa = _adapter(m.to_out[0])
+        on = [e for a, e in qa + [oa] if a is not None]
+        return [a for a, _ in qa], oa[0], (bool(on) and all(on))
+
+    def pads(self):
+        """(in_pad, out_pad): widths of the LoRA tails after this attention's input n (q/k/v adapters) and after its output
+        (to_out adapter) -- what the producers of those tensors append so that the projections run as ONE extended GEMM."""
+        qa, oa, _ = self.lora_state()
+        act = [a for a in qa if a is not None]
+        in_pad = len(act) * ops._pad_rank(act[0][0].shape[0]) if act else 0
+        out_pad = ops._pad_rank(oa[0].shape[0]) if oa is not None else 0
+        return in_pad, out_pad
+
+    def forward(self, n, text_len, rope):
+        m = self.mod
+        W, b = self.fused_qkv()
+        qa, oa, on = self.lora_state()
+        in_pad, out_pad = self.pads()
+        if in_pad:
+            if self._qkv_ext is None:
+                self._qkv_ext = ops.LoraExt()
+            qkv = ops.linear_lora_ext(n, W, b, self._qkv_ext, qa, enabled=on)
+        else:
+            qkv = ops.frozen_linear(n, W, b)
+        a = ops.qknorm_attention(qkv, _f32(m.norm_q.weight), _f32(m.norm_q.bias), _f32(m.norm_k.weight), _f32(m.norm_k.bias),
+                                 m.heads, text_len, rope, self.qk_eps, o_pad=out_pad, grad_pad=in_pad)
+        wo, bo, _ = _parts(m.to_out[0])
+        if out_pad:
+            if self._out_ext is None:
+                self._out_ext = ops.LoraExt()
+            return ops.linear_lora_ext(a, wo, bo, self._out_ext, [oa], enabled=on)
+        return ops.frozen_linear(a, wo, bo)
+
+
 class Attention(nn.Module):
     def __init__(self, dim, heads, head_dim, bias, qk_eps=1e-6):
         super().__init__()
@@ -180,54 +242,22 @@ class Attention(nn.Module):
         self.norm_k = nn.LayerNorm(head_dim, eps=qk_eps)
         self.to_out = nn.ModuleList([nn.Linear(dim, dim, bias=True), nn.Dropout(0.0)])
         self.qk_eps = qk_eps
-        self._fused = None
-        self._qkv_ext = self._out_ext = None
+        self.core = AttentionCore(self, qk_eps)
+        self.processor = None
+
+    def set_processor(self, processor):
+        """diffusers' plugin point (`attn.set_processor(P)`): kept so that the seam object of videogpa_amd/attn_processor.py can
+        be installed on this module too (tests); None restores the built-in path."""
+        self.processor = processor
 
     def fused_qkv(self):
-        """[3D, D] weight / [3D] bias, cached while the three base weights are unchanged (frozen base)."""
-        ws = [_parts(m)[0] for m in (self.to_q, self.to_k, self.to_v)]
-        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
-        if self._fused is None or self._fused[0] != key:
-            bs = [_parts(m)[1] for m in (self.to_q, self.to_k, self.to_v)]
-            W = torch.cat([w.detach() for w in ws], dim=0)
-            b = torch.cat([x.detach() for x in bs], dim=0) if bs[0] is not None else None
-            self._fused = (key, W, b)
-        return self._fused[1], self._fused[2]
-
-    def _lora_state(self):
-        """(adapters of q/k/v, adapter of to_out, enabled).  All wrapped linears of one attention share the on / off state."""
-        qa = [_adapter(m) for m in (self.to_q, self.to_k, self.to_v)]
-        oa = _adapter(self.to_out[0])
-        on = [e for a, e in qa + [oa] if a is not None]
-        return [a for a, _ in qa], oa[0], (bool(on) and all(on))
+        return self.core.fused_qkv()
 
     def pads(self):
-        """(in_pad, out_pad): widths of the LoRA tails after this attention's input n (q/k/v adapters) and after its output
-        (to_out adapter) -- what the producers of those tensors append so that the projections run as ONE extended GEMM."""
-        qa, oa, _ = self._lora_state()
-        act = [a for a in qa if a is not None]
-        in_pad = len(act) * ops._pad_rank(act[0][0].shape[0]) if act else 0
-        out_pad = ops._pad_rank(oa[0].shape[0]) if oa is not None else 0
-        return in_pad, out_pad
+        return self.core.pads()
 
     def forward(self, n, text_len, rope):
-        W, b = self.fused_qkv()
-        qa, oa, on = self._lora_state()
-        in_pad, out_pad = self.pads()
-        if in_pad:
-            if self._qkv_ext is None:
-                self._qkv_ext = ops.LoraExt()
-            qkv = ops.linear_lora_ext(n, W, b, self._qkv_ext, qa, enabled=on)
-        else:
-            qkv = ops.frozen_linear(n, W, b)
-        a = ops.qknorm_attention(qkv, _f32(self.norm_q.weight), _f32(self.norm_q.bias), _f32(self.norm_k.weight), _f32(self.norm_k.bias),
-                                 self.heads, text_len, rope, self.qk_eps, o_pad=out_pad, grad_pad=in_pad)
-        wo, bo, _ = _parts(self.to_out[0])
-        if out_pad:
-            if self._out_ext is None:
-                self._out_ext = ops.LoraExt()
-            return ops.linear_lora_ext(a, wo, bo, self._out_ext, [oa], enabled=on)
-        return ops.frozen_linear(a, wo, bo)
+        return self.core.forward(n, text_len, rope)
 
 
 class CogVideoXBlock(nn.Module):
