@@ -119,3 +119,76 @@ def test_tail_round_split_at_the_headline_launch_shape(ops):
         scale = b.float().abs().max().item()
         assert (a.float() - b.float()).abs().max().item() < 0.02 * scale + 1e-4
         assert torch.isfinite(a).all()
+
+
+# ---------------------------------------------------------------- BASELINE configs[3]: CogVideoX1.5-5B, S = 41 026 tokens
+S4 = 41026        # 226 text + (20/2) x 48 x 85 video tokens (81f x 768 x 1360, 21 latent frames even-cropped to 20, patch_size_t 2)
+
+
+def test_cfg4_attention_properties_at_41026_tokens(ops):
+    """The attention kernels at the config-4 sequence length (6 heads are enough for the properties; the launch geometry per
+    head is the same): row-stochastic softmax, sum_k dV = sum_q dO, sum_k dK = 0, and forward / backward consistency of the
+    tail-split launch."""
+    Hh = 6
+    g = torch.Generator(device="cuda").manual_seed(12)
+    q, k, v, do = (torch.randn(1, Hh, S4, 64, generator=g, device="cuda").to(torch.bfloat16) for _ in range(4))
+    c = torch.linspace(-2, 2, 64, device="cuda").to(torch.bfloat16)
+    o, _ = ops.attention_fwd_raw(q, k, c.expand(1, Hh, S4, 64).contiguous())
+    assert (o.view(1, S4, Hh, 64).float() - c.float()).abs().max().item() <= 0.016
+    o, lse = ops.attention_fwd_raw(q, k, v)
+    ov = o.view(1, S4, Hh, 64).permute(0, 2, 1, 3)
+    dq, dk, dv = (torch.empty(1, Hh, S4, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    ops.attention_bwd_raw(q, k, v, ov, do, lse, dq, dk, dv)
+    sdv, sdo = dv.float().sum(2), do.float().sum(2)
+    assert (sdv - sdo).abs().max().item() < 0.02 * sdo.abs().max().item() + 0.8
+    assert dk.float().sum(2).abs().max().item() < 0.02 * dk.float().abs().sum(2).max().item() + 0.05
+    assert torch.isfinite(dq).all() and dq.float().abs().max().item() > 0
+
+
+def test_cfg4_checkpointed_block_step_at_41026_tokens(ops):
+    """One CogVideoX1.5-shaped block (D = 3072, 48 heads, patch_size_t = 2 geometry: [1,2,21,16,96,170] -> crop -> S = 41 026) through the
+    1.5 step with per-block recompute (what configs[3] needs beyond ~22k tokens): loss = ln 2 exactly at B = 0, finite adapter
+    gradients only in lora_B, and recompute on / off give bit-identical gradients."""
+    from videogpa_amd.lora import LoraConfig, get_peft_model
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    from videogpa_amd.transformer import COGVIDEOX_1_5_5B, CogVideoXTransformer3DModel
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device("cuda"):
+            model = CogVideoXTransformer3DModel(**dict(COGVIDEOX_1_5_5B, num_layers=1))
+    finally:
+        torch.set_default_dtype(prev)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("norm.weight") or n == "norm_final.weight" or ".norm_q.weight" in n or ".norm_k.weight" in n:
+                p.fill_(1.0)
+            elif n.endswith(".bias"):
+                p.normal_(0.0, 0.02, generator=g)
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+    pm = get_peft_model(model, LoraConfig(r=64, lora_alpha=128, target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    x_pair = (0.7 * torch.randn(1, 2, 21, 16, 96, 170, generator=g, device="cuda")).to(torch.bfloat16)      # frame-major pair: not permuted, cropped to 20
+    prompt = (0.2 * torch.randn(1, 226, 4096, generator=g, device="cuda")).to(torch.bfloat16)
+    t = torch.tensor([500], device="cuda")
+    eps = torch.randn(1, 20, 16, 96, 170, generator=g, device="cuda").to(torch.bfloat16)
+    grads = []
+    for ckpt in (True, False):
+        tr = CogVideoXDPOTrainer({"beta": 1.0, "enable_gradient_checkpointing": ckpt}, transformer=pm)
+        if not ckpt:
+            pm.disable_gradient_checkpointing()
+        tr.train()
+        for p in pm.parameters():
+            p.grad = None
+        out = tr._shared_step({"x_pair": x_pair, "prompt_emb": prompt}, timesteps=t, noise=eps)
+        assert abs(out.loss.item() - math.log(2.0)) < 1e-6              # B = 0: policy == reference bit for bit, also at S = 41 026
+        out.loss.backward()
+        gd = {n: p.grad.clone() for n, p in pm.named_parameters() if p.grad is not None}
+        assert len(gd) == 8 and all(torch.isfinite(v).all() for v in gd.values())
+        assert all(float(v.abs().max()) == 0 for n, v in gd.items() if "lora_A" in n)       # dA = dT^T x with dT = dy B = 0
+        assert any(float(v.abs().max()) > 0 for n, v in gd.items() if "lora_B" in n)
+        grads.append(gd)
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
