@@ -37,7 +37,7 @@ CONFIGS = {
                  label="BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720"),
     "cfg3": dict(model="COGVIDEOX_5B_I2V", frames=13, height=60, width=90, checkpoint=False, cond=True,
                  label="BASELINE configs[2]: CogVideoX-5B-I2V (32 input channels, learned positional table), 49f x 480x720 + image-cond latent"),
-    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=True, cond=False,
+    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=True, checkpoint_stride=2, cond=False,
                  label="BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t=2), 81f x 768x1360 (21 latent frames, even-cropped to 20)"),
 }
 
@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--rank-r", type=int, default=64)
     ap.add_argument("--checkpoint", action="store_true", default=None, help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
+    ap.add_argument("--checkpoint-stride", type=int, default=None, help="with --checkpoint: recompute only every k-th block (1 = all, like the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -200,11 +201,12 @@ def main():
     H_ = C["height"] if args.height is None else args.height
     W_ = C["width"] if args.width is None else args.width
     ckpt = C["checkpoint"] if args.checkpoint is None else args.checkpoint
+    ckpt_stride = (C.get("checkpoint_stride", 1) if args.checkpoint_stride is None else args.checkpoint_stride) if ckpt else 1
     cfg_kw = dict(getattr(vtr, C["model"]), num_layers=args.layers)
     torch.manual_seed(0)                           # identical adapter init (PEFT kaiming-uniform A) on every rank
     model = build_model(cfg_kw, dev, seed=0)       # identical base weights on every rank
     trainer = CogVideoXDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2 * args.rank_r, "beta": 1.0, "accumulate_grad_batches": 1,
-                                   "enable_gradient_checkpointing": ckpt, "seed": 1234}, transformer=model)
+                                   "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": ckpt_stride, "seed": 1234}, transformer=model)
     # LoRA B ~ N(0, 1e-3) so the step is beyond the trivial B=0 point
     gB = torch.Generator(device=dev).manual_seed(1)
     with torch.no_grad():
@@ -261,7 +263,8 @@ def main():
             "config": {"workload": (C["label"] + " -> " if named else "NOT a BASELINE config (debug flags): CogVideoX-5B-shaped transformer, ")
                                    + f"paired latents [1,2,{F_},16,{H_},{W_}], S={S} tokens, {args.layers} blocks, LoRA r={args.rank_r} on "
                                    "to_q/to_k/to_v/to_out.0, 1 pair/GPU/step, optimizer step every step; random-init weights"
-                                   + ("; per-block activation recompute" if ckpt else ""),
+                                   + (f"; activation recompute of every {ckpt_stride}. block" if ckpt and ckpt_stride > 1 else
+                                      "; per-block activation recompute" if ckpt else ""),
                        "name": args.config, "layers": args.layers, "tokens": S, "pairs_per_gpu": 1, "parallelism": f"dp{world}"},
             "loss": float(logs["train/loss"]), "loss_rank_mean": sync[0],
             "step_flops_algorithmic": F_step,

@@ -148,7 +148,7 @@ def test_cfg4_attention_properties_at_41026_tokens(ops):
 def test_cfg4_checkpointed_block_step_at_41026_tokens(ops):
     """One CogVideoX1.5-shaped block (D = 3072, 48 heads, patch_size_t = 2 geometry: [1,2,21,16,96,170] -> crop -> S = 41 026) through the
     1.5 step with per-block recompute (what configs[3] needs beyond ~22k tokens): loss = ln 2 exactly at B = 0, finite adapter
-    gradients only in lora_B, and recompute on / off give bit-identical gradients."""
+    gradients only in lora_B, and recompute on / off give the same gradients (to fp32 summation order)."""
     from videogpa_amd.lora import LoraConfig, get_peft_model
     from videogpa_amd.trainer import CogVideoXDPOTrainer
     from videogpa_amd.transformer import COGVIDEOX_1_5_5B, CogVideoXTransformer3DModel
@@ -190,5 +190,6 @@ def test_cfg4_checkpointed_block_step_at_41026_tokens(ops):
         assert all(float(v.abs().max()) == 0 for n, v in gd.items() if "lora_A" in n)       # dA = dT^T x with dT = dy B = 0
         assert any(float(v.abs().max()) > 0 for n, v in gd.items() if "lora_B" in n)
         grads.append(gd)
-    for n in grads[0]:
-        assert torch.equal(grads[0][n], grads[1][n]), n
+    for n in grads[0]:       # same kernels and inputs; the token-contracted fp32 atomics of lora_grad leave summation-order noise
+        a, b = grads[0][n].double(), grads[1][n].double()
+        assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-12, n

@@ -66,7 +66,7 @@ class CogVideoXDPOTrainer(nn.Module):
                                      target_modules=cfg["lora_target_modules"])
             self.transformer = get_peft_model(transformer, lora_config)
         if cfg.get("enable_gradient_checkpointing"):
-            self.transformer.enable_gradient_checkpointing()
+            self.transformer.enable_gradient_checkpointing(stride=int(cfg.get("gradient_checkpointing_stride", 1)))
         self.ref_transformer = None
         if separate_ref:  # the reference's layout: a second frozen copy (:110-111)
             import copy

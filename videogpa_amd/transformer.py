@@ -335,8 +335,12 @@ class CogVideoXTransformer3DModel(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def enable_gradient_checkpointing(self):
+    def enable_gradient_checkpointing(self, stride=1):
+        """diffusers' switch (train/CogVideoX-5B/03_train.py:107-108).  stride = 1 recomputes every block like the reference;
+        stride = k > 1 recomputes only blocks 0, k, 2k, ... and keeps the activations of the others -- 288 GB of HBM3E usually
+        has room for most of them (config 4, S = 41 026: every 2nd block recomputed fits in ~170 GB)."""
         self.gradient_checkpointing = True
+        self.checkpoint_stride = max(1, int(stride))
 
     def disable_gradient_checkpointing(self):
         self.gradient_checkpointing = False
@@ -413,7 +417,7 @@ class CogVideoXTransformer3DModel(nn.Module):
             else:
                 (nw, nb), nmod, npad = (_f32(self.norm_final.weight), _f32(self.norm_final.bias)), None, 0
             args = (x, n, gates1, mod2, gates2, Lt, rope, nw, nb, nmod, cfg.norm_eps, npad)
-            if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
+            if self.gradient_checkpointing and self.training and torch.is_grad_enabled() and i % getattr(self, "checkpoint_stride", 1) == 0:
                 x, n = torch.utils.checkpoint.checkpoint(blk, *args, use_reentrant=False)
             else:
                 x, n = blk(*args)
