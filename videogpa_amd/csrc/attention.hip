@@ -19,6 +19,7 @@
 //    that XCD's private L2.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "mfma_tiles.h"
@@ -625,6 +626,340 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
     const int b = bh / H, h = bh % H;
     O[(size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + lane] = f32_to_bf16(acc / L);
     if (lane == 0) LSE2[(int64_t)bh * S + q] = M + __builtin_amdgcn_logf(L);
+}
+
+// =====================================================================================================
+// Forward, PING-PONG (selected by VGPA_ATTN_FWD=pp).  The forward is VALU-issue bound at head_dim 64: per 64 x 64 score tile a
+// wave has ~1150 matrix-pipe cycles (36 MFMAs) and ~1300-1450 VALU cycles (64 exp, 64 adds, 32 packs per lane), and inside ONE wave
+// they overlap badly (the dependent chain MFMA -> exp -> pack -> MFMA); two free-running waves on a SIMD do not phase-lock either
+// (2120 SIMD-cycles per wave-tile against ~1250 for a perfectly overlapped pair).  Here the overlap is made explicit
+// ACROSS the two waves of a SIMD: a 512-thread workgroup = 8 waves, waves 0-3 (group 0) and 4-7 (group 1) run the same sequence
+//       M(t): S_t = K_t Q^T (with -m folded in)  and  O += V_{t-1}^T P_{t-1}^T         36 MFMAs + LDS fragment reads, no VALU
+//       V(t): P_t = exp2(S_t), row sums, the max check, pack to bf16                      VALU only
+// one phase apart, with a workgroup barrier after every phase -- so on every SIMD one wave is always in an M phase while its partner
+// is in a V phase, and a pure-MFMA wave next to a pure-VALU wave co-issue almost perfectly (tools/ubench_mix).  The K / V tiles are
+// staged once per workgroup for 512 query rows (half the LDS fill traffic per row of the 4-wave kernels): 3-slot rings, the global
+// loads of tile t+2 (K) / t+1 (V) are issued by all threads in even phases and stored in odd phases, which no reader of the slot can
+// overlap (see the slot arithmetic at stage_store).  Softmax bookkeeping is the checked form of attn_fwd_kernel (V1): P is formed
+// against the running max folded into the MFMA chain; a tile sum above PSUM_TRIGGER (and the first / ragged tile) takes the slow
+// path -- recompute S, exact max, rescale -- inside the V phase (rare).
+//
+// MEASURED (MI355X, headline shape, profiles/r02g_pingpong_forward.txt) -- a NEGATIVE result, kept selectable and parity-tested like
+// the fused backward: 8.0-8.4 ms against 7.0 ms for attn_fwd_pipe_kernel.  Ablations of this kernel: V phases only (no MFMA issued)
+// 4.65 ms, M phases only (no exp / sums / packs) 6.77 ms, both 8.2 ms.  The M phase alone needs ~1800 cycles for its 1152 cycles of
+// MFMAs: the wave has the matrix pipe to itself, so every LDS fragment round trip (24 reads per tile, issued just in time because the
+// allocator is at 256 VGPRs with spills) is exposed -- in the free-running kernels the SIMD partner fills exactly those bubbles.
+// Requesting all fragments of a phase up front needs ~64 more registers than a QB = 2 wave has (tried: 49 spills); QB = 1 has the
+// registers but reads one LDS fragment per MFMA (LDS ~80 % busy).  s_setprio(3) around the M phase made it slower (8.8 ms).  The
+// wave -> SIMD map needed for the pairing is (w, w + 4) on this part (tools/hwid_probe: 1024 of 1024 workgroups), read from HW_ID.
+// =====================================================================================================
+#define PP_NW 8
+__device__ __forceinline__ void pp_barrier() {
+    // LDS traffic of this phase must be complete; the global loads in flight (next tiles) deliberately cross the barrier
+#ifdef PP_NO_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+#ifdef PP_NO_MFMA   // timing experiment only: the M phase keeps its LDS reads but issues no MFMA
+__device__ __forceinline__ f32x16_t pp_fake_mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+#define PP_MFMA pp_fake_mfma
+#else
+#define PP_MFMA mfma32
+#endif
+template <int QB, bool DO_S, bool DO_PV>
+__device__ __forceinline__ void pp_phase_m(const bf16_t* kl, const bf16_t* vl, int lane, const bf16x8_t& kx, const bf16x8_t (&qx)[QB],
+                                           const bf16x8_t (&qf)[QB][4], const bf16x8_t (&pf)[QB][2][2], f32x16_t (&s)[QB][2],
+                                           f32x16_t (&o)[QB][2]) {
+    // All PV products first (they consume the packed P_{t-1}; 4 independent accumulators o[j][db]), then the new scores with the
+    // two key halves interleaved (4 independent accumulators s[j][kb]): consecutive MFMAs never depend on each other, and the packed
+    // P is dead before any score register is written again (the allocator can give both the same registers).
+    if (DO_PV) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8_t vf = frag_tr(vl, kb * 32 + 16 * cc, db * 32, lane);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) o[j][db] = PP_MFMA(vf, pf[j][kb][cc], o[j][db]);
+                }
+    }
+    if (DO_S) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
+                s[j][kb] = PP_MFMA(kx, qx[j], s[j][kb]);                     // - m
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) s[j][kb] = PP_MFMA(kf, qf[j][ks], s[j][kb]);
+            }
+    }
+}
+
+template <int QB>
+__device__ __forceinline__ void pp_phase_v(const bf16_t* kl, int t, int S, bool force_slow, bool tail, int lane, int hi, const bf16x8_t (&qf)[QB][4],
+                                           bf16x8_t (&qx)[QB], float (&m)[QB], float (&l)[QB], f32x16_t (&o)[QB][2], f32x16_t (&s)[QB][2],
+                                           bf16x8_t (&pf)[QB][2][2]) {
+    float psum[QB];
+    bool slow = force_slow;
+#ifdef PP_NO_V   // timing experiment only
+    if (!slow) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            psum[j] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) asm volatile("" : "=v"(pf[j][kb][cc]) : "v"(s[j][kb]));
+            l[j] += 1.f;
+        }
+        return;
+    }
+#endif
+    if (!slow) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+#ifdef PP_NO_EXP
+                    const float a = s[j][kb][r] * 1e-9f, b = s[j][kb][r + 1] * 1e-9f;
+#else
+                    const float a = __builtin_amdgcn_exp2f(s[j][kb][r]), b = __builtin_amdgcn_exp2f(s[j][kb][r + 1]);
+#endif
+                    s[j][kb][r] = a;
+                    s[j][kb][r + 1] = b;
+                    p0 = nopack_add(p0, a);
+                    p1 = nopack_add(p1, b);
+                }
+            psum[j] = p0 + p1;
+            slow = slow || !(psum[j] <= PSUM_TRIGGER);
+        }
+        slow = __any(slow);
+    }
+    if (slow) {   // first tile, ragged tile, or a row outgrew its running max: exact max, raise m, rescale (MFMAs in a V phase: rare)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            if (tail) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * TILE + kb * 32 + acc_row(r, hi) >= S) s[j][kb][r] = -INFINITY;
+            }
+            float mx = s[j][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[j][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][1][r]);
+            mx = fmaxf(mx, other_half(mx));
+            const float m_new = fmaxf(m[j], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
+            m[j] = m_new;
+            qx[j] = shift_frag(m_new, hi);
+            l[j] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[j][0][i] *= alpha; o[j][1][i] *= alpha; }
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[j][kb][r] - m_new);
+                    s[j][kb][r] = pv;
+                    ps += pv;
+                }
+            psum[j] = ps;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        l[j] += psum[j];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) pf[j][kb][cc] = pack_frag(s[j][kb], 8 * cc);
+    }
+}
+
+template <int QB>
+__global__ __launch_bounds__(64 * PP_NW, 2) void attn_fwd_pp_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                     const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                                     float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
+                                                                     int S, int H, int n_qt) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[6 * TILE_ELEMS];   // K ring [3], V ring [3]
+    __shared__ int simd_of[PP_NW];
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int q0 = (qt * PP_NW + wave) * (32 * QB);
+    {   // which SIMD did the hardware put this wave on?  (HW_ID bits [5:4]; the wave -> SIMD map is not architected)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (lane == 0) simd_of[wave] = (int)((hwid >> 4) & 3u);
+    }
+
+    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
+    bf16_t* const kring = lds;
+    bf16_t* const vring = lds + 3 * TILE_ELEMS;
+
+    bf16x8_t qf[QB][4], qx[QB], pf[QB][2][2];
+    f32x16_t o[QB][2], s[QB][2];
+    float m[QB], l[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        load_row_frags(Qb, sq.s, q0 + 32 * j, S, lane, qf[j]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
+        m[j] = -INFINITY;
+        l[j] = 0.f;
+        qx[j] = shift_frag(0.f, hi);
+    }
+    bf16x8_t kx;
+    {
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
+        kx = f32_to_frag(o8);
+    }
+    const int nt = (S + TILE - 1) / TILE;
+    const bool ragged = (S & (TILE - 1)) != 0;
+    const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
+    const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
+    u32x4_t kr[1], vr[1];
+    // prologue: K_0, K_1, V_0 (rows past S read as zeros)
+    tile_load_buf(krs, sk.s, 0, koff, kr);
+    tile_store(kring, kr);
+    tile_load_buf(krs, sk.s, TILE, koff, kr);
+    tile_store(kring + TILE_ELEMS, kr);
+    tile_load_buf(vrs, sv.s, 0, voff, vr);
+    tile_store(vring, vr);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) frags_arrived(qf[j]);
+    __syncthreads();
+    // group = rank of this wave among the waves that share its SIMD (2 waves per SIMD at 256 VGPRs): the two partners of a SIMD are
+    // always in opposite phases.  Any placement is correct; only the MFMA / VALU overlap depends on it.
+    int grp_v = 0;
+#pragma unroll
+    for (int w = 0; w < PP_NW; ++w) grp_v += (w < wave && simd_of[w] == simd_of[wave]) ? 1 : 0;
+    const int grp = __builtin_amdgcn_readfirstlane(grp_v) & 1;
+
+    // Global phase 2t: all threads issue the loads of K_{t+2}, V_{t+1};  phase 2t+1: all threads store them to slots (t+2)%3, (t+1)%3.
+    // Readers: group 0 runs M(t) [reads K slot t%3, V slot (t-1)%3] in phase 2t, group 1 in phase 2t+1; the slow path of V(t) re-reads
+    // K slot t%3 in phases 2t+1 / 2t+2.  A store in phase 2t+1 hits K slot (t+2)%3 = (t-1)%3 (last read in phase 2t-1 / 2t) and V slot
+    // (t+1)%3 = (t-2)%3 (last read by M(t-1) in phase 2t-1): never a slot somebody can still read, and barrier-separated from the
+    // next reader (phase 2t+4 / 2t+2).
+#define PP_STAGE_ISSUE(t)                                         \
+    do {                                                          \
+        tile_load_buf(krs, sk.s, ((t) + 2) * TILE, koff, kr);     \
+        tile_load_buf(vrs, sv.s, ((t) + 1) * TILE, voff, vr);     \
+    } while (0)
+#define PP_STAGE_STORE(t)                                              \
+    do {                                                               \
+        tile_store(kring + (((t) + 2) % 3) * TILE_ELEMS, kr);          \
+        tile_store(vring + (((t) + 1) % 3) * TILE_ELEMS, vr);          \
+    } while (0)
+#define PP_KL(t) (kring + ((t) % 3) * TILE_ELEMS)
+#define PP_VL(t) (vring + (((t) + 2) % 3) * TILE_ELEMS)     /* V_{t-1} */
+#define PP_V(t) pp_phase_v<QB>(PP_KL(t), (t), S, (t) == 0 || (ragged && (t) == nt - 1), ragged && (t) == nt - 1, lane, hi, qf, qx, m, l, o, s, pf)
+
+    if (grp == 0) {
+        // phases 0, 1: M(0) (scores only), V(0)
+        PP_STAGE_ISSUE(0);
+        pp_phase_m<QB, true, false>(PP_KL(0), PP_VL(0), lane, kx, qx, qf, pf, s, o);
+        pp_barrier();
+        PP_V(0);
+        PP_STAGE_STORE(0);
+        pp_barrier();
+        for (int t = 1; t < nt; ++t) {
+            PP_STAGE_ISSUE(t);
+            pp_phase_m<QB, true, true>(PP_KL(t), PP_VL(t), lane, kx, qx, qf, pf, s, o);
+            pp_barrier();
+            PP_V(t);
+            PP_STAGE_STORE(t);
+            pp_barrier();
+        }
+        // phases 2nt, 2nt+1: M(nt) = the last PV; then idle
+        pp_phase_m<QB, false, true>(PP_KL(nt), PP_VL(nt), lane, kx, qx, qf, pf, s, o);
+        pp_barrier();
+        pp_barrier();
+    } else {
+        // phase 0 idle (loads only), phase 1: M(0)
+        PP_STAGE_ISSUE(0);
+        pp_barrier();
+        pp_phase_m<QB, true, false>(PP_KL(0), PP_VL(0), lane, kx, qx, qf, pf, s, o);
+        PP_STAGE_STORE(0);
+        pp_barrier();
+        for (int t = 1; t < nt; ++t) {
+            PP_STAGE_ISSUE(t);
+            PP_V(t - 1);
+            pp_barrier();
+            pp_phase_m<QB, true, true>(PP_KL(t), PP_VL(t), lane, kx, qx, qf, pf, s, o);
+            PP_STAGE_STORE(t);
+            pp_barrier();
+        }
+        PP_V(nt - 1);
+        pp_barrier();
+        pp_phase_m<QB, false, true>(PP_KL(nt), PP_VL(nt), lane, kx, qx, qf, pf, s, o);
+        pp_barrier();
+    }
+#undef PP_STAGE_ISSUE
+#undef PP_STAGE_STORE
+#undef PP_KL
+#undef PP_VL
+#undef PP_V
+
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const float lt = l[j] + other_half(l[j]);
+        const float inv = 1.f / lt;
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < S) {
+            bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t w;
+                    w[0] = pack_bf16x2(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv);
+                    w[1] = pack_bf16x2(o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+                }
+            if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
+        }
+    }
 }
 
 // =====================================================================================================
@@ -1318,6 +1653,16 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
     if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides)) return VGPA_ERR_INVALID;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
+    static const int use_pp = [] { const char* e = getenv("VGPA_ATTN_FWD"); return (e && e[0] == 'p' && e[1] == 'p') ? 1 : 0; }();
+    if (use_pp) {   // ping-pong kernel: 512 query rows per workgroup, no tail split
+        const int n_qt_pp = (int)((S + 64 * PP_NW - 1) / (64 * PP_NW));
+        const int64_t nb = (int64_t)n_qt_pp * B * H;
+        if (nb > 0x7fffffff) return VGPA_ERR_INVALID;
+        VGPA_LAUNCH((attn_fwd_pp_kernel<2>), dim3((unsigned)nb), dim3(64 * PP_NW), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt_pp);
+        VGPA_CHECK_LAUNCH();
+        return VGPA_OK;
+    }
     const int n_qt = (int)((S + FWD_QB * FWD_NW * 32 - 1) / (FWD_QB * FWD_NW * 32));
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
