@@ -293,10 +293,22 @@ def test_fit_end_to_end_from_disk(tmp_path):
     logs = []
     tr = fit({"base_path": str(tmp_path), "metadata_path": str(tmp_path / "meta_data.json"), "max_steps": 3, "accumulate_grad_batches": 2,
               "batch_size": 1, "num_workers": 0, "learning_rate": 1e-3, "warmup_steps": 1, "log_every_n_steps": 1,
-              "output_dir": str(tmp_path / "out")}, transformer=pm, log=logs.append)
+              "checkpoint_every_n_steps": 2, "output_dir": str(tmp_path / "out")}, transformer=pm, log=logs.append)
     assert tr.global_step == 3 and len(logs) >= 3
     assert (tmp_path / "out" / "final_lora" / "adapter_model.safetensors").exists()
-    assert any(float(p.abs().max()) > 0 for n, p in pm.named_parameters() if "lora_B" in n)   # B left zero -> trained
+    assert any(float(p.detach().abs().max()) > 0 for n, p in pm.named_parameters() if "lora_B" in n)   # B left zero -> trained
+    # periodic checkpoint (ModelCheckpoint every_n_train_steps, 03_train.py:268-275): adapter + optimizer state, and resume from it
+    ck = tmp_path / "out" / "checkpoints" / "step=2"
+    assert (ck / "adapter_model.safetensors").exists() and (ck / "optimizer.pt").exists()
+    state = torch.load(ck / "optimizer.pt")
+    assert state["global_step"] == 2 and state["step_count"] == 2 and state["exp_avg"].abs().max() > 0
+    cfg2, _, _, pm2 = _setup(b_std=0.0, r=4)
+    tr2 = fit({"base_path": str(tmp_path), "metadata_path": str(tmp_path / "meta_data.json"), "max_steps": 4, "accumulate_grad_batches": 2,
+               "batch_size": 1, "num_workers": 0, "learning_rate": 1e-3, "warmup_steps": 1, "checkpoint_every_n_steps": 0,
+               "resume_from": str(ck)}, transformer=pm2, log=lambda m: None)
+    assert tr2.global_step == 4                                   # continued from step 2, ran 2 more optimizer steps
+    with pytest.raises(ValueError, match="no preference pairs"):
+        fit({"base_path": str(tmp_path), "metadata_path": str(tmp_path / "meta_data.json"), "max_steps": 1, "min_gap": 10.0}, transformer=pm2)
 
 
 def test_generate_denoise_loop_matches_cpu_restatement():

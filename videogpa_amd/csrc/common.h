@@ -34,16 +34,16 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-// round-to-nearest-even, NaN kept quiet (same result as torch's float -> bfloat16 cast)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even (the result of torch's float -> bfloat16 cast for every non-NaN input; NaN stays NaN).
+// gfx950 converts in hardware, two values per instruction (v_cvt_pk_bf16_f32): the integer-arithmetic form this replaces cost
+// ~6 VALU instructions per element, which made the "HBM-bound" LN / GELU / QK-norm kernels co-limited by VALU issue.
+typedef __attribute__((ext_vector_type(2))) float vgpa_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 vgpa_bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const vgpa_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, vgpa_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
