@@ -348,6 +348,19 @@ def test_generate_denoise_loop_matches_cpu_restatement():
         lat = lat.to(torch.bfloat16).double()     # the pipeline casts latents back to the prompt dtype every step
     err = (out.double().cpu() - lat).abs().max().item()
     assert err < 0.06 * lat.abs().max().item(), (err, lat.abs().max().item())
+    # use_dynamic_cfg=True (generate/CogVideoX1.5-5B.py:85): the guidance scale follows the pipeline's cosine ramp in the timestep value
+    from videogpa_amd.generate import dynamic_guidance_scale
+    out_d = denoise(merged, sch, pos.cuda(), neg.cuda(), latent_frames=Fr, height=Hh, width=Ww, num_inference_steps=steps,
+                    guidance_scale=6.0, latents=lat0.cuda(), step_noise=noise.cuda(), use_dynamic_cfg=True)
+    lat, old = lat0.double(), None
+    for i, t in enumerate(ref_ts):
+        v = ocv.forward(sdm, cfg, torch.cat([lat, lat]), emb, t.expand(2), image_rotary_emb=(cos.double(), sin.double()))
+        gs = 1 + 6.0 * ((1 - math.cos(math.pi * ((steps - float(t)) / steps) ** 5.0)) / 2)
+        assert abs(gs - dynamic_guidance_scale(6.0, steps, int(t))) < 1e-12
+        v = v[:1] + gs * (v[1:] - v[:1])
+        lat, old = osch.dpm_step(abar, v, old, t, ref_ts[i - 1] if i > 0 else None, lat, steps, noise[i].double())
+        lat = lat.to(torch.bfloat16).double()
+    assert (out_d.double().cpu() - lat).abs().max().item() < 0.06 * lat.abs().max().item()
     # a perfect denoiser is a fixed point of the last step: prev_sample == predicted x0
     sch.set_timesteps(50)
     assert sch.timesteps[0].item() == 999 and sch.timesteps[-1].item() == 19     # "trailing" spacing, 50 steps

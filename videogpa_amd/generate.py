@@ -26,10 +26,19 @@ def rope_3d_tables(num_frames, grid_h, grid_w, head_dim=64, theta=10000.0, devic
     return combine(ct, ch, cw).to(device), combine(st, sh, sw).to(device)
 
 
+def dynamic_guidance_scale(guidance_scale, num_inference_steps, t):
+    """`use_dynamic_cfg=True` of the pipeline (generate/CogVideoX1.5-5B.py:85): the scale grows with a cosine ramp in the timestep
+    VALUE t (as upstream writes it): 1 + g * (1 - cos(pi * ((n - t) / n) ** 5)) / 2."""
+    import math
+    return 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - float(t)) / num_inference_steps) ** 5.0)) / 2)
+
+
 @torch.no_grad()
 def denoise(transformer, scheduler, prompt_embeds, negative_prompt_embeds=None, latent_frames=13, height=60, width=90,
-            num_inference_steps=50, guidance_scale=6.0, generator=None, latents=None, step_noise=None):
-    """-> latents [B, F, C, H, W].  `latents` / `step_noise` ([steps, 2, B, F, C, H, W]) may be injected for parity tests."""
+            num_inference_steps=50, guidance_scale=6.0, generator=None, latents=None, step_noise=None, use_dynamic_cfg=False):
+    """-> latents [B, F, C, H, W].  `latents` / `step_noise` ([steps, 2, B, F, C, H, W]) may be injected for parity tests.
+    With patch_size_t (CogVideoX1.5) and a latent frame count that is not a multiple of it, the pipeline denoises with extra
+    leading frames and drops them at the end; the same is done here."""
     cfg = transformer.config
     dev, dt = prompt_embeds.device, prompt_embeds.dtype
     B = prompt_embeds.shape[0]
@@ -40,6 +49,9 @@ def denoise(transformer, scheduler, prompt_embeds, negative_prompt_embeds=None, 
         embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
     else:
         embeds = prompt_embeds
+    pt_ = cfg.patch_size_t or 1
+    extra = (pt_ - latent_frames % pt_) % pt_
+    latent_frames = latent_frames + extra
     shape = (B, latent_frames, cfg.in_channels, height, width)
     if latents is None:
         latents = torch.randn(shape, generator=generator, device=dev, dtype=dt)
@@ -57,9 +69,10 @@ def denoise(transformer, scheduler, prompt_embeds, negative_prompt_embeds=None, 
         v = transformer(hidden_states=inp, encoder_hidden_states=embeds, timestep=t.expand(inp.shape[0]), image_rotary_emb=rope,
                         return_dict=False)[0].float()
         if do_cfg:
+            g_now = dynamic_guidance_scale(guidance_scale, num_inference_steps, t.item()) if use_dynamic_cfg else guidance_scale
             v_u, v_c = v.chunk(2)
-            v = v_u + guidance_scale * (v_c - v_u)
+            v = v_u + g_now * (v_c - v_u)
         latents, old_x0 = scheduler.step(v, old_x0, t, ts[i - 1] if i > 0 else None, latents, generator=generator,
                                          noise=None if step_noise is None else step_noise[i])
         latents = latents.to(dt)
-    return latents
+    return latents[:, extra:] if extra else latents
