@@ -163,3 +163,72 @@ def test_flatparams_keeps_values_and_accumulates():
     _pair_loss(params, x).sum().backward()
     assert torch.allclose(flat.grad, 2 * g1)
     assert flat.numel % 4 == 0
+
+
+# ---------------------------------------------------------------- DPOEngine itself under gloo (fake trainer, CPU update stub)
+class _FakeTrainer(torch.nn.Module):
+    """Stands for CogVideoXDPOTrainer in DPOEngine: same training_step / configure_optimizers protocol on a toy loss."""
+
+    def __init__(self, accumulate):
+        super().__init__()
+        self.params = torch.nn.ParameterList(_make_params(seed=int(os.environ.get("RANK", "0"))))   # ranks start DIFFERENT
+        self.config = {"accumulate_grad_batches": accumulate}
+        self.global_step = 0
+
+    def training_step(self, batch, idx=0):
+        loss = _pair_loss(list(self.params), batch).mean()
+        return loss, {"train/loss": loss.detach(), "train/reward_margin": loss.detach() * 3, "train/reward_accuracy": (loss.detach() > 0).float()}
+
+    def configure_optimizers(self, process_group=None):
+        return _CpuStepAdamW(FlatParams(self.parameters()), lr=1e-2, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0, total_steps=10,
+                             process_group=process_group)
+
+
+def _engine_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from videogpa_amd import ops
+    from videogpa_amd.trainer import DPOEngine
+    tr = _FakeTrainer(accumulate=2)
+    e0 = ops.ADAPTER_EPOCH
+    eng = DPOEngine(tr)                                         # broadcasts rank 0's parameters
+    assert ops.ADAPTER_EPOCH == e0 + 1
+    assert all(torch.equal(p.detach(), q.detach()) for p, q in zip(tr.params, _make_params(seed=0)))
+    data = _data(8)
+    synced, lrs = [], []
+    for micro in range(4):                                      # 2 optimizer steps of 2 micro-steps, one pair per rank and micro-step
+        i = micro * world + rank
+        logs = eng.micro_step(data[i:i + 1])
+        if "lr" in logs:
+            synced.append(logs["sync"].clone())
+            lrs.append(logs["lr"])
+    assert tr.global_step == 2 and len(synced) == 2 and ops.ADAPTER_EPOCH == e0 + 3
+    torch.save({"param": eng.opt.flat.flat.clone(), "synced": torch.stack(synced)}, os.path.join(out_dir, f"eng{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_dpo_engine_two_ranks_accumulation_and_synced_scalars(tmp_path):
+    world = 2
+    mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"eng{i}.pt") for i in range(world)]
+    assert torch.equal(r[0]["param"], r[1]["param"]) and torch.equal(r[0]["synced"], r[1]["synced"])
+    # single process: each optimizer step sees the mean loss over its 4 pairs (2 ranks x 2 micro-steps)
+    params = _make_params(0)
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.0)
+    data = _data(8)
+    ref = []
+    from videogpa_amd.optim import cosine_schedule_with_warmup
+    for step in range(2):
+        for gq in opt.param_groups:
+            gq["lr"] = 1e-2 * cosine_schedule_with_warmup(step, 0, 10)
+        opt.zero_grad()
+        losses = _pair_loss(params, data[step * 4:(step + 1) * 4])
+        losses.mean().backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        ref.append(losses.mean().item())
+    flat = FlatParams(_make_params(0))
+    for p, o in zip(params, flat.offsets):
+        assert torch.allclose(r[0]["param"][o:o + p.numel()].view_as(p), p.detach(), rtol=0, atol=1e-6)
+    assert torch.allclose(r[0]["synced"][:, 0], torch.tensor(ref), rtol=1e-5, atol=1e-6)            # loss: mean over ranks and micro-steps
+    assert torch.allclose(r[0]["synced"][:, 1], 3 * torch.tensor(ref), rtol=1e-5, atol=1e-6)        # reward margin rides the same tail
