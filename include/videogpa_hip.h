@@ -211,6 +211,10 @@ int32_t vgpa_frame_metric(const void* gt, int32_t gt_dtype, int32_t gt_layout, i
                           int32_t rep_dtype, int32_t rep_layout, int32_t rep_is_tensor, int64_t T, int64_t C, int64_t H,
                           int64_t W, int64_t H2, int64_t W2, int32_t psnr, float* out, void* workspace, size_t ws_bytes,
                           vgpa_stream_t stream);
+/* Input side of LPIPSMetric.compute, metrics/lpips.py:21-63 (the LPIPS network itself is the caller's): frames -> fp32
+ * [T,C,Ho,Wo] in [-1,1] by the reference's range rules, bilinearly resized when (Ho,Wo) != (H,W). */
+int32_t vgpa_frames_to_pm1(const void* src, int32_t dtype, int32_t layout, int32_t is_tensor, int64_t T, int64_t C, int64_t H,
+                           int64_t W, int64_t Ho, int64_t Wo, float* out, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* MVCSMetric.compute, metrics/mvcs.py:12-114.  depth fp32 [T,H,W]; K fp32 [T,k_dim,k_dim] (k_dim 3|4); E fp32
  * [T,e_rows(3|4),4] world-to-camera; out[0] = exp(-mean over valid consecutive pairs of the masked depth MSE). */
 size_t vgpa_mvcs_workspace_bytes(int64_t T);

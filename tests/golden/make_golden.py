@@ -290,6 +290,32 @@ def golden_scorer2():
     wp = unproject_depth(d.unsqueeze(0).unsqueeze(-1), K.unsqueeze(0), c2w.unsqueeze(0)).squeeze(0)
     out["da3_unproject"].append({"depths": d, "intrinsics": K, "extrinsics": E, "c2w": c2w, "world_points": wp})
 
+    # ---- LPIPSMetric / Consistency_Score wrappers around a STAND-IN perceptual net (the LPIPS-VGG weights are third-party): pins the
+    #      input normalisation, layout change, resize and the MSE + ratio * LPIPS combination (metrics/lpips.py:21-63,
+    #      metrics/consistency_score.py:52-72)
+    lp_mod = load("metrics.lpips", os.path.join(REF, "metrics/lpips.py"))
+    cs_mod = load("metrics.consistency_score", os.path.join(REF, "metrics/consistency_score.py"))
+    net = lambda a, b: (a - b).abs().mean(dim=(1, 2, 3), keepdim=True) + 0.01 * a.mean(dim=(1, 2, 3), keepdim=True)
+    lpm = lp_mod.LPIPSMetric(device="cpu", lpips_net=net)
+    csm = cs_mod.Consistency_Score(lpips_net=net, device="cpu")
+    out["lpips"], out["consistency"] = [], []
+    T_, H_, W_ = 3, 14, 18
+    gt_u8 = (torch.rand(T_, H_, W_, 3, generator=g) * 255).to(torch.uint8)
+    rep_pm1 = torch.rand(T_, 3, H_, W_, generator=g) * 2 - 1
+    gt_01 = torch.rand(T_, 3, H_, W_, generator=g)
+    rep_small = torch.rand(T_, 3, 9, 11, generator=g) * 2 - 1
+    gt_255 = torch.rand(T_, 3, H_, W_, generator=g) * 255
+    Es = torch.eye(4).repeat(T_, 1, 1)
+    for i in range(T_):
+        a_ = 0.07 * i
+        Es[i, :3, :3] = torch.tensor([[np.cos(a_), -np.sin(a_), 0], [np.sin(a_), np.cos(a_), 0], [0, 0, 1]], dtype=torch.float32)
+        Es[i, :3, 3] = torch.tensor([0.1 * i, 0.02 * i, -0.05 * i])
+    for gt_, rep_ in ((gt_u8.numpy(), rep_pm1), (gt_01, rep_pm1), (gt_u8, rep_small), (gt_255, gt_01)):
+        out["lpips"].append({"gt": gt_, "rep": rep_, "val": lpm.compute(gt=gt_, rep=rep_)})
+        for ratio in (1, 0.1):
+            sc_, mo_ = csm.compute(gt=gt_, rep=rep_, extrinsics=Es, ratio=ratio)
+            out["consistency"].append({"gt": gt_, "rep": rep_, "extrinsics": Es, "ratio": ratio, "score": sc_, "motion": mo_})
+
     torch.save(out, os.path.join(HERE, "scorer2.pt"))
     print("scorer2.pt written:", {k: len(v) for k, v in out.items()})
 

@@ -158,6 +158,29 @@ def test_psnr_resized_mse_mvcs_vs_reference_golden(sc, golden_dir):
     assert mv.compute(depths=g["mvcs"][-1]["depths"], intrinsics=g["mvcs"][-1]["intrinsics"], extrinsics=g["mvcs"][-1]["extrinsics"]) == 0.0
 
 
+def test_lpips_and_consistency_wrappers_vs_reference_golden(sc, golden_dir):
+    """LPIPSMetric / Consistency_Score (metrics/lpips.py:21-63, metrics/consistency_score.py:52-72) with the stand-in perceptual net the
+    goldens were made with: the device-side normalisation / layout / resize in front of the caller's network, and the combination."""
+    g = _g2(golden_dir)
+    net = lambda a, b: (a - b).abs().mean(dim=(1, 2, 3), keepdim=True) + 0.01 * a.mean(dim=(1, 2, 3), keepdim=True)
+    lp = sc.LPIPSMetric(device="cuda", lpips_net=net)
+    cs = sc.Consistency_Score(net, device="cuda")                # positional, as replicate_scorer.py:68 constructs it
+    for c in g["lpips"]:
+        got = lp.compute(gt=c["gt"], rep=c["rep"])
+        assert abs(got - c["val"]) <= 5e-6 * max(1.0, abs(c["val"])), (got, c["val"])
+    for c in g["consistency"]:
+        s_, m_ = cs.compute(gt=c["gt"], rep=c["rep"], extrinsics=c["extrinsics"], ratio=c["ratio"])
+        assert abs(s_ - c["score"]) <= 5e-6 * max(1.0, abs(c["score"])), (s_, c["score"])
+        assert abs(m_ - c["motion"]) <= 2e-6 * max(1.0, abs(c["motion"]))
+    pm = sc.frames_to_pm1(g["lpips"][0]["gt"])
+    assert pm.shape == (3, 3, 14, 18) and float(pm.min()) >= -1.0 and float(pm.max()) <= 1.0
+    with pytest.raises(RuntimeError, match="third-party"):
+        sc.LPIPSMetric().compute(gt=g["lpips"][0]["gt"], rep=g["lpips"][0]["rep"])
+    assert sc.Consistency_Score(None).compute(gt=g["lpips"][1]["gt"], rep=g["lpips"][1]["rep"], extrinsics=g["consistency"][0]["extrinsics"], ratio=0)[0] > 0
+    with pytest.raises(ValueError):
+        sc.EpipolarMetric(descriptor_type="orb")
+
+
 def test_pose_decode_and_unprojection_vs_reference_golden(sc, golden_dir):
     g = _g2(golden_dir)
     for c in g["pose_enc"]:

@@ -105,3 +105,18 @@ def test_pose_encoding_and_unprojection_match_reference(golden_dir):
         assert torch.equal(scorer.affine_inverse(c["extrinsics"]), c["c2w"])
         wp = scorer.unproject_depth(c["depths"], c["intrinsics"], c["c2w"])
         assert torch.allclose(wp, c["world_points"], rtol=1e-5, atol=1e-6)
+
+
+_STANDIN_NET = lambda a, b: (a - b).abs().mean(dim=(1, 2, 3), keepdim=True) + 0.01 * a.mean(dim=(1, 2, 3), keepdim=True)
+
+
+def test_lpips_and_consistency_wrappers_match_reference(golden_dir):
+    """The reference's LPIPSMetric / Consistency_Score around a stand-in perceptual net (same lambda as make_golden.py)."""
+    g = _g2(golden_dir)
+    assert len(g["lpips"]) == 4 and len(g["consistency"]) == 8
+    for c in g["lpips"]:
+        got = scorer.lpips_metric(c["gt"], c["rep"], _STANDIN_NET)
+        assert abs(got - c["val"]) <= 2e-6 * max(1.0, abs(c["val"])), (got, c["val"])
+    for c in g["consistency"]:
+        sc_, mo_ = scorer.consistency_score(c["gt"], c["rep"], c["extrinsics"].numpy(), _STANDIN_NET, c["ratio"])
+        assert abs(sc_ - c["score"]) <= 2e-6 * max(1.0, abs(c["score"])) and mo_ == c["motion"], (sc_, c["score"], mo_, c["motion"])

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vgpa_conf_threshold": (I32, [P, I64, F32, P, P, SZ, P]),
     "vgpa_frame_metric_workspace_bytes": (SZ, []),
     "vgpa_frame_metric": (I32, [P, I32, I32, I32, P, I32, I32, I32, I64, I64, I64, I64, I64, I64, I32, P, P, SZ, P]),
+    "vgpa_frames_to_pm1": (I32, [P, I32, I32, I32, I64, I64, I64, I64, I64, I64, P, P, SZ, P]),
     "vgpa_mvcs_workspace_bytes": (SZ, [I64]),
     "vgpa_mvcs": (I32, [P, P, I32, P, I32, I64, I64, I64, P, P, SZ, P]),
     "vgpa_unproject_depth": (I32, [P, P, P, I32, I64, I64, I64, P, P]),

@@ -172,6 +172,45 @@ __global__ __launch_bounds__(S2_THREADS) void mse_resize_kernel(const void* __re
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// LPIPSMetric._to_tensor_neg1_pos1 (metrics/lpips.py:38-63) + the resize of :31-32: any frame container -> fp32 [T,C,Ho,Wo] in [-1,1].
+//   torch.Tensor: min >= 0 -> (max > 1 ? x/255 : x) * 2 - 1, else unchanged;  numpy: always (x/255) * 2 - 1.
+__device__ __forceinline__ float to_pm1(float x, float mn, float mx, int is_tensor) {
+    if (!is_tensor) return (x / 255.0f) * 2.0f - 1.0f;
+    if (mn >= 0.f) {
+        if (mx > 1.0f) x = x / 255.0f;
+        return x * 2.0f - 1.0f;
+    }
+    return x;
+}
+__global__ __launch_bounds__(S2_THREADS) void frames_pm1_kernel(const void* __restrict__ src, int dtype, int layout, int is_tensor, int64_t T, int C,
+                                                                  int H, int W, int Ho, int Wo, const uint32_t* __restrict__ mm, float* __restrict__ out) {
+    const float mn = f32_unordered2(~mm[0]), mx = f32_unordered2(mm[1]);
+    const int64_t n = T * C * (int64_t)Ho * Wo;
+    const bool same = (H == Ho) && (W == Wo);
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    for (int64_t i = (int64_t)blockIdx.x * S2_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * S2_THREADS) {
+        const int x = (int)(i % Wo);
+        const int y = (int)((i / Wo) % Ho);
+        const int c = (int)((i / ((int64_t)Wo * Ho)) % C);
+        const int64_t t = i / ((int64_t)Wo * Ho * C);
+        float r;
+        if (same) {
+            r = to_pm1(img_at2(src, dtype, layout, t, c, y, x, C, H, W), mn, mx, is_tensor);
+        } else {
+            int y0, y1, x0, x1;
+            float wy0, wy1, wx0, wx1;
+            lin_tap(y, H, sy, y0, y1, wy0, wy1);
+            lin_tap(x, W, sx, x0, x1, wx0, wx1);
+            const float a00 = to_pm1(img_at2(src, dtype, layout, t, c, y0, x0, C, H, W), mn, mx, is_tensor);
+            const float a01 = to_pm1(img_at2(src, dtype, layout, t, c, y0, x1, C, H, W), mn, mx, is_tensor);
+            const float a10 = to_pm1(img_at2(src, dtype, layout, t, c, y1, x0, C, H, W), mn, mx, is_tensor);
+            const float a11 = to_pm1(img_at2(src, dtype, layout, t, c, y1, x1, C, H, W), mn, mx, is_tensor);
+            r = (a00 * wx0 + a01 * wx1) * wy0 + (a10 * wx0 + a11 * wx1) * wy1;
+        }
+        out[i] = r;
+    }
+}
+
 __global__ __launch_bounds__(S2_THREADS) void mse_finish_kernel(const double* __restrict__ partial, int nblk, double inv_n, int psnr, float* __restrict__ out) {
     __shared__ double smem[16];
     double s = 0;
@@ -391,6 +430,23 @@ int32_t vgpa_frame_metric(const void* gt, int32_t gt_dtype, int32_t gt_layout, i
                 rep_is_tensor, T, (int)C, (int)H, (int)W, (int)H2, (int)W2, mm, partial);
     VGPA_CHECK_LAUNCH();
     VGPA_LAUNCH(mse_finish_kernel, dim3(1), dim3(S2_THREADS), 0, stream, partial, (int)nb, 1.0 / (double)n, (int)psnr, out);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// Input side of LPIPSMetric.compute (metrics/lpips.py:21-63): frames (dtype 0 f32 / 2 u8; layout 0 [T,C,H,W] / 1 [T,H,W,C]; is_tensor
+// selects the torch.Tensor vs numpy rule) -> fp32 [T,C,Ho,Wo] in [-1,1], bilinearly resized (align_corners=False) when (Ho,Wo) != (H,W).
+// workspace: 2 x uint32 (vgpa_frame_metric_workspace_bytes is enough).
+int32_t vgpa_frames_to_pm1(const void* src, int32_t dtype, int32_t layout, int32_t is_tensor, int64_t T, int64_t C, int64_t H, int64_t W,
+                           int64_t Ho, int64_t Wo, float* out, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!src || !out || !workspace || T <= 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || (dtype != 0 && dtype != 2)) return VGPA_ERR_INVALID;
+    if (ws_bytes < 2 * sizeof(uint32_t)) return VGPA_ERR_WORKSPACE;
+    uint32_t* mm = (uint32_t*)workspace;
+    if (hipMemsetAsync(mm, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) return VGPA_ERR_LAUNCH;
+    const int64_t n_in = T * C * H * W, n_out = T * C * Ho * Wo;
+    VGPA_LAUNCH(minmax1_kernel, dim3(s2_grid(n_in, 1024)), dim3(S2_THREADS), 0, stream, src, dtype, n_in, mm);
+    VGPA_LAUNCH(frames_pm1_kernel, dim3(s2_grid(n_out, 2048)), dim3(S2_THREADS), 0, stream, src, dtype, layout, is_tensor, T, (int)C, (int)H, (int)W,
+                (int)Ho, (int)Wo, mm, out);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

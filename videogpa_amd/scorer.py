@@ -225,24 +225,51 @@ def unproject_depth_to_world(depths, intrinsics, extrinsics):
     return world
 
 
+def frames_to_pm1(x, size=None):
+    """LPIPSMetric._to_tensor_neg1_pos1 (metrics/lpips.py:38-63) on device: any frame container -> fp32 [T,C,H,W] in [-1,1];
+    `size` = (H, W) additionally resizes bilinearly (align_corners=False), as :31-32 do for `rep`."""
+    t, dt, layout, is_tensor, T, C, H, W = _img_desc(x)
+    Ho, Wo = (H, W) if size is None else size
+    out = torch.empty(T, C, Ho, Wo, dtype=torch.float32, device=t.device)
+    ws_bytes = _lib.query("vgpa_frame_metric_workspace_bytes")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
+    _lib.call("vgpa_frames_to_pm1", t, dt, layout, is_tensor, T, C, H, W, Ho, Wo, out, ws, ws_bytes, _stream())
+    return out
+
+
+class LPIPSMetric(Metric):
+    """Video-level LPIPS (metrics/lpips.py:7-36).  The perceptual network (`lpips.LPIPS(net='vgg')` upstream) is third-party: it is
+    passed in, exactly as the reference's own drivers pass it (`LPIPSMetric(device=..., lpips_net=net)`, replicate_scorer.py:63-74);
+    the input normalisation / layout / resize in front of it runs on the device."""
+
+    def __init__(self, device=None, lpips_net=None):
+        super().__init__(name="lpips")
+        self.device = device or "cuda"
+        self.lpips = lpips_net
+
+    def compute(self, *, gt, rep, **kwargs) -> float:
+        if self.lpips is None:
+            raise RuntimeError("LPIPSMetric: the LPIPS-VGG weights are third-party and not bundled; pass lpips_net=lpips.LPIPS(net='vgg')")
+        gt_t = frames_to_pm1(gt)
+        rep_t = frames_to_pm1(rep, size=tuple(gt_t.shape[-2:]))
+        with torch.no_grad():
+            d = self.lpips(gt_t, rep_t)
+        return float(torch.as_tensor(d, dtype=torch.float32).mean().item())
+
+
 class Consistency_Score(Metric):
-    """MSE + ratio * LPIPS, motion score returned separately (metrics/consistency_score.py:43-72).  `lpips_net` is the
-    caller's perceptual network (`lpips.LPIPS('vgg')` upstream): a callable (gt_pm1, rep_pm1) -> per-frame distances."""
+    """MSE + ratio * LPIPS, motion score returned separately (metrics/consistency_score.py:43-72).  `lpips_net` is the caller's
+    perceptual network, wrapped in LPIPSMetric like the reference does (:54-58)."""
 
     def __init__(self, lpips_net=None, device="cuda"):
         super().__init__("Consistency_Score")
         self.device = device
         self.mse_metric = MSEMetric()
-        self.lpips_net = lpips_net
+        self.lpips_metric = LPIPSMetric(lpips_net=lpips_net, device=device)
 
     def compute(self, *, gt, rep, extrinsics, ratio=1, **kwargs):
         val_mse = self.mse_metric.compute(gt=gt, rep=rep)
-        if ratio != 0:
-            if self.lpips_net is None:
-                raise RuntimeError("Consistency_Score: LPIPS weights are third-party and not bundled; pass lpips_net=... or ratio=0")
-            val_lpips = float(self.lpips_net(gt, rep))
-        else:
-            val_lpips = 0.0
+        val_lpips = self.lpips_metric.compute(gt=gt, rep=rep) if ratio != 0 else 0.0     # ratio = 0: usable without the network
         motion = compute_motion_score_vectorized(extrinsics, device=self.device)
         return float(val_mse + ratio * val_lpips), float(motion)
 
@@ -264,8 +291,13 @@ class EpipolarMetric(Metric):
     """Video-level epipolar consistency (metrics/epipolar.py:142-232).  `matcher(frame_i, frame_j) -> (pts1, pts2)` is the
     caller's SIFT / LightGlue front end (third-party); the 8-point + Sampson geometry runs on device."""
 
-    def __init__(self, matcher=None, min_matches: int = 20):
+    def __init__(self, descriptor_type: str = "sift", ratio_thresh: float = 0.75, min_matches: int = 20, device: str = None, matcher=None):
+        """Reference signature (metrics/epipolar.py:146-158) + `matcher`: the reference builds a cv2-SIFT or LightGlue matcher from
+        `descriptor_type`; both are third-party, so the front end is the caller's callable here."""
         super().__init__(name="Epipolar")
+        if descriptor_type not in ("sift", "lightglue"):
+            raise ValueError(f"Unsupported descriptor type: {descriptor_type}")
+        self.descriptor_type, self.ratio_thresh, self.device = descriptor_type, ratio_thresh, device or "cuda"
         self.matcher, self.min_matches = matcher, min_matches
 
     def compute_from_matches(self, pts1_list, pts2_list) -> float:
