@@ -24,8 +24,10 @@ from . import scorer
 
 
 class VideoProcessor:
-    def __init__(self, metrics, backbone_fn, frame_sampler=None, backbone=None, model_name=None, device="cuda"):
-        self.device = device
+    def __init__(self, metrics, model_name=None, device=None, backbone=None, backbone_fn=None, frame_sampler=None):
+        """First four arguments as the reference's (pipelines/process_video.py:17-29).  Where the reference loads VGGT-1B / DA3 weights
+        itself, this class takes `backbone_fn` (and `frame_sampler` for paths): third-party networks and video decoding stay the caller's."""
+        self.device = device or "cuda"
         self.metrics = metrics
         self.backbone = self._resolve_backbone(backbone, model_name)
         self.model_name = model_name
@@ -48,6 +50,8 @@ class VideoProcessor:
     def process(self, video_path, thresholds, num_frames, save_visuals=False, out_dir=None):
         if save_visuals:
             raise NotImplementedError("save_visuals (PNG dumps through cv2) is host I/O outside the on-device path")
+        if self.backbone_fn is None:
+            raise RuntimeError("VideoProcessor needs backbone_fn (the VGGT / DA3 network is third-party: pass a callable frames -> predictions)")
         frames = video_path if not isinstance(video_path, (str, os.PathLike)) else self._sample(video_path, num_frames)
         if self.backbone == "da3":
             return self._process_da3(frames, thresholds)
