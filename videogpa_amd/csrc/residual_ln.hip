@@ -11,8 +11,10 @@
 // HBM-bound.  Fusing saves one full read of the residual stream in the forward and three full passes in the backward
 // (LN-backward output, the autograd add, the gate multiply input).  One wave per token row, row held in registers;
 // the three per-column fp32 parameter vectors (gate, alpha, beta) of the workgroup's (batch, text|video) range live in
-// LDS, so a lane needs no parameter registers and the kernel runs at 5-6 waves/SIMD.  Rows of another range inside a
-// boundary workgroup take a slow path that reads the parameters from global memory.
+// LDS, so a lane needs no parameter registers.  Workgroups are aligned to the (batch, text | video) ranges -- blockIdx maps to
+// (batch, range, 32-row block inside the range) -- so every row of a workgroup uses the LDS copy: the earlier layout (blocks of
+// 32 consecutive rows, a global-memory slow path for rows of another range) cost the forward 58 VGPRs for a path that 2 of 1111
+// workgroups ever took (166 -> 110 VGPRs, 3 -> 4 waves per SIMD).
 #include "common.h"
 
 #define RL_WAVES 4
@@ -59,9 +61,10 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_fwd_kernel(const bf
     extern __shared__ __attribute__((aligned(16))) float sp[];   // [3][D]: alpha, beta, gate of the home range
     float* s_alpha = sp; float* s_beta = sp + D; float* s_gate = sp + 2 * D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t blk_row0 = (int64_t)blockIdx.x * RL_ROWS;
-    const int hb = (int)(blk_row0 / S);
-    const bool htext = (int)(blk_row0 - (int64_t)hb * S) < text_len;
+    const int nT = (text_len + RL_ROWS - 1) / RL_ROWS, per = nT + (S - text_len + RL_ROWS - 1) / RL_ROWS;
+    const int hb = (int)blockIdx.x / per, rblk = (int)blockIdx.x % per;
+    const bool htext = rblk < nT;
+    const int tok0 = htext ? rblk * RL_ROWS : text_len + (rblk - nT) * RL_ROWS, tok_end = htext ? text_len : S;
     for (int c = threadIdx.x; c * 8 < D; c += 64 * RL_WAVES) {
         float a[8], be[8], g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         params_global(P, hb, htext, c * 8, a, be, g);
@@ -70,11 +73,9 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_fwd_kernel(const bf
     }
     __syncthreads();
     for (int rr = 0; rr < RL_ROWS_PER_WAVE; ++rr) {
-        const int64_t row = blk_row0 + wave * RL_ROWS_PER_WAVE + rr;
-        if (row >= rows) return;
-        const int b = (int)(row / S);
-        const bool is_text = (int)(row - (int64_t)b * S) < text_len;
-        const bool home = (b == hb) && (is_text == htext);
+        const int tok = tok0 + wave * RL_ROWS_PER_WAVE + rr;
+        if (tok >= tok_end) return;
+        const int64_t row = (int64_t)hb * S + tok;
         u32x4_t xp[NV], yp[NV];
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
@@ -90,9 +91,9 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_fwd_kernel(const bf
             const int i0 = (c * 64 + lane) * 8;
             unpack8(xp[c], v[c]);
             if (HAS_Y) {
-                float yy[8], g[8], dummy[8];
+                float yy[8], g[8];
                 unpack8(yp[c], yy);
-                if (i0 < D) { if (home) ld8(s_gate + i0, g); else params_global(P, b, is_text, i0, dummy, nullptr, g); }
+                if (i0 < D) ld8(s_gate + i0, g);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[c][j] = round_bf16(v[c][j] + round_bf16(g[j] * yy[j]));
                 if (i0 < D) *reinterpret_cast<u32x4_t*>(x_new + (size_t)row * D + i0) = pack8(v[c]);
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_fwd_kernel(const bf
             const int i0 = (c * 64 + lane) * 8;
             if (i0 < D) {
                 float a[8], be[8], o[8];
-                if (home) { ld8(s_alpha + i0, a); ld8(s_beta + i0, be); } else params_global(P, b, is_text, i0, a, be, nullptr);
+                ld8(s_alpha + i0, a);
+                ld8(s_beta + i0, be);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * a[j] + be[j];
                 *reinterpret_cast<u32x4_t*>(n_out + (size_t)row * n_stride + i0) = pack8(o);
@@ -140,9 +142,10 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_bwd_kernel(const bf
     extern __shared__ __attribute__((aligned(16))) float sp[];   // [2][D]: alpha, gate
     float* s_alpha = sp; float* s_gate = sp + D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t blk_row0 = (int64_t)blockIdx.x * RL_ROWS;
-    const int hb = (int)(blk_row0 / S);
-    const bool htext = (int)(blk_row0 - (int64_t)hb * S) < text_len;
+    const int nT = (text_len + RL_ROWS - 1) / RL_ROWS, per = nT + (S - text_len + RL_ROWS - 1) / RL_ROWS;
+    const int hb = (int)blockIdx.x / per, rblk = (int)blockIdx.x % per;
+    const bool htext = rblk < nT;
+    const int tok0 = htext ? rblk * RL_ROWS : text_len + (rblk - nT) * RL_ROWS, tok_end = htext ? text_len : S;
     for (int c = threadIdx.x; c * 8 < D; c += 64 * RL_WAVES) {
         float a[8], g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         params_global(P, hb, htext, c * 8, a, nullptr, g);
@@ -151,11 +154,9 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_bwd_kernel(const bf
     }
     __syncthreads();
     for (int rr = 0; rr < RL_ROWS_PER_WAVE; ++rr) {
-        const int64_t row = blk_row0 + wave * RL_ROWS_PER_WAVE + rr;
-        if (row >= rows) return;
-        const int b = (int)(row / S);
-        const bool is_text = (int)(row - (int64_t)b * S) < text_len;
-        const bool home = (b == hb) && (is_text == htext);
+        const int tok = tok0 + wave * RL_ROWS_PER_WAVE + rr;
+        if (tok >= tok_end) return;
+        const int64_t row = (int64_t)hb * S + tok;
         const float mean = mean_in[row], rstd = rstd_in[row];
         u32x4_t dnp[NV], xp[NV], rp[NV];   // packed bf16: g and xhat are recomputed in the second pass instead of held as fp32
 #pragma unroll
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_bwd_kernel(const bf
                 float g[8], xh[8], a[8];
                 unpack8(dnp[c], g);
                 unpack8(xp[c], xh);
-                if (home) ld8(s_alpha + i0, a); else params_global(P, b, is_text, i0, a, nullptr, nullptr);
+                ld8(s_alpha + i0, a);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float gg = g[j] * a[j];
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(64 * RL_WAVES) void residual_ln_bwd_kernel(const bf
                 float g[8], xh[8], a[8], gt[8], o[8], r[8];
                 unpack8(dnp[c], g);
                 unpack8(xp[c], xh);
-                if (home) { ld8(s_alpha + i0, a); if (HAS_DY) ld8(s_gate + i0, gt); } else params_global(P, b, is_text, i0, a, nullptr, HAS_DY ? gt : nullptr);
+                ld8(s_alpha + i0, a);
+                if (HAS_DY) ld8(s_gate + i0, gt);
                 if (HAS_DRES) unpack8(rp[c], r);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -239,7 +241,7 @@ int32_t vgpa_residual_ln_fwd(const void* x, const void* y, const float* gate_v, 
     if ((mean == nullptr) != (rstd == nullptr)) return VGPA_ERR_INVALID;
     RLParams P = {ln_w, ln_b, shift_v, scale1p_v, shift_t, scale1p_t, mod_stride, y ? gate_v : nullptr, y ? gate_t : nullptr, gate_stride};
     const int64_t rows = B * S;
-    const dim3 grid((unsigned)((rows + RL_ROWS - 1) / RL_ROWS));
+    const dim3 grid((unsigned)(B * ((text_len + RL_ROWS - 1) / RL_ROWS + (S - text_len + RL_ROWS - 1) / RL_ROWS)));   // range-aligned blocks
     const size_t shmem = (size_t)3 * D * sizeof(float);
 #define FWD_ARGS grid, dim3(64 * RL_WAVES), shmem, stream, (const bf16_t*)x, (const bf16_t*)y, P, (int)text_len, (int)S, (int)D, rows, eps, \
                  (bf16_t*)x_new, (bf16_t*)n_out, n_stride, mean, rstd
@@ -262,7 +264,7 @@ int32_t vgpa_residual_ln_bwd(const void* dn, const void* x_new, const float* mea
     if (scale1p_v && text_len > 0 && !scale1p_t) return VGPA_ERR_INVALID;
     RLParams P = {ln_w, nullptr, nullptr, scale1p_v, nullptr, scale1p_t, mod_stride, dy ? gate_v : nullptr, dy ? gate_t : nullptr, gate_stride};
     const int64_t rows = B * S;
-    const dim3 grid((unsigned)((rows + RL_ROWS - 1) / RL_ROWS));
+    const dim3 grid((unsigned)(B * ((text_len + RL_ROWS - 1) / RL_ROWS + (S - text_len + RL_ROWS - 1) / RL_ROWS)));   // range-aligned blocks
     const size_t shmem = (size_t)2 * D * sizeof(float);
 #define BWD_ARGS grid, dim3(64 * RL_WAVES), shmem, stream, (const bf16_t*)dn, (const bf16_t*)x_new, mean, rstd, P, (int)text_len, (int)S, (int)D, \
                  rows, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dy, dy_stride
