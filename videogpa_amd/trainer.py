@@ -144,9 +144,14 @@ class CogVideoXDPOTrainer(nn.Module):
     # ------------------------------------------------------------------ model-variant rules of the reference's three step functions
     def _base_config(self):
         m = self.transformer
-        while not hasattr(m, "config") or not hasattr(m.config, "patch_size"):
-            m = m.get_base_model() if hasattr(m, "get_base_model") else m.base_model
-        return m.config
+        for _ in range(4):                       # PeftModel -> LoraModel -> transformer at most
+            cfg = getattr(m, "config", None)
+            if cfg is not None and hasattr(cfg, "patch_size"):
+                return cfg
+            m = m.get_base_model() if hasattr(m, "get_base_model") else getattr(m, "base_model", getattr(m, "model", None))
+            if m is None:
+                break
+        raise RuntimeError("the transformer exposes no CogVideoX config (patch_size / in_channels): cannot choose the step variant")
 
     def _paired_latents(self, batch):
         """-> x_pair [B,2,F,C,H,W] bf16.  T2V / I2V permute [B,C,F,H,W] -> [B,F,C,H,W] unconditionally
