@@ -422,9 +422,18 @@ def _transposed(W):
     return c[1]
 
 
+def _gemm(x2, W, bias=None):
+    """x2 [M,K] @ W[N,K]^T (+ bias) through hipBLASLt (torch), timed like the hand-written kernels when bench.py asks for it."""
+    if TIMER is None:
+        return torch.nn.functional.linear(x2, W, bias)
+    out = []
+    _timed("hipblaslt_gemm (vendor)", 2.0 * x2.shape[0] * W.shape[0] * W.shape[1], lambda: out.append(torch.nn.functional.linear(x2, W, bias)))
+    return out[0]
+
+
 def _frozen_dx(dy2, W):
     Wt = _transposed(W)
-    return dy2 @ W if Wt is None else torch.nn.functional.linear(dy2, Wt)
+    return dy2 @ W if Wt is None else _gemm(dy2, Wt)
 
 
 class _FrozenLinearFn(torch.autograd.Function):
@@ -433,7 +442,7 @@ class _FrozenLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, bias):
         ctx.save_for_backward(W)
-        return torch.nn.functional.linear(x, W, bias)
+        return _gemm(x.reshape(-1, x.shape[-1]), W, bias).view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -446,8 +455,10 @@ class _FrozenLinearFn(torch.autograd.Function):
 
 def frozen_linear(x, W, bias):
     """F.linear for a projection whose weight / bias do not train (falls back to F.linear otherwise)."""
-    if W.requires_grad or (bias is not None and bias.requires_grad) or not (torch.is_grad_enabled() and x.requires_grad):
+    if W.requires_grad or (bias is not None and bias.requires_grad):
         return torch.nn.functional.linear(x, W, bias)
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return _gemm(x.reshape(-1, x.shape[-1]), W, bias).view(*x.shape[:-1], W.shape[0])
     return _FrozenLinearFn.apply(x, W, bias)
 
 
@@ -537,7 +548,7 @@ class _LinearLoraExtFn(torch.autograd.Function):
             lora_down(xv, ext.A_cat, out=tv)
         else:
             tv.zero_()
-        y = torch.nn.functional.linear(x_ext, ext.W_ext, bias)
+        y = _gemm(x_ext, ext.W_ext, bias)
         ctx.save_for_backward(x_ext)
         ctx.ext, ctx.enabled, ctx.xshape, ctx.scalings = ext, enabled, x.shape, scalings
         return y.view(*x.shape[:-1], N)
@@ -558,7 +569,7 @@ class _LinearLoraExtFn(torch.autograd.Function):
                 lora_down(dy_ext[:, i * Dn:(i + 1) * Dn], ext.sBt[j], out=dy_ext[:, N + j * rp:N + (j + 1) * rp])      # dT_i = dy_i (s B_i)
         else:
             dy_ext[:, N:].zero_()
-        dx = torch.nn.functional.linear(dy_ext, ext.Wt_ext)                                                           # dy W + dT A
+        dx = _gemm(dy_ext, ext.Wt_ext)                                                                                # dy W + dT A
         out_grads = [None] * len(ctx.needs_input_grad[5:])
         if enabled:
             for j, i in enumerate(act):
