@@ -41,5 +41,8 @@ torch.cuda.synchronize()
 unit = 2.0 * S * S * 64 * B * H
 hw_units = {"attn_fwd_kernel": 2, "attn_bwd_dkv_kernel": 4, "attn_bwd_dq_kernel": 3, "attn_bwd_fused_kernel": 5}
 for name, s in ops.TIMER.summary().items():
+    if name not in hw_units:          # HBM-bound helpers (attn_delta_kernel): bytes, not FLOPs
+        print(f"{name:22s} avg {s['avg_ms']:8.3f} ms  {s['work_per_launch'] / s['avg_ms'] / 1e6:7.1f} GB/s")
+        continue
     print(f"{name:22s} avg {s['avg_ms']:8.3f} ms  algorithmic {s['work_per_launch'] / s['avg_ms'] / 1e9:7.1f} TF/s  "
           f"executed-MFMA {hw_units[name] * unit / s['avg_ms'] / 1e9:7.1f} TF/s")
