@@ -2,6 +2,7 @@
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import cogvideox as ocv
@@ -145,3 +146,18 @@ def test_eight_point_and_sampson():
     assert np.allclose(Fm, Ft, rtol=1e-5, atol=1e-8)
     assert abs(np.linalg.det(Fm)) < 1e-12
     assert scorer.epipolar_pair_error(p1, p2) < 2e-4   # sqrt(0 + 1e-8)
+
+
+def test_interleaved_rope_matches_installed_third_party_implementation():
+    """The interleaved-pair rotation of oracle.cogvideox.apply_rotary_emb (diffusers' apply_rotary_emb with
+    use_real_unbind_dim=-1) is the same operation as GPT-J's `rotate_every_two` rotary embedding; the installed `transformers`
+    package carries an independent implementation of it -> one more third-party pin for a piece of the unpinned transformer."""
+    gptj = pytest.importorskip("transformers.models.gptj.modeling_gptj")
+    g = torch.Generator().manual_seed(3)
+    B, H, S, D = 2, 3, 24, 64
+    x = torch.randn(B, H, S, D, generator=g)
+    cos, sin = ocv.rope_3d_tables(2, 3, 4, D)                      # [S, D], pair-repeated
+    ours = ocv.apply_rotary_emb(x, cos, sin)
+    # GPT-J layout: tensor [B, S, H, D]; sin / cos [B, S, D/2] (it repeat-interleaves them itself)
+    theirs = gptj.apply_rotary_pos_emb(x.permute(0, 2, 1, 3), sin[None, :, ::2].expand(B, -1, -1), cos[None, :, ::2].expand(B, -1, -1))
+    assert torch.allclose(ours, theirs.permute(0, 2, 1, 3), rtol=0, atol=1e-6)
