@@ -14,7 +14,8 @@ Tolerances (the HIP path computes in bf16, the oracle in fp32 on the same bf16-r
                         passes the fixed 5 % / 0.99 bounds with room (cos >= 0.995), where plain torch bf16 does not (cos 0.95-0.99).
                         In the r8 variant (B ~ N(0, 1e-3)) that family's gradient norm is 6e-5: below the bf16 noise of ANY
                         implementation (torch bf16: norm off by 48 %, cos 0.88) -- the factor 3 covers the run-to-run spread of
-                        a noise-dominated quantity; it is not a statement about signal.
+                        a noise-dominated quantity; it is not a statement about signal.  A family whose torch-bf16 floor is itself
+                        below cos 0.95 is checked for direction (cos > 0.5) and magnitude (norm within a factor 2) only.
 
 The bf16 floor: the same step run by the ORACLE'S OWN CODE (plain torch ops) on the GPU with bf16 weights and activations,
 compared with the same fp32 golden.  It is needed for one family of tensors: the to_q / to_k adapters of the LAST block.
