@@ -168,3 +168,17 @@ def test_dpm_sampler_step_matches_oracle_restatement():
             x, old = s.step(v, old, t, back, x, noise=n)
             xo, oldo = osch.dpm_step(abar, v, oldo, t, back, xo, steps, n)
             assert torch.allclose(x, xo, rtol=0, atol=1e-12) and torch.allclose(old, oldo, rtol=0, atol=1e-12)
+
+
+def test_variant_configs_match_the_reference_scripts():
+    """Per-script hyper-parameters (train/*/03_train.py DEFAULT_CONFIG + the 1.5 script's hard-coded weight decay)."""
+    from videogpa_amd.trainer import variant_config
+    t2v, i2v, v15 = variant_config("t2v"), variant_config("i2v"), variant_config("1.5")
+    assert (t2v["batch_size"], t2v["accumulate_grad_batches"], t2v["max_steps"], t2v["weight_decay"]) == (1, 2, 10000, 0.01)
+    assert (i2v["batch_size"], i2v["accumulate_grad_batches"]) == (2, 1)
+    assert (v15["max_steps"], v15["weight_decay"]) == (1500, 1e-3)
+    for c in (t2v, i2v, v15):
+        assert (c["lora_rank"], c["lora_alpha"], c["learning_rate"], c["warmup_steps"], c["gradient_clip_val"], c["beta"]) == (64, 128, 5e-6, 500, 1.0, 1.0)
+    import pytest
+    with pytest.raises(ValueError):
+        variant_config("2b")

@@ -41,6 +41,27 @@ DEFAULT_CONFIG: Dict[str, Any] = {
 }
 
 
+# What the reference's four training scripts change against the T2V defaults (their DEFAULT_CONFIG dicts and optimizer lines):
+#   I2V  train/CogVideoX-I2V-5B/03_train.py:59-60   batch 2, no accumulation
+#   1.5  train/CogVideoX1.5-5B/03_train.py:54,210   1500 steps, AdamW weight_decay 1e-3 (hard-coded there)
+#   Wan  train/Wan2.2-TI2V-5B/03_train.py:54-97     q/k/v/o targets, flow-matching shift 5 (videogpa_amd/wan.py)
+VARIANT_CONFIGS: Dict[str, Dict[str, Any]] = {
+    "t2v": {},
+    "i2v": {"batch_size": 2, "accumulate_grad_batches": 1},
+    "1.5": {"max_steps": 1500, "weight_decay": 1e-3},
+}
+
+
+def variant_config(variant: str, **overrides) -> Dict[str, Any]:
+    """DEFAULT_CONFIG of the named reference script ("t2v", "i2v", "1.5") as a dict for CogVideoXDPOTrainer / fit."""
+    if variant not in VARIANT_CONFIGS:
+        raise ValueError(f"unknown variant {variant!r}; one of {sorted(VARIANT_CONFIGS)}")
+    cfg = dict(DEFAULT_CONFIG)
+    cfg.update(VARIANT_CONFIGS[variant])
+    cfg.update(overrides)
+    return cfg
+
+
 class CogVideoXDPOTrainer(nn.Module):
     def __init__(self, config: Dict[str, Any], transformer: Optional[nn.Module] = None, scheduler=None, separate_ref: bool = False,
                  image_encoder=None):
