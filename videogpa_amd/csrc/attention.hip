@@ -22,46 +22,18 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "mfma_tiles.h"
+#include "attn_common.h"
 
-// fp32 adds / multiplies next to MFMAs are written one element at a time and this file is built with -fno-slp-vectorize:
-// a packed fp32 instruction (v_pk_add_f32, v_pk_mul_f32) does not co-issue with the matrix pipe -- tools/dot2_probe: 2
-// v_pk_add_f32 per MFMA stretch a 64 ns group of four MFMAs to 107 ns, 4 scalar v_add_f32 leave it at 68 ns -- and hipcc's
-// SLP vectoriser would pack adjacent scalar operations by itself.  (Not inline asm: the compiler must see these to place
-// the MFMA -> VALU hazard wait states.)
-__device__ __forceinline__ float nopack_add(float a, float b) { return a + b; }
-__device__ __forceinline__ float nopack_mul(float a, float b) { return a * b; }
-
-// XCD-aware remap of the linear block id: consecutive virtual ids (same head) land on one XCD.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, j = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-}
-
+#ifndef FWD_WPS
+#define FWD_WPS 2   // waves per SIMD the forward is compiled for (1 = the whole 512-register file per wave)
+#endif
+#ifndef DQ_WPS
+#define DQ_WPS 2
+#endif
 
 // =====================================================================================================
 // Forward:  O = softmax(scale * Q K^T) V ;  lse2 = log2 sum_k exp2(scale*log2e * q.k)
 // =====================================================================================================
-// bf16x8 fragment <-> 8 floats
-__device__ __forceinline__ void frag_to_f32(const bf16x8_t& f, float* o) {
-    const u32x4_t u = __builtin_bit_cast(u32x4_t, f);
-    unpack8(u, o);
-}
-__device__ __forceinline__ bf16x8_t f32_to_frag(const float* o) { return __builtin_bit_cast(bf16x8_t, pack8(o)); }
-
-// The "-m" operand of the folded softmax shift: -m = a1 + a2 + a3 exactly enough (3 bf16 pieces = 24 mantissa bits),
-// living in k-slots 0..2 of an extra MFMA k-step whose K-side operand is (1,1,1,0,...): the QK^T accumulators then
-// come out as  c*q.k - m  and go straight into exp2.
-__device__ __forceinline__ bf16x8_t shift_frag(float m, int hi) {
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (hi == 0) {
-        const float t = -m;
-        const float a1 = round_bf16(t), a2 = round_bf16(t - a1), a3 = round_bf16((t - a1) - a2);
-        o[0] = a1; o[1] = a2; o[2] = a3;
-    }
-    return f32_to_frag(o);
-}
-
 // -DFWD_DIAG: s_memtime stamps at four points of tiles 128..131 plus HW_ID, written INTO THE LSE BUFFER (the results are
 // then wrong by design); decoded by tools/fwd_diag.py.  -DFWD_DYN_LDS=90000 forces one workgroup per CU.
 #ifdef FWD_DIAG
@@ -441,7 +413,7 @@ __device__ __forceinline__ void safe_tile(const bf16_t* kl, const bf16_t* vl, in
 // (blockIdx % nsplit is also the XCD the workgroup lands on for nsplit = 8: the workgroups of one XCD share one key range.)
 #define FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64], m[256], l[256]
 template <int QB, int NW, bool SPLIT>
-__global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : FWD_WPS) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
                                                                  int S, int H, int n_qt, int task0, int nsplit, float* __restrict__ part) {
@@ -994,7 +966,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // SPLIT: as in the forward -- workgroup (task0 + blockIdx / nsplit, chunk blockIdx % nsplit) sweeps key tiles
 // [nt*chunk/nsplit, nt*(chunk+1)/nsplit) and leaves its unscaled fp32 dQ [128*QB][64] in `part`; attn_dq_merge_kernel adds them.
 template <int QB, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, DQ_WPS) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ LSE2, const float* __restrict__ DELTA,
                                                                bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo,
@@ -1577,14 +1549,6 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
     }
 }
 
-static inline bool stride_ok(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= HD && (st[0] % 8 == 0) && (st[1] % 8 == 0) && (st[2] % 8 == 0); }
-// every element offset reachable inside one (batch, head) slab and across the tensor must fit 31 bits
-static inline bool range_ok(const int64_t* st, int64_t B, int64_t H, int64_t S) {
-    return (B - 1) * st[0] + (H - 1) * st[1] + (S - 1) * st[2] + HD < ((int64_t)1 << 31);
-}
-static inline TStride mk(const int64_t* st) { TStride t; t.b = (uint32_t)st[0]; t.h = (uint32_t)st[1]; t.s = (uint32_t)st[2]; return t; }
-static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-
 #ifndef DQ_QB
 #define DQ_QB 2    // query blocks (of 32 rows) per wave in the dQ kernel
 #endif
@@ -1603,40 +1567,6 @@ extern "C" {
 // CONTRACT: q holds the queries PRE-MULTIPLIED by scale*log2(e) (vgpa_qknorm_rope_fwd writes them that way through
 // q_out_scale), in all four entry points; `scale` is still the softmax scale (used for the dQ / dK multipliers).
 // dq is the gradient w.r.t. the UNscaled query.
-// Workgroup slots the attention kernels have on the current device (2 workgroups of 256 threads per CU): a launch whose
-// task count is not a multiple of this ends in a partially filled scheduling round.  Read once per process.
-static int wg_slots() {
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        slots = 2 * cus;
-    }
-    return slots;
-}
-// How to run `tasks` equal tasks that each sweep `nt` tiles: n_main tasks as they are, the rest split `nsplit` ways along
-// the sweep so that they fill (at most) one round.  split_mode: -1 automatic, 0 never, k >= 2 force k chunks for ALL tasks
-// (tests).  Splitting is only worth it when the leftover round would be mostly empty and the chunks keep a few tiles each.
-static void split_plan(int64_t tasks, int nt, int split_mode, int max_split, int64_t* n_main, int* nsplit) {
-    *n_main = tasks;
-    *nsplit = 1;
-    if (split_mode == 0 || nt < 8) return;
-    if (split_mode >= 2) {
-        *n_main = 0;
-        *nsplit = split_mode < nt / 2 ? split_mode : nt / 2;
-        if (*nsplit > max_split) *nsplit = max_split;
-        return;
-    }
-    const int64_t slots = wg_slots();
-    const int64_t rem = tasks % slots;
-    if (tasks < slots || rem == 0 || rem * 2 > slots) return;      // a single round, a full last round, or one at least half full
-    int64_t k = slots / rem;
-    if (k > nt / 4) k = nt / 4;
-    if (k > max_split) k = max_split;
-    if (k < 2) return;
-    *n_main = tasks - rem;
-    *nsplit = (int)k;
-}
 #define FWD_MAX_SPLIT 16
 
 size_t vgpa_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t S) {

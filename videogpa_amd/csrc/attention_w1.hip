@@ -1,0 +1,181 @@
+// "w1" attention kernels for gfx950: one wave per SIMD (a 4-wave workgroup owns a CU), the whole 512-entry register file per
+// wave, streamed tiles by LDS-DMA.  Same mathematics, operand conventions and C ABI as attention.hip (see the header there);
+// what changes is the blocking:
+//   * __launch_bounds__(256, 1): accumulators and the stationary operand fragments (MFMA-only values) may live in the
+//     accumulator half of the register file, which leaves the 256 architectural VGPRs to a software pipeline that is one
+//     32-row half-tile deep in every stage:   scores(g+1)  ||  exp / multiply / pack (g)  ||  accumulate (g-1),
+//     the stage the 2-waves-per-SIMD kernels could not hold in 256 registers.
+//   * K/V (Q/dO) tiles never pass through VGPRs: each wave issues `buffer_load_dwordx4 ... lds` pieces two tiles ahead
+//     into a 4-slot ring (attn_w1.h), completion counted by hand (s_waitcnt vmcnt(N)), ONE s_barrier per 64-row tile.
+//   * the LDS image is unpadded and chunk-swizzled: row-fragment reads and transpose reads are both conflict-free.
+#include "attn_common.h"
+
+#include <type_traits>
+
+#include "attn_w1.h"
+
+// =====================================================================================================
+// Backward, dQ:  dQ = scale * sum_k dS[q,k] K[k],  dS = P o (dP - delta),  P = exp2(c*s - lse2),  dP = dO V^T
+// (S^T and dP^T are made per 32-key half-tile with q on the MFMA columns; -lse2 and -delta ride an extra k-step.)
+// The main loop is tools/gen_w1_asm.py::DqLoop (w1_dq_loop.inc): read its docstring for the pipeline and the register map.
+// =====================================================================================================
+typedef __attribute__((ext_vector_type(16))) uint32_t u32x16_t;
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
+
+__device__ __forceinline__ u32x16_t pack4(const bf16x8_t& a, const bf16x8_t& b, const bf16x8_t& c, const bf16x8_t& d) {
+    const u32x4_t w[4] = {__builtin_bit_cast(u32x4_t, a), __builtin_bit_cast(u32x4_t, b), __builtin_bit_cast(u32x4_t, c), __builtin_bit_cast(u32x4_t, d)};
+    u32x16_t r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = w[i >> 2][i & 3];
+    return r;
+}
+
+// SPLIT: workgroup (task0 + blockIdx / nsplit, chunk blockIdx % nsplit) sweeps key tiles [nt*chunk/nsplit, nt*(chunk+1)/nsplit)
+// and leaves its unscaled fp32 dQ [256][64] in `part` (attn_dq_merge_kernel of attention.hip adds the chunks).
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                  const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                                  const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                                  bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo,
+                                                                  TStride sdq, int S, int H, int n_qt, float scale, int task0, int nsplit,
+                                                                  float* __restrict__ part) {
+    constexpr int QB = 2;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[W1_RING_BYTES];   // slot = [K tile | V tile]
+    const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
+    const int chunk = SPLIT ? (int)blockIdx.x % nsplit : 0;
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int q0 = (qt * 4 + wave) * (32 * QB);
+
+    // stationary operands first, and waited for, so that no compiler-counted VMEM operation is in flight next to the LDS-DMA
+    bf16x8_t qf[QB][4], dof[QB][4], qx[QB], dx[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        load_row_frags(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0 + 32 * j, S, lane, qf[j]);
+        load_row_frags(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0 + 32 * j, S, lane, dof[j]);
+        int qc = q0 + 32 * j + (lane & 31);
+        qc = qc < S ? qc : S - 1;
+        qx[j] = shift_frag(LSE2[(int64_t)bh * S + qc], hi);   // -lse folded into the QK^T chain
+        dx[j] = shift_frag(DELTA[(int64_t)bh * S + qc], hi);  // -delta folded into the dP chain
+    }
+    bf16x8_t kx;
+    {
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
+        kx = f32_to_frag(o8);
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) { frags_arrived(qf[j]); frags_arrived(dof[j]); }
+
+    const int nt_all = (S + TILE - 1) / TILE;
+    const int tb = SPLIT ? nt_all * chunk / nsplit : 0;              // this workgroup's key tiles: [tb, nt)
+    const int nt = SPLIT ? nt_all * (chunk + 1) / nsplit : nt_all;
+
+    // the pipeline's first transposed-K reads hit the slot "before" tile tb (ring slot 3): make it finite
+    {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4_t*>(lds + 3 * W1_SLOT_BYTES + threadIdx.x * 16) = z;
+        *reinterpret_cast<u32x4_t*>(lds + 3 * W1_SLOT_BYTES + 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
+    const W1Rsrc krs = w1_rsrc(Kb, ((uint32_t)(S - 1) * sk.s + (uint32_t)HD) * 2u);
+    const W1Rsrc vrs = w1_rsrc(Vb, ((uint32_t)(S - 1) * sv.s + (uint32_t)HD) * 2u);
+    uint32_t kvo[2], vvo[2];
+    w1_dma_offsets<2>(wave, lane, sk.s, kvo);
+    w1_dma_offsets<2>(wave, lane, sv.s, vvo);
+    const uint32_t kstep = __builtin_amdgcn_readfirstlane(64u * sk.s * 2u), vstep = __builtin_amdgcn_readfirstlane(64u * sv.s * 2u);   // bytes per tile
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds + (uint32_t)wave * 2048u);
+    // The tile offset rides in the per-lane offset (not in the scalar offset): the descriptor's range check must see it, so
+    // that rows at or past S -- and whole tiles past the end -- arrive as zeros.
+    u32x4_t voff = {kvo[0] + (uint32_t)tb * kstep, kvo[1] + (uint32_t)tb * kstep, vvo[0] + (uint32_t)tb * vstep, vvo[1] + (uint32_t)tb * vstep};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // tiles tb, tb + 1 -> ring slots 0, 1
+        const uint32_t dst = wbase + (uint32_t)i * W1_SLOT_BYTES;
+        w1_dma(dst, krs, voff[0], 0u);
+        w1_dma(dst + 1024u, krs, voff[1], 0u);
+        w1_dma(dst + W1_TILE_BYTES, vrs, voff[2], 0u);
+        w1_dma(dst + W1_TILE_BYTES + 1024u, vrs, voff[3], 0u);
+        voff[0] += kstep; voff[1] += kstep; voff[2] += vstep; voff[3] += vstep;
+    }
+
+    const W1Lane la = w1_lane_offsets(lane);
+    const u32x8_t la8 = {la.row[0], la.row[1], la.row[2], la.row[3], la.tr[0][0], la.tr[0][1], la.tr[1][0], la.tr[1][1]};
+    const u32x16_t qf0 = pack4(qf[0][0], qf[0][1], qf[0][2], qf[0][3]), qf1 = pack4(qf[1][0], qf[1][1], qf[1][2], qf[1][3]);
+    const u32x16_t do0 = pack4(dof[0][0], dof[0][1], dof[0][2], dof[0][3]), do1 = pack4(dof[1][0], dof[1][1], dof[1][2], dof[1][3]);
+    const u32x16_t xs = pack4(qx[0], qx[1], dx[0], dx[1]);
+    const u32x4_t kxw = __builtin_bit_cast(u32x4_t, kx);
+    const uint32_t niter = (uint32_t)(nt - tb + 1);   // one extra tile step drains the pipeline
+    f32x16_t dq[QB][2];
+    uint32_t t0, t1, t2;
+    asm volatile(
+#include "w1_dq_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "={a[0:15]}"(dq[0][0]), "={a[16:31]}"(dq[0][1]), "={a[32:47]}"(dq[1][0]), "={a[48:63]}"(dq[1][1]),
+          "+{v[200:203]}"(voff)
+        : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), "{a[64:79]}"(qf0),
+          "{a[80:95]}"(qf1), "{a[96:111]}"(do0), "{a[112:127]}"(do1), "{a[128:143]}"(xs), "{a[144:147]}"(kxw), "{v[192:199]}"(la8)
+        : "memory", "scc",
+#include "w1_dq_clobbers.inc"
+    );
+
+    if (SPLIT) {
+        float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * (128 * QB * HD);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const int r = wave * (32 * QB) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t w = {dq[j][db][4 * g], dq[j][db][4 * g + 1], dq[j][db][4 * g + 2], dq[j][db][4 * g + 3]};
+                    *reinterpret_cast<f32x4_t*>(pb + r * HD + db * 32 + 8 * g + 4 * hi) = w;
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < S) {
+            bf16_t* op = dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t w;
+                    w[0] = pack_bf16x2(dq[j][db][4 * g] * scale, dq[j][db][4 * g + 1] * scale);
+                    w[1] = pack_bf16x2(dq[j][db][4 * g + 2] * scale, dq[j][db][4 * g + 3] * scale);
+                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+                }
+        }
+    }
+}
+
+extern "C" {
+
+// dQ on the w1 structure; arguments as vgpa_attn_bwd_dq (include/videogpa_hip.h)
+int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dq,
+                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                            const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, hipStream_t stream) {
+    if (!q || !k || !v || !d_o || !lse2 || !delta || !dq || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
+#define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dq_strides) || !al16(q) || !al16(k) || !al16(v) ||
+        !al16(d_o) || !al16(dq))
+        return VGPA_ERR_INVALID;
+#undef SOK
+    const int rows = 256;
+    const int n_t = (int)((S + rows - 1) / rows);
+    const int64_t tasks = (int64_t)n_t * B * H;
+    if (tasks > 0x7fffffff) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH((attn_bwd_dq_w1_kernel<false>), dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                mk(dq_strides), (int)S, (int)H, n_t, scale, 0, 1, (float*)nullptr);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+}  // extern "C"
