@@ -133,11 +133,11 @@ int32_t vgpa_attn_bwd_dq(const void* q, const void* k, const void* v, const void
 /* fused alternative to bwd_dkv + bwd_dq (5 instead of 7 matrix products per score block): dK, dV as above, dQ added with
  * fp32 atomics into dq_f32 = fp32 [B,H,S,64] contiguous, which the CALLER MUST ZERO first. */
 /* dQ on the "w1" structure (attention_w1.hip: one wave per SIMD, 512-register waves, LDS-DMA ring, hand-scheduled main
- * loop); same arguments and results as vgpa_attn_bwd_dq. */
+ * loop); arguments and results as vgpa_attn_bwd_dq_ws (workspace >= vgpa_attn_bwd_split_workspace_bytes, may be NULL). */
 int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
                             void* dq, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                             const int64_t* do_strides, const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,
-                            float scale, vgpa_stream_t stream);
+                            float scale, int32_t split_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* vgpa_attn_bwd_dkv / _dq with a caller-owned workspace (>= vgpa_attn_bwd_split_workspace_bytes, may be shared by the two
  * calls): the leftover tasks of a mostly empty last scheduling round are cut into chunks along the streamed axis (second
  * small launch + fp32 merge), as in vgpa_attn_fwd_ws.  split_mode: -1 automatic, 0 never, k >= 2 force k chunks. */

@@ -68,28 +68,111 @@ class Emitter:
     def drain(self):
         self.lgkm = []
 
+    def arrived(self, tag):
+        return tag not in self.lgkm
+
+    def retag(self, mapping):
+        self.lgkm = [mapping.get(t, t) for t in self.lgkm]
+
     def text(self):
         return "\n".join('    "%s\\n\\t"' % ln for ln in self.lines)
+
+
+# ------------------------------------------------------------------------------------------------------ stream scheduling
+def schedule(em, mfmas, frag_issue, frag_need, valu, lead, pre_issued=(), post_issue=(), fill_first=()):
+    """Emit one straight-line stretch: `mfmas` = list of (text, frag id or None); `frag_need[f]` = index of the first MFMA that
+    reads fragment f; `frag_issue(f)` emits its LDS read(s) (tags them f).  Fragments are requested `lead` MFMAs ahead (those in
+    `pre_issued` already are); `post_issue` = callables emitting the next stretch's first requests, placed in the last gaps.
+    `valu` = ordered VALU/SALU/VMEM filler instructions, spread so that every MFMA gap carries about the same number of
+    instructions; `fill_first` = fillers that must come first, one per gap from gap 0 on (the LDS-DMA issue pairs).
+    Waits are merged per two fragments (one s_waitcnt per four MFMAs)."""
+    n = len(mfmas)
+    gap_ds = [[] for _ in range(n)]
+    for f, need in sorted(frag_need.items(), key=lambda kv: kv[1]):
+        if f in pre_issued:
+            continue
+        g = max(need - lead - 1, 0)
+        gap_ds[g].append(f)
+    for k, fn in enumerate(post_issue):
+        gap_ds[n - len(post_issue) + k].append(fn)
+    # which MFMAs carry a wait: the first reader of every second fragment (in need order) waits for that fragment AND the next
+    order = [f for f, _ in sorted(frag_need.items(), key=lambda kv: kv[1])]
+    wait_at = {}
+    for k in range(0, len(order), 2):
+        wait_at[frag_need[order[k]]] = order[min(k + 1, len(order) - 1)]
+    # the merged wait may only name a fragment that has been requested by then; otherwise fall back to single waits
+    fixed = list(fill_first)
+    weights = [len(gap_ds[g]) * 1 + (1 if (g + 1) in wait_at else 0) + (len(fixed[g]) if g < len(fixed) else 0) for g in range(n)]
+    total = sum(weights) + len(valu)
+    per_gap = [0] * n
+    # water-fill the VALU list over the gaps
+    left = len(valu)
+    level = max(weights) if weights else 0
+    target = -(-total // n)
+    for g in range(n):
+        room = max(target - weights[g], 0)
+        per_gap[g] = room
+    # trim / grow to match exactly
+    extra = sum(per_gap) - left
+    g = n - 1
+    while extra > 0:
+        if per_gap[g] > 0:
+            per_gap[g] -= 1
+            extra -= 1
+        g = g - 1 if g > 0 else n - 1
+    g = 0
+    while extra < 0:
+        per_gap[g] += 1
+        extra += 1
+        g = (g + 1) % n
+    vk = 0
+    requested = set(pre_issued)
+    for i, (text, f) in enumerate(mfmas):
+        if i in wait_at:
+            tgt = wait_at[i]
+            if tgt not in requested:
+                tgt = f
+            em.wait_tag(tgt)
+        elif f is not None and frag_need.get(f) == i and not em.arrived(f):
+            em.wait_tag(f)
+        if "nomfma" not in ABLATE:
+            em.raw(text)
+        if i < len(fixed):
+            for t in fixed[i]:
+                em.raw(t)
+        for item in gap_ds[i]:
+            if callable(item):
+                item()
+            else:
+                frag_issue(item)
+                requested.add(item)
+        for _ in range(per_gap[i]):
+            em.raw(valu[vk])
+            vk += 1
+    assert vk == len(valu), (vk, len(valu))
 
 
 # ---------------------------------------------------------------------------------------------------------------- dQ loop
 class DqLoop:
     """dQ:  per 32-key half-tile g (tile = g >> 1 in the K|V ring, key block kb = g & 1), two 32-row q-blocks j per wave:
-         A(g): S[g&1][j] = -lse + K_g Q_j^T, DP[g&1][j] = -delta + V_g dO_j^T          20 MFMAs (4 folds + 8 + 8)
+         A(g): S[g&1][j] = -lse + K_g Q_j^T, DP[g&1][j] = -delta + V_g dO_j^T          16 MFMAs (-lse / -delta enter as srcC)
          B(g): D[g&1][j] = bf16(exp2(S) * DP)                                             80 VALU
          C(g): dq[j] += K_g^T D[g&1][j]                                                   8 MFMAs (transpose-read K)
-       half-step(g) issues A(g+1) | B(g) | C(g-1) interleaved.  The loop is uniform from g = -1 to 2 nt: the pipeline is
-       filled and drained with zeros (S, DP, D start as 0; the slot "before the first tile" is zero-filled by the caller;
-       tiles past the end arrive as zeros because their rows are out of the buffer descriptor's range), and rows past S
-       need no masking at all: their K rows are zero, so whatever dS they get multiplies 0.
+       half-step(g) issues C(g-1) | A(g+1) | B(g) interleaved (the C products first: their fragments can be requested before
+       the tile barrier).  The loop is uniform from g = -1 to 2 nt: the pipeline is filled and drained with zeros (S, DP, D start
+       as 0; the slot "before the first tile" is zero-filled by the caller; tiles past the end arrive as zeros because their
+       rows are out of the buffer descriptor's range), and rows past S need no masking at all: their K rows are zero, so
+       whatever dS they get multiplies 0.
 
-       register map      a[0:63] dq[j][db]   a[64:95] qf[j][ks]   a[96:127] dof[j][ks]   a[128:143] qx0 qx1 dx0 dx1   a[144:147] kx
-                         v[0:127] S/DP[p][j] (p-major: s0 s1 dp0 dp1)   v[128:159] D[p][j][cc]   v[160:183] fragment ring (6)
-                         v[192:199] lane LDS offsets   v[200:203] LDS-DMA source offsets (K0 K1 V0 V1; advanced per tile)"""
+       register map      a[0:63] dq[j][db]   a[64:95] qf[j][ks]   a[96:127] dof[j][ks]   a[128:151] fragment ring (6 x 4)
+                         v[0:127] S/DP[p][j] (p-major: s0 s1 dp0 dp1)   v[128:159] D[p][j][cc]
+                         v[160:223] srcC of the first k-step: -lse2[q] x16 (j = 0,1), -delta[q] x16 (j = 0,1)
+                         v[224:231] lane LDS offsets   v[232:235] LDS-DMA source offsets (K0 K1 V0 V1; advanced per tile)"""
 
-    LA = 192
-    VOFF = 200
-    FR = 160
+    LA = 224
+    VOFF = 232
+    CI = 160
+    FR = 128       # AGPR
     NFR = 6
     LEAD = KNOB.get("lead", 6)       # fragment reads are issued this many MFMAs ahead of their first use
 
@@ -102,89 +185,89 @@ class DqLoop:
     def D(self, p, j, cc):
         return 128 + p * 16 + j * 8 + cc * 4
 
+    # fragments of one half-step: 0..3 K transposed (cc, db) = (f >> 1, f & 1) of the PREVIOUS tile; 4..7 K rows ks; 8..11 V rows ks.
+    # ring position advances continuously (12 per half-step, ring of 6: every half-step starts at position 0)
     def frag_reg(self, f):
-        return self.FR + 4 * (f % self.NFR)
+        return (160 if KNOB.get("ringv") else self.FR) + 4 * (f % self.NFR)
 
-    def issue_frag(self, em, f, slotA, kbA, slotC, kbC):
+    def fr(self, f):
+        return (vr if KNOB.get("ringv") else ar)(self.frag_reg(f), 4)
+
+    def issue_frag(self, em, f, slotA, kbA, slotC, kbC, tag=None):
         r = self.frag_reg(f)
-        if f < 4:      # K rows, ks = f
-            em.ds(f"ds_read_b128 {vr(r, 4)}, v{self.LA + f} offset:{slotA * 16384 + kbA * 4096}", f)
-        elif f < 8:    # V rows
-            em.ds(f"ds_read_b128 {vr(r, 4)}, v{self.LA + f - 4} offset:{slotA * 16384 + 8192 + kbA * 4096}", f)
-        else:          # K transposed, (cc, db) = ((f-8) >> 1, (f-8) & 1)
-            c = f - 8
-            cc, db = c >> 1, c & 1
+        ar = vr if KNOB.get("ringv") else globals()["ar"]
+        tag = f if tag is None else tag
+        if f < 4:
+            cc, db = f >> 1, f & 1
             off = slotC * 16384 + kbC * 4096 + cc * 2048
-            em.ds(f"ds_read_b64_tr_b16 {vr(r, 2)}, v{self.LA + 4 + 2 * db} offset:{off}", f)
-            em.ds(f"ds_read_b64_tr_b16 {vr(r + 2, 2)}, v{self.LA + 5 + 2 * db} offset:{off}", f)
+            em.ds(f"ds_read_b64_tr_b16 {ar(r, 2)}, v{self.LA + 4 + 2 * db} offset:{off}", tag)
+            em.ds(f"ds_read_b64_tr_b16 {ar(r + 2, 2)}, v{self.LA + 5 + 2 * db} offset:{off}", tag)
+        elif f < 8:
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{self.LA + f - 4} offset:{slotA * 16384 + kbA * 4096}", tag)
+        else:
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{self.LA + f - 8} offset:{slotA * 16384 + 8192 + kbA * 4096}", tag)
 
-    def mfma(self, i, pa, pc):
-        """text of MFMA slot i (0..27) and the fragment it needs (or None)"""
-        j = i & 1
-        if i < 2:
-            return f"{MFMA} {vr(self.S(pa, j), 16)}, {ar(144, 4)}, {ar(128 + 4 * j, 4)}, 0", None
-        if i < 4:
-            return f"{MFMA} {vr(self.DP(pa, j), 16)}, {ar(144, 4)}, {ar(136 + 4 * j, 4)}, 0", None
-        if i < 12:
-            ks = (i - 4) >> 1
-            d = vr(self.S(pa, j), 16)
-            return f"{MFMA} {d}, {vr(self.frag_reg(ks), 4)}, {ar(64 + 16 * j + 4 * ks, 4)}, {d}", ks
-        if i < 20:
-            ks = (i - 12) >> 1
-            d = vr(self.DP(pa, j), 16)
-            return f"{MFMA} {d}, {vr(self.frag_reg(4 + ks), 4)}, {ar(96 + 16 * j + 4 * ks, 4)}, {d}", 4 + ks
-        c = (i - 20) >> 1
-        cc, db = c >> 1, c & 1
-        d = ar(32 * j + 16 * db, 16)
-        return f"{MFMA} {d}, {vr(self.frag_reg(8 + c), 4)}, {vr(self.D(pc, j, cc), 4)}, {d}", 8 + c
+    def mfmas(self, pa, pc):
+        out = []
+        for i in range(24):
+            j = i & 1
+            if i < 8:
+                c = i >> 1
+                cc, db = c >> 1, c & 1
+                d = ar(32 * j + 16 * db, 16)
+                out.append((f"{MFMA} {d}, {self.fr(c)}, {vr(self.D(pc, j, cc), 4)}, {d}", c))
+            elif i < 16:
+                ks = (i - 8) >> 1
+                d = vr(self.S(pa, j), 16)
+                c = (vr(self.CI + 16 * j, 16) if KNOB.get("cinit", 1) in (1, 2) else "0") if ks == 0 else d
+                out.append((f"{MFMA} {d}, {self.fr(4 + ks)}, {ar(64 + 16 * j + 4 * ks, 4)}, {c}", 4 + ks))
+            else:
+                ks = (i - 16) >> 1
+                d = vr(self.DP(pa, j), 16)
+                c = (vr(self.CI + 32 + 16 * j, 16) if KNOB.get("cinit", 1) in (1, 3) else "0") if ks == 0 else d
+                out.append((f"{MFMA} {d}, {self.fr(8 + ks)}, {ar(96 + 16 * j + 4 * ks, 4)}, {c}", 8 + ks))
+        return out
 
     def valu_ops(self, pb):
         """B stage on S[pb], DP[pb] -> D[pb]: 16 units of (exp, exp, mul, mul, cvt), software-pipelined by one unit"""
+        if "novalu" in ABLATE:
+            return []
+
         def unit(u):
             j, p = u >> 3, u & 7
             s0, d0 = self.S(pb, j) + 2 * p, self.DP(pb, j) + 2 * p
             w = self.D(pb, j, p >> 2) + (p & 3)
             return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
                     [f"v_mul_f32 v{s0}, v{d0}, v{s0}", f"v_mul_f32 v{s0 + 1}, v{d0 + 1}, v{s0 + 1}", f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}"])
+        if KNOB.get("vorder", 1) == 0:
+            ops = list(unit(0)[0])
+            for u in range(16):
+                if u + 1 < 16:
+                    ops += unit(u + 1)[0]
+                ops += unit(u)[1]
+            return ops
+        # no instruction directly follows one it depends on: step t = mul(t).a, exp(t+1).a, mul(t).b, exp(t+1).b, cvt(t-1)
         ops = list(unit(0)[0])
-        for u in range(16):
-            if u + 1 < 16:
-                ops += unit(u + 1)[0]
-            ops += unit(u)[1]
+        for t in range(17):
+            x = unit(t + 1)[0] if t + 1 < 16 else [None, None]
+            m = unit(t)[1][:2] if t < 16 else [None, None]
+            c = unit(t - 1)[1][2] if 1 <= t else None
+            ops += [o for o in (m[0], x[0], m[1], x[1], c) if o is not None]
         return ops
 
-    def half_step(self, em, slotA, kbA, slotC, kbC, pa, extra_valu=()):
-        """A writes S/DP[pa]; B reads S/DP[pa ^ 1], writes D[pa ^ 1]; C reads D[pa]"""
-        pb, pc = pa ^ 1, pa
-        valu = list(extra_valu) + ([] if "novalu" in ABLATE else self.valu_ops(pb))
-        nv = len(valu)
-        need = {f: 4 + 2 * f for f in range(12)}
-        issued = set()
-        for f in range(12):                      # fragments wanted within the first LEAD MFMAs
-            if need[f] - self.LEAD <= 0:
-                self.issue_frag(em, f, slotA, kbA, slotC, kbC)
-                issued.add(f)
-        vk = 0
-        for i in range(28):
-            text, f = self.mfma(i, pa, pc)
-            if f is not None and (i & 1) == 0:
-                em.wait_tag(f)
-            if "nomfma" not in ABLATE:
-                em.raw(text)
-            for g in range(12):
-                if g not in issued and need[g] - self.LEAD <= i + 1:
-                    self.issue_frag(em, g, slotA, kbA, slotC, kbC)
-                    issued.add(g)
-            vend = nv * (i + 1) // 28
-            while vk < vend:
-                em.raw(valu[vk])
-                vk += 1
-        assert vk == nv and len(issued) == 12
+    def half_step(self, em, slotA, kbA, slotC, kbC, pa, nxt, fill_first=()):
+        """C reads D[pa] (tile slotC, kbC); A writes S/DP[pa] (tile slotA, kbA); B reads S/DP[pa ^ 1], writes D[pa ^ 1].
+        nxt = (slotC, kbC) of the following half-step, whose transposed fragments are requested in the last four gaps (their ring positions are free by then)."""
+        need = {f: 2 * f for f in range(12)}
+        post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
+        # the prefetched fragments carry the tag ("n", f): rename them to plain f for this stretch
+        em.retag({("n", f): f for f in range(4)})
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+                 pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
 
     def generate(self):
         em = Emitter()
-        # operands: %0-%3 scratch SGPRs (=&s), %4.. inputs -- see attention_w1.hip
-        SAVE_M0, CNT, T0 = "%0", "%1", "%2"
+        SAVE_M0, CNT = "%0", "%1"
         RK, RV, KSTEP, VSTEP, WBASE, NITER = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]"
         em.raw(f"s_mov_b32 {SAVE_M0}, m0")
         em.raw(f"s_mov_b32 {CNT}, {NITER}")
@@ -192,25 +275,25 @@ class DqLoop:
             em.raw(f"v_accvgpr_write_b32 a{i}, 0")
         for r in list(range(64, 128)) + list(range(128, 144)):      # S/DP[1], D[0]
             em.raw(f"v_mov_b32 v{r}, 0")
+        # the first half-step's transposed fragments: tile "-1" = ring slot 3 (zero-filled by the caller), key block 0
+        for f in range(4):
+            self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
         em.raw("L_w1dq_loop_%=:")
         for ph in range(4):
-            # tile i (ring slot ph) must have landed for every wave; every read of tile i-2's slot is done -> DMA tile i+2 into it
-            em.raw("s_waitcnt vmcnt(4) lgkmcnt(0)")
-            em.drain()
+            # tile i (ring slot ph) must have landed for every wave.  Every read of tile i-2's slot has been waited for by its
+            # consumer MFMA, so after the barrier LDS-DMA may refill that slot with tile i+2 (issued inside the first gaps).
+            em.raw("s_waitcnt vmcnt(4)")
             if "nosync" not in ABLATE:
                 em.raw("s_barrier")
             dst = ((ph + 2) & 3) * 16384
-            adds = []
+            fill = []
             for k, (rs, extra) in enumerate([(RK, 0), (RK, 1024), (RV, 8192), (RV, 9216)]):
-                em.raw(f"s_add_u32 m0, {WBASE}, {dst + extra}")
-                em.raw("s_nop 0")
-                em.raw(f"buffer_load_dwordx4 v{self.VOFF + k}, {rs}, 0 offen lds")
-                adds.append(f"v_add_u32 v{self.VOFF + k}, {KSTEP if k < 2 else VSTEP}, v{self.VOFF + k}")
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + extra}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {rs}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {KSTEP if k < 2 else VSTEP}, v{self.VOFF + k}"])
             sp = (ph - 1) & 3
-            # half-step(2i-1): A(2i) -> S[0] (tile i, kb 0) | B(2i-1) on S[1] -> D[1] | C(2i-2): D[0], tile i-1, kb 0
-            self.half_step(em, ph, 0, sp, 0, 0, extra_valu=adds)
-            # half-step(2i):   A(2i+1) -> S[1] (tile i, kb 1) | B(2i) on S[0] -> D[0] | C(2i-1): D[1], tile i-1, kb 1
-            self.half_step(em, ph, 1, sp, 1, 1)
+            self.half_step(em, ph, 0, sp, 0, 0, nxt=(sp, 1), fill_first=fill)
+            self.half_step(em, ph, 1, sp, 1, 1, nxt=(ph, 0))
             em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
             em.raw(f"s_cmp_eq_u32 {CNT}, 0")
             if ph < 3:
@@ -225,16 +308,18 @@ class DqLoop:
         return em.text() + "\n"
 
 
-def clobbers(ranges):
+def clobbers(ranges, aranges=()):
     regs = []
     for lo, hi in ranges:
         regs += [f'"v{i}"' for i in range(lo, hi + 1)]
+    for lo, hi in aranges:
+        regs += [f'"a{i}"' for i in range(lo, hi + 1)]
     lines = [", ".join(regs[i:i + 16]) for i in range(0, len(regs), 16)]
     return ",\n".join("    " + ln for ln in lines) + "\n"
 
 
 TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
-           "w1_dq_clobbers.inc": lambda: clobbers([(0, 183)])}
+           "w1_dq_clobbers.inc": lambda: clobbers([(0, 159)], [(128, 151)])}
 
 
 def main():

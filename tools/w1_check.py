@@ -49,7 +49,8 @@ for (B, H, S) in [(1, 2, 128), (1, 1, 64), (2, 3, 100), (1, 2, 200), (1, 2, 777)
         same = torch.equal(r, n)
         err = (r.float() - n.float()).abs().max().item()
         fin = bool(torch.isfinite(n.float()).all())
-        print(f"B{B} H{H} S{S:5d} {name}: bitwise {same}  max|diff| {err:.3e} finite {fin}  ref absmax {r.float().abs().max().item():.3e}")
+        nd = int((r != n).sum())
+        print(f"B{B} H{H} S{S:5d} {name}: bitwise {same}  differing {nd}/{r.numel()}  max|diff| {err:.3e} finite {fin}  ref absmax {r.float().abs().max().item():.3e}")
         if not fin or err > 2e-2 * max(1.0, r.float().abs().max().item()):
             bad += 1
 print("PARITY", "FAIL" if bad else "OK")

@@ -31,7 +31,7 @@ def _stale(target, deps):
 
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
     if force or _stale(obj, [src] + headers):
         # the MFMA kernels keep fp32 adds / multiplies unpacked: v_pk_*_f32 does not co-issue with the matrix pipe (attention.hip)
         extra = ["-fno-slp-vectorize"] if os.path.basename(src) in ("attention.hip", "attention_w1.hip", "lora.hip") else []

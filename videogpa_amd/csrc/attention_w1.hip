@@ -50,21 +50,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
     const int q0 = (qt * 4 + wave) * (32 * QB);
 
     // stationary operands first, and waited for, so that no compiler-counted VMEM operation is in flight next to the LDS-DMA
-    bf16x8_t qf[QB][4], dof[QB][4], qx[QB], dx[QB];
+    bf16x8_t qf[QB][4], dof[QB][4];
+    f32x16_t cs[QB], cd[QB];
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         load_row_frags(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0 + 32 * j, S, lane, qf[j]);
         load_row_frags(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0 + 32 * j, S, lane, dof[j]);
         int qc = q0 + 32 * j + (lane & 31);
         qc = qc < S ? qc : S - 1;
-        qx[j] = shift_frag(LSE2[(int64_t)bh * S + qc], hi);   // -lse folded into the QK^T chain
-        dx[j] = shift_frag(DELTA[(int64_t)bh * S + qc], hi);  // -delta folded into the dP chain
-    }
-    bf16x8_t kx;
-    {
-        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
-        kx = f32_to_frag(o8);
+        // -lse2[q] and -delta[q] enter the score chains as the srcC of their first k-step (every accumulator row of column q)
+        const float nl = -LSE2[(int64_t)bh * S + qc], nd = -DELTA[(int64_t)bh * S + qc];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { cs[j][i] = nl; cd[j][i] = nd; }
     }
 #pragma unroll
     for (int j = 0; j < QB; ++j) { frags_arrived(qf[j]); frags_arrived(dof[j]); }
@@ -107,20 +104,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
     const u32x8_t la8 = {la.row[0], la.row[1], la.row[2], la.row[3], la.tr[0][0], la.tr[0][1], la.tr[1][0], la.tr[1][1]};
     const u32x16_t qf0 = pack4(qf[0][0], qf[0][1], qf[0][2], qf[0][3]), qf1 = pack4(qf[1][0], qf[1][1], qf[1][2], qf[1][3]);
     const u32x16_t do0 = pack4(dof[0][0], dof[0][1], dof[0][2], dof[0][3]), do1 = pack4(dof[1][0], dof[1][1], dof[1][2], dof[1][3]);
-    const u32x16_t xs = pack4(qx[0], qx[1], dx[0], dx[1]);
-    const u32x4_t kxw = __builtin_bit_cast(u32x4_t, kx);
     const uint32_t niter = (uint32_t)(nt - tb + 1);   // one extra tile step drains the pipeline
     f32x16_t dq[QB][2];
     uint32_t t0, t1, t2;
     asm volatile(
 #include "w1_dq_loop.inc"
         : "=&s"(t0), "=&s"(t1), "=&s"(t2), "={a[0:15]}"(dq[0][0]), "={a[16:31]}"(dq[0][1]), "={a[32:47]}"(dq[1][0]), "={a[48:63]}"(dq[1][1]),
-          "+{v[200:203]}"(voff)
+          "+{v[232:235]}"(voff)
         : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), "{a[64:79]}"(qf0),
-          "{a[80:95]}"(qf1), "{a[96:111]}"(do0), "{a[112:127]}"(do1), "{a[128:143]}"(xs), "{a[144:147]}"(kxw), "{v[192:199]}"(la8)
+          "{a[80:95]}"(qf1), "{a[96:111]}"(do0), "{a[112:127]}"(do1), "{v[160:175]}"(cs[0]), "{v[176:191]}"(cs[1]), "{v[192:207]}"(cd[0]), "{v[208:223]}"(cd[1]), "{v[224:231]}"(la8)
         : "memory", "scc",
 #include "w1_dq_clobbers.inc"
     );
+    // bring the accumulators over to the architectural registers as whole tuples (element reads straight off the asm's
+    // physical AGPR outputs make hipcc 7.2 emit illegal V_MOVs)
+#pragma unroll
+    for (int j = 0; j < QB; ++j) { asm volatile("" : "+v"(dq[j][0])); asm volatile("" : "+v"(dq[j][1])); }
 
     if (SPLIT) {
         float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * (128 * QB * HD);
@@ -155,26 +154,65 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
     }
 }
 
+// sum the key-range chunks of the split dQ tasks: one wave per query row, lane = d
+__global__ __launch_bounds__(256) void w1_dq_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_qt, int rows_per_task,
+                                                            bf16_t* __restrict__ dQ, TStride sdq, int S, int H, float scale) {
+    const int lane = threadIdx.x & 63, rows4 = rows_per_task >> 2;
+    const int r = ((int)blockIdx.x % rows4) * 4 + (threadIdx.x >> 6), tl = (int)blockIdx.x / rows4;
+    const int vid = task0 + tl, bh = vid / n_qt, qt = vid % n_qt;
+    const int q = qt * rows_per_task + r;
+    if (q >= S) return;
+    const float* pb = part + (size_t)tl * nsplit * rows_per_task * HD + r * HD + lane;
+    float acc = 0.f;
+    for (int c = 0; c < nsplit; ++c) acc += pb[(size_t)c * rows_per_task * HD];
+    const int b = bh / H, h = bh % H;
+    dQ[(size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s + lane] = f32_to_bf16(acc * scale);
+}
+
+#define W1_MAX_SPLIT 16
+static inline int64_t w1_slots() { return wg_slots() / 2; }   // one 256-thread workgroup per CU
+
 extern "C" {
 
-// dQ on the w1 structure; arguments as vgpa_attn_bwd_dq (include/videogpa_hip.h)
+// dQ on the w1 structure; arguments as vgpa_attn_bwd_dq_ws (include/videogpa_hip.h): with a workspace
+// (>= vgpa_attn_bwd_split_workspace_bytes) the tasks of a mostly empty last scheduling round are cut into key-range chunks.
 int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta, void* dq,
                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
-                            const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, hipStream_t stream) {
+                            const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode,
+                            void* workspace, size_t ws_bytes, hipStream_t stream) {
     if (!q || !k || !v || !d_o || !lse2 || !delta || !dq || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
 #define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dq_strides) || !al16(q) || !al16(k) || !al16(v) ||
-        !al16(d_o) || !al16(dq))
+        !al16(d_o) || !al16(dq) || (workspace && !al16(workspace)))
         return VGPA_ERR_INVALID;
 #undef SOK
     const int rows = 256;
     const int n_t = (int)((S + rows - 1) / rows);
     const int64_t tasks = (int64_t)n_t * B * H;
     if (tasks > 0x7fffffff) return VGPA_ERR_INVALID;
-    VGPA_LAUNCH((attn_bwd_dq_w1_kernel<false>), dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
-                mk(dq_strides), (int)S, (int)H, n_t, scale, 0, 1, (float*)nullptr);
-    VGPA_CHECK_LAUNCH();
+    int64_t n_main = tasks;
+    int nsplit = 1;
+    if (workspace) split_plan(tasks, (int)((S + TILE - 1) / TILE), split_mode, W1_MAX_SPLIT, &n_main, &nsplit, w1_slots());
+    const int64_t n_tail = tasks - n_main;
+    if (n_tail > 0 && ws_bytes < (size_t)n_tail * nsplit * rows * HD * sizeof(float)) {
+        if (split_mode >= 2) return VGPA_ERR_WORKSPACE;
+        n_main = tasks;
+    }
+    if (n_main > 0) {
+        VGPA_LAUNCH((attn_bwd_dq_w1_kernel<false>), dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                    (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                    mk(dq_strides), (int)S, (int)H, n_t, scale, 0, 1, (float*)nullptr);
+        VGPA_CHECK_LAUNCH();
+    }
+    if (n_main < tasks) {
+        VGPA_LAUNCH((attn_bwd_dq_w1_kernel<true>), dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                    (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                    mk(dq_strides), (int)S, (int)H, n_t, scale, (int)n_main, nsplit, (float*)workspace);
+        VGPA_CHECK_LAUNCH();
+        VGPA_LAUNCH(w1_dq_merge_kernel, dim3((unsigned)(n_tail * (rows / 4))), dim3(256), 0, stream, (const float*)workspace, nsplit, (int)n_main, n_t,
+                    rows, (bf16_t*)dq, mk(dq_strides), (int)S, (int)H, scale);
+        VGPA_CHECK_LAUNCH();
+    }
     return VGPA_OK;
 }
 

@@ -65,7 +65,7 @@ static inline int wg_slots() {
 // How to run `tasks` equal tasks that each sweep `nt` tiles: n_main tasks as they are, the rest split `nsplit` ways along
 // the sweep so that they fill (at most) one round.  split_mode: -1 automatic, 0 never, k >= 2 force k chunks for ALL tasks
 // (tests).  Splitting is only worth it when the leftover round would be mostly empty and the chunks keep a few tiles each.
-static inline void split_plan(int64_t tasks, int nt, int split_mode, int max_split, int64_t* n_main, int* nsplit) {
+static inline void split_plan(int64_t tasks, int nt, int split_mode, int max_split, int64_t* n_main, int* nsplit, int64_t slots = 0) {
     *n_main = tasks;
     *nsplit = 1;
     if (split_mode == 0 || nt < 8) return;
@@ -75,7 +75,7 @@ static inline void split_plan(int64_t tasks, int nt, int split_mode, int max_spl
         if (*nsplit > max_split) *nsplit = max_split;
         return;
     }
-    const int64_t slots = wg_slots();
+    if (slots <= 0) slots = wg_slots();
     const int64_t rem = tasks % slots;
     if (tasks < slots || rem == 0 || rem * 2 > slots) return;      // a single round, a full last round, or one at least half full
     int64_t k = slots / rem;

@@ -680,13 +680,8 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
     _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
         "vgpa_attn_bwd_dkv_ws", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
         _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
-    if "dq" in ATTN_W1:
-        _timed("attn_bwd_dq_kernel", 2.0 * S * S * Dh * B * H, lambda: _lib.call(
-            "vgpa_attn_bwd_dq_w1", q, k, v, do, lse, delta, dq, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
-            _bhs_strides(dq), B, H, S, Dh, float(scale), st))
-        return
     _timed("attn_bwd_dq_kernel", 2.0 * S * S * Dh * B * H, lambda: _lib.call(
-        "vgpa_attn_bwd_dq_ws", q, k, v, do, lse, delta, dq, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+        "vgpa_attn_bwd_dq_w1" if "dq" in ATTN_W1 else "vgpa_attn_bwd_dq_ws", q, k, v, do, lse, delta, dq, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
         _bhs_strides(dq), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
 
 
