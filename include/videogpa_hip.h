@@ -138,6 +138,14 @@ int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const v
                             void* dq, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                             const int64_t* do_strides, const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,
                             float scale, int32_t split_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* w1 backward, step 1 and step 2: vgpa_attn_bwd_prep_w1 writes delta (fp32 [B,H,S], as vgpa_attn_bwd_delta) and the statistics
+ * planes stats = fp32 [B,H,2,S] = {-lse2, -delta}; vgpa_attn_bwd_dkv_w1 = vgpa_attn_bwd_dkv_ws on the w1 structure, reading `stats`. */
+int32_t vgpa_attn_bwd_prep_w1(const void* o, const void* d_o, const float* lse2, const int64_t* o_strides, const int64_t* do_strides,
+                              float* delta, float* stats, int64_t B, int64_t H, int64_t S, int64_t head_dim, vgpa_stream_t stream);
+int32_t vgpa_attn_bwd_dkv_w1(const void* q, const void* k, const void* v, const void* d_o, const float* stats, void* dk, void* dv,
+                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                             const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,
+                             float scale, int32_t split_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* vgpa_attn_bwd_dkv / _dq with a caller-owned workspace (>= vgpa_attn_bwd_split_workspace_bytes, may be shared by the two
  * calls): the leftover tasks of a mostly empty last scheduling round are cut into chunks along the streamed axis (second
  * small launch + fp32 merge), as in vgpa_attn_fwd_ws.  split_mode: -1 automatic, 0 never, k >= 2 force k chunks. */

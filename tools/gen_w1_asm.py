@@ -308,6 +308,165 @@ class DqLoop:
         return em.text() + "\n"
 
 
+# --------------------------------------------------------------------------------------------------------------- dK/dV loop
+class DkvLoop:
+    """dK, dV:  a wave owns two 32-key blocks kb (K, V fragments and the dK^T, dV^T accumulators stay in AGPRs for the whole
+       sweep) and streams 64-row Q|dO tiles; per 32-row half-tile g (tile = g >> 1, row block qb = g & 1):
+         A(g): S[g&1][kb] = -lse[q] + Q_g K_kb^T,  DP[g&1][kb] = -delta[q] + dO_g V_kb^T   16 MFMAs; q runs over the accumulator
+               ROWS here, so the srcC of each chain's first k-step is a 16-register tuple read from the tile's statistics
+               (fp32 -lse2 / -delta of the 64 rows, brought in by LDS-DMA next to the tile)
+         B(g): P = exp2(S) -> PK[g&1][kb] (bf16), dS = P * DP -> DSK[g&1][kb] (bf16)          96 VALU
+         C(g): dV^T[kb] += dO_g^T P,  dK^T[kb] += Q_g^T dS                                    16 MFMAs on transpose-read fragments
+       half-step(g) issues C(g-1) | A(g+1) | B(g) interleaved; the loop is uniform (pipeline filled and drained with zeros; rows
+       past S need no mask: their Q / dO rows are zero, whatever P / dS they get multiplies 0).
+
+       register map   a[0:63] dk[kb][db]  a[64:127] dv[kb][db]  a[128:159] kf[kb][ks]  a[160:191] vf[kb][ks]  a[192:223] fragment ring (8 x 4)
+                      v[0:127] S/DP[p][kb] (p-major: s0 s1 dp0 dp1)   v[128:191] PK / DSK[p][kb][cc]   v[192:207] srcC -lse   v[208:223] srcC -delta
+                      v[224:231] lane LDS offsets   v[232:236] LDS-DMA source offsets (Q0 Q1 dO0 dO1 stats)   v237 statistics read base
+       LDS            ring slot s at 16384 s: Q tile | dO tile;  statistics of slot s at 65536 + 1024 s: wave w's 256-byte piece holds
+                      -lse2 of rows 16w..16w+15 at +0 and -delta of the same rows at +64"""
+
+    LA = 224
+    VOFF = 232
+    SB = 237
+    FR = 192
+    NFR = 8
+    LEAD = KNOB.get("lead", 6)
+
+    def S(self, p, kb):
+        return p * 64 + kb * 16
+
+    def DP(self, p, kb):
+        return p * 64 + 32 + kb * 16
+
+    def PK(self, p, kb, cc):
+        return 128 + p * 32 + kb * 8 + cc * 4
+
+    def DSK(self, p, kb, cc):
+        return 128 + p * 32 + 16 + kb * 8 + cc * 4
+
+    def frag_reg(self, f):
+        return self.FR + 4 * (f % self.NFR)
+
+    def issue_frag(self, em, f, slotA, qbA, slotC, qbC, tag=None):
+        """f 0..7: transposed fragments of the PREVIOUS half (even: dO tile, odd: Q tile; (cc, db) = (f >> 2, (f >> 1) & 1));
+        8..11: Q rows ks; 12..15: dO rows ks; "cs" / "cd": the srcC tuples (-lse / -delta of the 32 rows)"""
+        tag = f if tag is None else tag
+        if f == "cs" or f == "cd":
+            base = 192 if f == "cs" else 208
+            for g in range(4):
+                off = slotA * 1024 + 512 * qbA + 256 * (g >> 1) + 32 * (g & 1) + (64 if f == "cd" else 0)
+                em.ds(f"ds_read_b128 {vr(base + 4 * g, 4)}, v{self.SB} offset:{off}", tag)
+            return
+        r = self.frag_reg(f)
+        if f < 8:
+            c = f >> 1
+            cc, db = c >> 1, c & 1
+            off = slotC * 16384 + (8192 if (f & 1) == 0 else 0) + qbC * 4096 + cc * 2048
+            em.ds(f"ds_read_b64_tr_b16 {ar(r, 2)}, v{self.LA + 4 + 2 * db} offset:{off}", tag)
+            em.ds(f"ds_read_b64_tr_b16 {ar(r + 2, 2)}, v{self.LA + 5 + 2 * db} offset:{off}", tag)
+        elif f < 12:
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{self.LA + f - 8} offset:{slotA * 16384 + qbA * 4096}", tag)
+        else:
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{self.LA + f - 12} offset:{slotA * 16384 + 8192 + qbA * 4096}", tag)
+
+    def mfmas(self, pa, pc):
+        out = []
+        for i in range(32):
+            kb = i & 1
+            if i < 16:
+                f = i >> 1
+                c = f >> 1
+                cc, db = c >> 1, c & 1
+                if (f & 1) == 0:
+                    d = ar(64 + 32 * kb + 16 * db, 16)
+                    b = vr(self.PK(pc, kb, cc), 4)
+                else:
+                    d = ar(32 * kb + 16 * db, 16)
+                    b = vr(self.DSK(pc, kb, cc), 4)
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(f), 4)}, {b}, {d}", f))
+            elif i < 24:
+                ks = (i - 16) >> 1
+                d = vr(self.S(pa, kb), 16)
+                c = vr(192, 16) if ks == 0 else d
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(8 + ks), 4)}, {ar(128 + 16 * kb + 4 * ks, 4)}, {c}", 8 + ks))
+            else:
+                ks = (i - 24) >> 1
+                d = vr(self.DP(pa, kb), 16)
+                c = vr(208, 16) if ks == 0 else d
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(12 + ks), 4)}, {ar(160 + 16 * kb + 4 * ks, 4)}, {c}", 12 + ks))
+        return out
+
+    def valu_ops(self, pb):
+        if "novalu" in ABLATE:
+            return []
+
+        def unit(u):
+            kb, p = u >> 3, u & 7
+            s0, d0 = self.S(pb, kb) + 2 * p, self.DP(pb, kb) + 2 * p
+            wp, wd = self.PK(pb, kb, p >> 2) + (p & 3), self.DSK(pb, kb, p >> 2) + (p & 3)
+            return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                    [f"v_mul_f32 v{d0}, v{d0}, v{s0}", f"v_mul_f32 v{d0 + 1}, v{d0 + 1}, v{s0 + 1}"],
+                    [f"v_cvt_pk_bf16_f32 v{wp}, v{s0}, v{s0 + 1}", f"v_cvt_pk_bf16_f32 v{wd}, v{d0}, v{d0 + 1}"])
+        ops = list(unit(0)[0])
+        for t in range(17):
+            x = unit(t + 1)[0] if t + 1 < 16 else [None, None]
+            m = unit(t)[1] if t < 16 else [None, None]
+            c = unit(t - 1)[2] if 1 <= t else [None, None]
+            ops += [o for o in (m[0], x[0], c[0], m[1], x[1], c[1]) if o is not None]
+        return ops
+
+    def half_step(self, em, slotA, qbA, slotC, qbC, pa, nxt, fill_first=()):
+        need = {f: 2 * f for f in range(16)}
+        need["cs"] = 16
+        need["cd"] = 24
+        post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
+        em.retag({("n", f): f for f in range(4)})
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, qbA, slotC, qbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+                 pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT = "%0", "%1"
+        RQ, RDO, RST, QSTEP, DSTEP, WBASE, SBASE, NITER = "%[rq]", "%[rdo]", "%[rst]", "%[qstep]", "%[dstep]", "%[wbase]", "%[sbase]", "%[niter]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        for i in range(128):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        for r in list(range(64, 128)) + list(range(128, 160)):      # S/DP[1], PK/DSK[0]
+            em.raw(f"v_mov_b32 v{r}, 0")
+        for f in range(4):
+            self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        em.raw("L_w1dkv_loop_%=:")
+        for ph in range(4):
+            em.raw("s_waitcnt vmcnt(5)")
+            if "nosync" not in ABLATE:
+                em.raw("s_barrier")
+            dst = ((ph + 2) & 3) * 16384
+            fill = []
+            for k, (rs, extra) in enumerate([(RQ, 0), (RQ, 1024), (RDO, 8192), (RDO, 9216)]):
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + extra}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {rs}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {QSTEP if k < 2 else DSTEP}, v{self.VOFF + k}"])
+            fill.append([f"s_add_u32 m0, {SBASE}, {((ph + 2) & 3) * 1024}"])
+            fill.append([f"buffer_load_dword v{self.VOFF + 4}, {RST}, 0 offen lds", f"v_add_u32 v{self.VOFF + 4}, 256, v{self.VOFF + 4}"])
+            sp = (ph - 1) & 3
+            self.half_step(em, ph, 0, sp, 0, 0, nxt=(sp, 1), fill_first=fill)
+            self.half_step(em, ph, 1, sp, 1, 1, nxt=(ph, 0))
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if ph < 3:
+                em.raw("s_cbranch_scc1 L_w1dkv_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1dkv_loop_%=")
+        em.raw("L_w1dkv_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 def clobbers(ranges, aranges=()):
     regs = []
     for lo, hi in ranges:
@@ -319,7 +478,9 @@ def clobbers(ranges, aranges=()):
 
 
 TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
-           "w1_dq_clobbers.inc": lambda: clobbers([(0, 159)], [(128, 151)])}
+           "w1_dq_clobbers.inc": lambda: clobbers([(0, 159)], [(128, 151)]),
+           "w1_dkv_loop.inc": lambda: DkvLoop().generate(),
+           "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)])}
 
 
 def main():

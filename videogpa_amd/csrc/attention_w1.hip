@@ -154,6 +154,189 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
     }
 }
 
+// =====================================================================================================
+// Backward, dK / dV:  dV = P^T dO,  dK = scale * dS^T Q      (workgroup = 256 keys = 4 waves x 2 key blocks; streams Q | dO tiles)
+// The main loop is tools/gen_w1_asm.py::DkvLoop (w1_dkv_loop.inc).  `stats` = fp32 [B, H, 2, S]: plane 0 = -lse2, plane 1 = -delta
+// (w1_bwd_prep_kernel); the 64 rows' statistics of a tile travel next to it by LDS-DMA and enter the score chains as srcC.
+// =====================================================================================================
+#define W1_STAT_BYTES 1024   // per ring slot: 4 waves x (16 x -lse2 | 16 x -delta | 128 B unused)
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                   const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                                   const float* __restrict__ STATS, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
+                                                                   TStride sq, TStride sk, TStride sv, TStride sdo, TStride sdk, TStride sdv, int S,
+                                                                   int H, int n_kt, float kscale, int task0, int nsplit, float* __restrict__ part) {
+    constexpr int KB = 2;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[W1_RING_BYTES + W1_SLOTS * W1_STAT_BYTES];   // slot = [Q tile | dO tile]; statistics behind the ring
+    const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
+    const int chunk = SPLIT ? (int)blockIdx.x % nsplit : 0;
+    const int bh = vid / n_kt, kt = vid % n_kt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int k0 = (kt * 4 + wave) * (32 * KB);
+
+    bf16x8_t kf[KB][4], vf[KB][4];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        load_row_frags(K + ((size_t)b * sk.b + (size_t)h * sk.h), sk.s, k0 + 32 * j, S, lane, kf[j]);
+        load_row_frags(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, k0 + 32 * j, S, lane, vf[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < KB; ++j) { frags_arrived(kf[j]); frags_arrived(vf[j]); }
+
+    const int nt_all = (S + TILE - 1) / TILE;
+    const int tb = SPLIT ? nt_all * chunk / nsplit : 0;              // this workgroup's query tiles: [tb, nt)
+    const int nt = SPLIT ? nt_all * (chunk + 1) / nsplit : nt_all;
+
+    // the pipeline's first transposed reads hit the slot "before" tile tb (ring slot 3, both tiles): make it finite
+    {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(lds + 3 * W1_SLOT_BYTES + i * 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
+    const bf16_t* dOb = dO + ((size_t)b * sdo.b + (size_t)h * sdo.h);
+    const W1Rsrc qrs = w1_rsrc(Qb, ((uint32_t)(S - 1) * sq.s + (uint32_t)HD) * 2u);
+    const W1Rsrc dors = w1_rsrc(dOb, ((uint32_t)(S - 1) * sdo.s + (uint32_t)HD) * 2u);
+    const W1Rsrc strs = w1_rsrc(STATS + (int64_t)bh * 2 * S, (uint32_t)(2 * S) * 4u);
+    uint32_t qvo[2], dvo[2];
+    w1_dma_offsets<2>(wave, lane, sq.s, qvo);
+    w1_dma_offsets<2>(wave, lane, sdo.s, dvo);
+    const uint32_t qstep = __builtin_amdgcn_readfirstlane(64u * sq.s * 2u), dstep = __builtin_amdgcn_readfirstlane(64u * sdo.s * 2u);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 2048u);
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)W1_RING_BYTES + (uint32_t)wave * 256u);
+    // statistics piece of this wave: lanes 0..15 fetch -lse2 of rows 16 wave + lane, lanes 16..31 -delta of the same rows (plane 1);
+    // the upper half-wave repeats the lower one (its 128 bytes of the LDS piece are never read)
+    const uint32_t srow = (uint32_t)(16 * wave + (lane & 15)), splane = (uint32_t)((lane >> 4) & 1);
+    uint32_t svo = (splane * (uint32_t)S + srow + (uint32_t)tb * 64u) * 4u;
+    u32x4_t voff = {qvo[0] + (uint32_t)tb * qstep, qvo[1] + (uint32_t)tb * qstep, dvo[0] + (uint32_t)tb * dstep, dvo[1] + (uint32_t)tb * dstep};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // tiles tb, tb + 1 -> ring slots 0, 1
+        const uint32_t dst = wbase + (uint32_t)i * W1_SLOT_BYTES;
+        w1_dma(dst, qrs, voff[0], 0u);
+        w1_dma(dst + 1024u, qrs, voff[1], 0u);
+        w1_dma(dst + W1_TILE_BYTES, dors, voff[2], 0u);
+        w1_dma(dst + W1_TILE_BYTES + 1024u, dors, voff[3], 0u);
+        w1_dma4(sbase + (uint32_t)i * W1_STAT_BYTES, strs, svo, 0u);
+        voff[0] += qstep; voff[1] += qstep; voff[2] += dstep; voff[3] += dstep;
+        svo += 256u;
+    }
+
+    const W1Lane la = w1_lane_offsets(lane);
+    const u32x8_t la8 = {la.row[0], la.row[1], la.row[2], la.row[3], la.tr[0][0], la.tr[0][1], la.tr[1][0], la.tr[1][1]};
+    const uint32_t sread = lds0 + (uint32_t)W1_RING_BYTES + 16u * (uint32_t)hi;
+    const u32x16_t kf0 = pack4(kf[0][0], kf[0][1], kf[0][2], kf[0][3]), kf1 = pack4(kf[1][0], kf[1][1], kf[1][2], kf[1][3]);
+    const u32x16_t vf0 = pack4(vf[0][0], vf[0][1], vf[0][2], vf[0][3]), vf1 = pack4(vf[1][0], vf[1][1], vf[1][2], vf[1][3]);
+    const uint32_t niter = (uint32_t)(nt - tb + 1);   // one extra tile step drains the pipeline
+    f32x16_t dk[KB][2], dv[KB][2];
+    uint32_t t0, t1;
+    asm volatile(
+#include "w1_dkv_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "={a[0:15]}"(dk[0][0]), "={a[16:31]}"(dk[0][1]), "={a[32:47]}"(dk[1][0]), "={a[48:63]}"(dk[1][1]),
+          "={a[64:79]}"(dv[0][0]), "={a[80:95]}"(dv[0][1]), "={a[96:111]}"(dv[1][0]), "={a[112:127]}"(dv[1][1]), "+{v[232:235]}"(voff), "+{v236}"(svo)
+        : [rq] "s"(qrs.w), [rdo] "s"(dors.w), [rst] "s"(strs.w), [qstep] "s"(qstep), [dstep] "s"(dstep), [wbase] "s"(wbase), [sbase] "s"(sbase),
+          [niter] "s"(niter), "{a[128:143]}"(kf0), "{a[144:159]}"(kf1), "{a[160:175]}"(vf0), "{a[176:191]}"(vf1), "{v[224:231]}"(la8), "{v237}"(sread)
+        : "memory", "scc",
+#include "w1_dkv_clobbers.inc"
+    );
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { asm volatile("" : "+v"(dk[j][db])); asm volatile("" : "+v"(dv[j][db])); }
+
+    if (SPLIT) {   // unscaled fp32 partials: [dK 256 x 64 | dV 256 x 64] per (task, chunk)
+        float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * (2 * 256 * HD);
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int r = wave * (32 * KB) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t wk = {dk[j][db][4 * g], dk[j][db][4 * g + 1], dk[j][db][4 * g + 2], dk[j][db][4 * g + 3]};
+                    const f32x4_t wv = {dv[j][db][4 * g], dv[j][db][4 * g + 1], dv[j][db][4 * g + 2], dv[j][db][4 * g + 3]};
+                    *reinterpret_cast<f32x4_t*>(pb + r * HD + db * 32 + 8 * g + 4 * hi) = wk;
+                    *reinterpret_cast<f32x4_t*>(pb + 256 * HD + r * HD + db * 32 + 8 * g + 4 * hi) = wv;
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        const int k = k0 + 32 * j + (lane & 31);
+        if (k < S) {
+            bf16_t* kp = dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s);
+            bf16_t* vp = dV + ((size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)k * sdv.s);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t w;
+                    w[0] = pack_bf16x2(dk[j][db][4 * g] * kscale, dk[j][db][4 * g + 1] * kscale);
+                    w[1] = pack_bf16x2(dk[j][db][4 * g + 2] * kscale, dk[j][db][4 * g + 3] * kscale);
+                    *reinterpret_cast<u32x2_t*>(kp + db * 32 + 8 * g + 4 * hi) = w;
+                    w[0] = pack_bf16x2(dv[j][db][4 * g], dv[j][db][4 * g + 1]);
+                    w[1] = pack_bf16x2(dv[j][db][4 * g + 2], dv[j][db][4 * g + 3]);
+                    *reinterpret_cast<u32x2_t*>(vp + db * 32 + 8 * g + 4 * hi) = w;
+                }
+        }
+    }
+}
+
+// sum the query-range chunks of the split dK/dV tasks: one wave per key row, lane = d
+__global__ __launch_bounds__(256) void w1_dkv_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_kt, bf16_t* __restrict__ dK,
+                                                             bf16_t* __restrict__ dV, TStride sdk, TStride sdv, int S, int H, float kscale) {
+    const int lane = threadIdx.x & 63;
+    const int r = ((int)blockIdx.x % 64) * 4 + (threadIdx.x >> 6), tl = (int)blockIdx.x / 64;
+    const int vid = task0 + tl, bh = vid / n_kt, kt = vid % n_kt;
+    const int key = kt * 256 + r;
+    if (key >= S) return;
+    const float* pb = part + (size_t)tl * nsplit * (2 * 256 * HD) + r * HD + lane;
+    float ak = 0.f, av = 0.f;
+    for (int c = 0; c < nsplit; ++c) {
+        ak += pb[(size_t)c * (2 * 256 * HD)];
+        av += pb[(size_t)c * (2 * 256 * HD) + 256 * HD];
+    }
+    const int b = bh / H, h = bh % H;
+    dK[(size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)key * sdk.s + lane] = f32_to_bf16(ak * kscale);
+    dV[(size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)key * sdv.s + lane] = f32_to_bf16(av);
+}
+
+// step 1 of the w1 backward: delta[b,h,q] = sum_d dO * O (as vgpa_attn_bwd_delta) and the statistics planes the dK/dV kernel
+// streams: stats[b,h,0,q] = -lse2, stats[b,h,1,q] = -delta
+__global__ __launch_bounds__(256) void w1_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, const float* __restrict__ LSE2,
+                                                            TStride sdo, TStride so, int S, int H, int64_t total /* B*H*S */, float* __restrict__ delta,
+                                                            float* __restrict__ stats) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 8 lanes per (b,h,q) row, 16 B each
+    const int64_t row = gid >> 3;
+    const int c8 = (int)(gid & 7);
+    float acc = 0.f;
+    int64_t bh = 0;
+    int q = 0;
+    if (row < total) {
+        q = (int)(row % S);
+        bh = row / S;
+        const int h = (int)(bh % H), b = (int)(bh / H);
+        float a[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h + (size_t)q * sdo.s + c8 * 8)), a);
+        unpack8(*reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c8 * 8)), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (row < total && c8 == 0) {
+        delta[row] = acc;
+        stats[bh * 2 * S + q] = -LSE2[row];
+        stats[bh * 2 * S + S + q] = -acc;
+    }
+}
+
 // sum the key-range chunks of the split dQ tasks: one wave per query row, lane = d
 __global__ __launch_bounds__(256) void w1_dq_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_qt, int rows_per_task,
                                                             bf16_t* __restrict__ dQ, TStride sdq, int S, int H, float scale) {
@@ -211,6 +394,61 @@ int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const v
         VGPA_CHECK_LAUNCH();
         VGPA_LAUNCH(w1_dq_merge_kernel, dim3((unsigned)(n_tail * (rows / 4))), dim3(256), 0, stream, (const float*)workspace, nsplit, (int)n_main, n_t,
                     rows, (bf16_t*)dq, mk(dq_strides), (int)S, (int)H, scale);
+        VGPA_CHECK_LAUNCH();
+    }
+    return VGPA_OK;
+}
+
+
+// step 1 for the w1 dK/dV kernel: delta (fp32 [B,H,S]) and stats (fp32 [B,H,2,S] = {-lse2, -delta})
+int32_t vgpa_attn_bwd_prep_w1(const void* o, const void* d_o, const float* lse2, const int64_t* o_strides, const int64_t* do_strides, float* delta,
+                              float* stats, int64_t B, int64_t H, int64_t S, int64_t head_dim, hipStream_t stream) {
+    if (!o || !d_o || !lse2 || !delta || !stats || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
+#define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
+    if (!SOK(o_strides) || !SOK(do_strides) || !al16(o) || !al16(d_o)) return VGPA_ERR_INVALID;
+    const int64_t total = B * H * S;
+    VGPA_LAUNCH(w1_bwd_prep_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, lse2,
+                mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta, stats);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// dK, dV on the w1 structure: arguments as vgpa_attn_bwd_dkv_ws, with `stats` (vgpa_attn_bwd_prep_w1) in the place of lse2 / delta
+int32_t vgpa_attn_bwd_dkv_w1(const void* q, const void* k, const void* v, const void* d_o, const float* stats, void* dk, void* dv,
+                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
+                             const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
+                             int32_t split_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    (void)scale;
+    if (!q || !k || !v || !d_o || !stats || !dk || !dv || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dk_strides) || !SOK(dv_strides) || !al16(q) || !al16(k) ||
+        !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv) || (workspace && !al16(workspace)))
+        return VGPA_ERR_INVALID;
+#undef SOK
+    const int n_t = (int)((S + 255) / 256);
+    const int64_t tasks = (int64_t)n_t * B * H;
+    if (tasks > 0x7fffffff) return VGPA_ERR_INVALID;
+    const float kscale = 0.6931471805599453f;   // q arrives pre-scaled by scale * log2(e): dK = ln 2 * (dS^T Q)
+    int64_t n_main = tasks;
+    int nsplit = 1;
+    if (workspace) split_plan(tasks, (int)((S + TILE - 1) / TILE), split_mode, W1_MAX_SPLIT, &n_main, &nsplit, w1_slots());
+    const int64_t n_tail = tasks - n_main;
+    if (n_tail > 0 && ws_bytes < (size_t)n_tail * nsplit * 2 * 256 * HD * sizeof(float)) {
+        if (split_mode >= 2) return VGPA_ERR_WORKSPACE;
+        n_main = tasks;
+    }
+    if (n_main > 0) {
+        VGPA_LAUNCH((attn_bwd_dkv_w1_kernel<false>), dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (const bf16_t*)d_o, stats, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides), mk(dk_strides),
+                    mk(dv_strides), (int)S, (int)H, n_t, kscale, 0, 1, (float*)nullptr);
+        VGPA_CHECK_LAUNCH();
+    }
+    if (n_main < tasks) {
+        VGPA_LAUNCH((attn_bwd_dkv_w1_kernel<true>), dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                    (const bf16_t*)v, (const bf16_t*)d_o, stats, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides), mk(v_strides), mk(do_strides),
+                    mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, kscale, (int)n_main, nsplit, (float*)workspace);
+        VGPA_CHECK_LAUNCH();
+        VGPA_LAUNCH(w1_dkv_merge_kernel, dim3((unsigned)(n_tail * 64)), dim3(256), 0, stream, (const float*)workspace, nsplit, (int)n_main, n_t,
+                    (bf16_t*)dk, (bf16_t*)dv, mk(dk_strides), mk(dv_strides), (int)S, (int)H, kscale);
         VGPA_CHECK_LAUNCH();
     }
     return VGPA_OK;

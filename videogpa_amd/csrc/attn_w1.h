@@ -49,6 +49,20 @@ __device__ __forceinline__ void w1_dma(uint32_t lds_dst /* uniform */, const W1R
         : "memory");
 }
 
+// the 4-byte-per-lane form (256 B per wave-instruction)
+__device__ __forceinline__ void w1_dma4(uint32_t lds_dst /* uniform */, const W1Rsrc& rs, uint32_t voff, uint32_t soff /* uniform */) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dword %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(voff), "s"(rs.w), "s"(soff)
+        : "memory");
+}
+
 // wait until at most N of this wave's VMEM operations are outstanding, and all of its LDS reads have returned
 #define W1_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
 

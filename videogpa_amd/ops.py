@@ -664,8 +664,14 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
         q = prescale_q(q, scale)
     delta = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     st = _stream()
-    _timed("attn_delta_kernel", 4.0 * B * H * S * Dh, lambda: _lib.call(
-        "vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st), "byte")
+    w1_dkv = "dkv" in ATTN_W1 and not ATTN_BWD_FUSED
+    if w1_dkv:     # one pass: delta + the {-lse2, -delta} planes the w1 dK/dV kernel streams
+        stats = torch.empty(B, H, 2, S, dtype=torch.float32, device=q.device)
+        _timed("attn_delta_kernel", 4.0 * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_attn_bwd_prep_w1", o, do, lse, _bhs_strides(o), _bhs_strides(do), delta, stats, B, H, S, Dh, st), "byte")
+    else:
+        _timed("attn_delta_kernel", 4.0 * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st), "byte")
     if ATTN_BWD_FUSED:
         dq32 = torch.zeros(B, H, S, Dh, dtype=torch.float32, device=q.device)
         _timed("attn_bwd_fused_kernel", 8.0 * S * S * Dh * B * H, lambda: _lib.call(
@@ -677,7 +683,12 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
     ws_bytes = _lib.query("vgpa_attn_bwd_split_workspace_bytes", B, H, S) if split_mode != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
     wsp = ws if ws_bytes else None
-    _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
+    if w1_dkv:
+        _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
+            "vgpa_attn_bwd_dkv_w1", q, k, v, do, stats, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+            _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
+    else:
+      _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
         "vgpa_attn_bwd_dkv_ws", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
         _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
     _timed("attn_bwd_dq_kernel", 2.0 * S * S * Dh * B * H, lambda: _lib.call(
