@@ -467,6 +467,153 @@ class DkvLoop:
         return em.text() + "\n"
 
 
+# --------------------------------------------------------------------------------------------------------------- forward loop
+class FwdLoop:
+    """forward:  a wave owns two 32-row q-blocks j (Q fragments and O^T accumulators in AGPRs) and streams 64-key K|V tiles; per
+       32-key half-tile g:
+         A(g): S[g&1][j] = -M[q] + K_g Q_j^T                     8 MFMAs; -M[q] is the srcC of the first k-step (loop-invariant tuple)
+         B(g): P = exp2(S), l[j] += rowsum(P), PK[g&1][j] = bf16(P)   80 VALU (4 partial sums per q-block keep the add chains short)
+         C(g): O^T[j] += V_g^T P                                  8 MFMAs on transpose-read V fragments
+       half-step(g) issues C(g-1) | A(g+1) | B(g).  M[q] = |q| max_k |k| bounds every score of the row from above (the caller
+       computes it), so P <= 1 and the loop carries no running maximum, no rescale and no branch.  Keys past the end must not
+       count in l: while fewer than 64 keys remain (the ragged last tile and the drain step) a small block in front of each
+       half-step rewrites the srcC tuples to -inf for the missing keys -- otherwise the loop is uniform; S starts as -inf (P = 0).
+
+       register map   a[0:63] O[j][db]   a[64:95] qf[j][ks]   a[96:127] fragment ring (8 x 4)
+                      v[0:63] S[p][j]   v[64:95] PK[p][j][cc]   v[96:127] srcC tuples (j = 0, 1)   v[128:135] l[j][0..3]   v136 v137 -M[q]
+                      v[144:151] lane LDS offsets   v[152:155] LDS-DMA source offsets (K0 K1 V0 V1)   v156 4 * (lane >> 5)   v157 -inf"""
+
+    LA = 144
+    VOFF = 152
+    FR = 96
+    NFR = 8
+    LEAD = KNOB.get("lead", 6)
+
+    def S(self, p, j):
+        return p * 32 + j * 16
+
+    def PK(self, p, j, cc):
+        return 64 + p * 16 + j * 8 + cc * 4
+
+    def frag_reg(self, f):
+        return self.FR + 4 * (f % self.NFR)
+
+    def issue_frag(self, em, f, slotA, kbA, slotC, kbC, tag=None):
+        """f 0..3: transposed V fragments (cc, db) = (f >> 1, f & 1) of the PREVIOUS half; 4..7: K rows ks"""
+        tag = f if tag is None else tag
+        r = self.frag_reg(f)
+        if f < 4:
+            cc, db = f >> 1, f & 1
+            off = slotC * 16384 + 8192 + kbC * 4096 + cc * 2048
+            em.ds(f"ds_read_b64_tr_b16 {ar(r, 2)}, v{self.LA + 4 + 2 * db} offset:{off}", tag)
+            em.ds(f"ds_read_b64_tr_b16 {ar(r + 2, 2)}, v{self.LA + 5 + 2 * db} offset:{off}", tag)
+        else:
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{self.LA + f - 4} offset:{slotA * 16384 + kbA * 4096}", tag)
+
+    def mfmas(self, pa, pc):
+        out = []
+        for i in range(16):
+            j = i & 1
+            if i < 8:
+                c = i >> 1
+                cc, db = c >> 1, c & 1
+                d = ar(32 * j + 16 * db, 16)
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(c), 4)}, {vr(self.PK(pc, j, cc), 4)}, {d}", c))
+            else:
+                ks = (i - 8) >> 1
+                d = vr(self.S(pa, j), 16)
+                c = vr(96 + 16 * j, 16) if ks == 0 else d
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(4 + ks), 4)}, {ar(64 + 16 * j + 4 * ks, 4)}, {c}", 4 + ks))
+        return out
+
+    def valu_ops(self, pb):
+        if "novalu" in ABLATE:
+            return []
+
+        def unit(u):
+            j, p = u >> 3, u & 7
+            s0 = self.S(pb, j) + 2 * p
+            w = self.PK(pb, j, p >> 2) + (p & 3)
+            l0, l1 = 128 + 4 * j + ((2 * p) & 3), 128 + 4 * j + ((2 * p + 1) & 3)
+            return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                    [f"v_add_f32 v{l0}, v{l0}, v{s0}", f"v_add_f32 v{l1}, v{l1}, v{s0 + 1}"],
+                    f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
+        ops = list(unit(0)[0])
+        for t in range(16):
+            x = unit(t + 1)[0] if t + 1 < 16 else [None, None]
+            m = unit(t)[1]
+            ops += [o for o in (m[0], x[0], m[1], x[1], unit(t)[2]) if o is not None]
+        return ops
+
+    def mask_block(self, em, kb, krem, tmp, label):
+        """srcC tuples for a half-tile with fewer than 32 valid keys left: row r of this lane is key 32 kb + rowconst(r) + 4 hi"""
+        em.raw(f"s_cmp_ge_i32 {krem}, 64")
+        em.raw(f"s_cbranch_scc1 {label}")
+        for r in range(16):
+            rowc = (r & 3) + 8 * (r >> 2) + 32 * kb
+            em.raw(f"s_sub_i32 {tmp}, {krem}, {rowc}")
+            em.raw(f"v_cmp_lt_i32 vcc, v156, {tmp}")
+            for j in range(2):
+                em.raw(f"v_cndmask_b32 v{96 + 16 * j + r}, v157, v{136 + j}, vcc")
+        em.raw(f"{label}:")
+
+    def half_step(self, em, slotA, kbA, slotC, kbC, pa, nxt, fill_first=()):
+        need = {f: 2 * f for f in range(8)}
+        post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
+        em.retag({("n", f): f for f in range(4)})
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+                 pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT, KREM, TMP = "%0", "%1", "%2", "%3"
+        RK, RV, KSTEP, VSTEP, WBASE, NITER, KREM0 = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]", "%[krem]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        em.raw(f"s_mov_b32 {KREM}, {KREM0}")
+        for i in range(64):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        em.raw("v_mov_b32 v157, 0xff800000")                      # -inf
+        for r in range(32, 64):                                   # S[1] = -inf: the pipeline's first B stage adds nothing
+            em.raw(f"v_mov_b32 v{r}, v157")
+        for r in list(range(64, 80)) + list(range(128, 136)):    # PK[0], l
+            em.raw(f"v_mov_b32 v{r}, 0")
+        for j in range(2):                                        # srcC tuples = -M[q]
+            for r in range(16):
+                em.raw(f"v_mov_b32 v{96 + 16 * j + r}, v{136 + j}")
+        for f in range(4):
+            self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        em.raw("L_w1fwd_loop_%=:")
+        for ph in range(4):
+            em.raw("s_waitcnt vmcnt(4)")
+            if "nosync" not in ABLATE:
+                em.raw("s_barrier")
+            dst = ((ph + 2) & 3) * 16384
+            fill = []
+            for k, (rs, extra) in enumerate([(RK, 0), (RK, 1024), (RV, 8192), (RV, 9216)]):
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + extra}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {rs}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {KSTEP if k < 2 else VSTEP}, v{self.VOFF + k}"])
+            sp = (ph - 1) & 3
+            self.mask_block(em, 0, KREM, TMP, f"L_w1fwd_m{2 * ph}_%=")
+            self.half_step(em, ph, 0, sp, 0, 0, nxt=(sp, 1), fill_first=fill)
+            self.mask_block(em, 1, KREM, TMP, f"L_w1fwd_m{2 * ph + 1}_%=")
+            self.half_step(em, ph, 1, sp, 1, 1, nxt=(ph, 0))
+            em.raw(f"s_sub_i32 {KREM}, {KREM}, 64")
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if ph < 3:
+                em.raw("s_cbranch_scc1 L_w1fwd_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1fwd_loop_%=")
+        em.raw("L_w1fwd_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 def clobbers(ranges, aranges=()):
     regs = []
     for lo, hi in ranges:
@@ -480,7 +627,9 @@ def clobbers(ranges, aranges=()):
 TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_dq_clobbers.inc": lambda: clobbers([(0, 159)], [(128, 151)]),
            "w1_dkv_loop.inc": lambda: DkvLoop().generate(),
-           "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)])}
+           "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)]),
+           "w1_fwd_loop.inc": lambda: FwdLoop().generate(),
+           "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 127)])}
 
 
 def main():

@@ -416,10 +416,12 @@ template <int QB, int NW, bool SPLIT>
 __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : FWD_WPS) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
-                                                                 int S, int H, int n_qt, int task0, int nsplit, float* __restrict__ part) {
+                                                                 int S, int H, int n_qt, int task0, int nsplit, float* __restrict__ part,
+                                                                 const int* __restrict__ only_flagged = nullptr) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[5 * TILE_ELEMS];  // K ring [3], V ring [2]
     __shared__ int redo_flag;
     const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
+    if (only_flagged && only_flagged[vid] == 0) return;   // redo pass behind the w1 forward: only the strips it flagged
     const int chunk = SPLIT ? (int)blockIdx.x % nsplit : 0;
     const int bh = vid / n_qt, qt = vid % n_qt;
     const int b = bh / H, h = bh % H;
@@ -1559,6 +1561,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
 #define FWD_QB 2   // query blocks (of 32 rows) per wave in the forward kernel
 #endif
 #define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
+
+// Redo pass behind the w1 forward (attention_w1.hip): the online-softmax kernel over every 256-row strip whose flag is set.
+int32_t vgpa_internal_attn_fwd_redo(const void* q, const void* k, const void* v, void* o, float* lse2, TStride sq, TStride sk, TStride sv, TStride so,
+                                    int S, int H, int n_qt, int64_t tasks, const int* flags, hipStream_t stream) {
+    VGPA_LAUNCH((attn_fwd_pipe_kernel<2, 4, false>), dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                (bf16_t*)o, lse2, sq, sk, sv, so, S, H, n_qt, 0, 1, (float*)nullptr, flags);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
 
 extern "C" {
 

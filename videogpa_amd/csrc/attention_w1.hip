@@ -155,6 +155,192 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 }
 
 // =====================================================================================================
+// Forward:  O = softmax(scale * Q K^T) V ;  lse2 = log2 sum_k exp2(scale*log2e * q.k)        (q arrives pre-scaled by scale*log2e)
+// The main loop is tools/gen_w1_asm.py::FwdLoop (w1_fwd_loop.inc).  Scores are shifted by M[q] = |q| * max_k |k| (>= every score of
+// the row), so the loop needs no running maximum.  A row whose true maximum lies more than ~100 (log2) below that bound would
+// underflow: such strips are flagged (flags[task] = 1) and redone by the online-softmax kernel of attention.hip
+// (vgpa_internal_attn_fwd_redo), so the result never depends on the bound being tight.
+// =====================================================================================================
+#define W1_FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64] (un-normalised), M[256], l[256] -- layout of attention.hip's split forward
+#define W1_L_MIN 7.8886e-31f                  // 2^-100: below this the row's sum is too close to underflow -> redo
+
+// max_k |k| per (batch, head): kmax2[bh] = max over keys of sum_d k^2 (fp32 bits compared as integers: non-negative floats)
+__global__ __launch_bounds__(256) void w1_kmax_kernel(const bf16_t* __restrict__ K, TStride sk, int S, int H, unsigned* __restrict__ kmax2) {
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)S * 8; i += (int64_t)gridDim.x * 256) {   // 8 lanes per row
+        const int row = (int)(i >> 3), c8 = (int)(i & 7);
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(Kb + ((size_t)row * sk.s + c8 * 8)), f);
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += f[j] * f[j];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax(kmax2 + bh, __float_as_uint(mx));
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               bf16_t* __restrict__ O, float* __restrict__ LSE2, const unsigned* __restrict__ KMAX2,
+                                                               int* __restrict__ flags, TStride sq, TStride sk, TStride sv, TStride so, int S, int H,
+                                                               int n_qt, int task0, int nsplit, float* __restrict__ part) {
+    constexpr int QB = 2;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[W1_RING_BYTES];   // slot = [K tile | V tile]
+    const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
+    const int chunk = SPLIT ? (int)blockIdx.x % nsplit : 0;
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int q0 = (qt * 4 + wave) * (32 * QB);
+
+    bf16x8_t qf[QB][4];
+    float nm[QB];   // -M[q]
+    const float kmax = sqrtf(__uint_as_float(KMAX2[bh]));
+#pragma unroll
+    for (int j = 0; j < QB; ++j) load_row_frags(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0 + 32 * j, S, lane, qf[j]);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        frags_arrived(qf[j]);
+        float a = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float f[8];
+            frag_to_f32(qf[j][ks], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += f[i] * f[i];
+        }
+        a += other_half(a);                              // the row's other 32 columns live in lane ^ 32
+        nm[j] = -(sqrtf(a) * kmax * 1.0009765625f);      // a hair above |q| |k|max: rounding of the bound itself can never let a score exceed it
+    }
+
+    const int nt_all = (S + TILE - 1) / TILE;
+    const int tb = SPLIT ? nt_all * chunk / nsplit : 0;              // this workgroup's key tiles: [tb, nt)
+    const int nt = SPLIT ? nt_all * (chunk + 1) / nsplit : nt_all;
+
+    {   // the pipeline's first transposed reads hit the V tile of the slot "before" tile tb (ring slot 3): make it finite
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4_t*>(lds + 3 * W1_SLOT_BYTES + W1_TILE_BYTES + threadIdx.x * 16) = z;
+        *reinterpret_cast<u32x4_t*>(lds + 3 * W1_SLOT_BYTES + W1_TILE_BYTES + 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
+    const W1Rsrc krs = w1_rsrc(Kb, ((uint32_t)(S - 1) * sk.s + (uint32_t)HD) * 2u);
+    const W1Rsrc vrs = w1_rsrc(Vb, ((uint32_t)(S - 1) * sv.s + (uint32_t)HD) * 2u);
+    uint32_t kvo[2], vvo[2];
+    w1_dma_offsets<2>(wave, lane, sk.s, kvo);
+    w1_dma_offsets<2>(wave, lane, sv.s, vvo);
+    const uint32_t kstep = __builtin_amdgcn_readfirstlane(64u * sk.s * 2u), vstep = __builtin_amdgcn_readfirstlane(64u * sv.s * 2u);
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds + (uint32_t)wave * 2048u);
+    u32x4_t voff = {kvo[0] + (uint32_t)tb * kstep, kvo[1] + (uint32_t)tb * kstep, vvo[0] + (uint32_t)tb * vstep, vvo[1] + (uint32_t)tb * vstep};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // tiles tb, tb + 1 -> ring slots 0, 1
+        const uint32_t dst = wbase + (uint32_t)i * W1_SLOT_BYTES;
+        w1_dma(dst, krs, voff[0], 0u);
+        w1_dma(dst + 1024u, krs, voff[1], 0u);
+        w1_dma(dst + W1_TILE_BYTES, vrs, voff[2], 0u);
+        w1_dma(dst + W1_TILE_BYTES + 1024u, vrs, voff[3], 0u);
+        voff[0] += kstep; voff[1] += kstep; voff[2] += vstep; voff[3] += vstep;
+    }
+
+    const W1Lane la = w1_lane_offsets(lane);
+    const u32x8_t la8 = {la.row[0], la.row[1], la.row[2], la.row[3], la.tr[0][0], la.tr[0][1], la.tr[1][0], la.tr[1][1]};
+    const u32x16_t qf0 = pack4(qf[0][0], qf[0][1], qf[0][2], qf[0][3]), qf1 = pack4(qf[1][0], qf[1][1], qf[1][2], qf[1][3]);
+    const uint32_t niter = (uint32_t)(nt - tb + 1);                       // one extra tile step drains the pipeline
+    const int kend = nt * TILE < S ? nt * TILE : S;
+    const uint32_t krem = (uint32_t)(kend - tb * TILE);                   // valid keys from tile tb on (of this chunk)
+    const uint32_t hi4 = 4u * (uint32_t)hi;
+    f32x16_t o[QB][2];
+    u32x8_t lv;   // l[j][0..3]
+    uint32_t t0, t1, t2, t3;
+    asm volatile(
+#include "w1_fwd_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "={a[0:15]}"(o[0][0]), "={a[16:31]}"(o[0][1]), "={a[32:47]}"(o[1][0]), "={a[48:63]}"(o[1][1]),
+          "={v[128:135]}"(lv), "+{v[152:155]}"(voff)
+        : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [krem] "s"(krem),
+          "{a[64:79]}"(qf0), "{a[80:95]}"(qf1), "{v136}"(nm[0]), "{v137}"(nm[1]), "{v[144:151]}"(la8), "{v156}"(hi4)
+        : "memory", "scc", "vcc",
+#include "w1_fwd_clobbers.inc"
+    );
+#pragma unroll
+    for (int j = 0; j < QB; ++j) { asm volatile("" : "+v"(o[j][0])); asm volatile("" : "+v"(o[j][1])); }
+
+    float l[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const float a = (__uint_as_float(lv[4 * j]) + __uint_as_float(lv[4 * j + 1])) + (__uint_as_float(lv[4 * j + 2]) + __uint_as_float(lv[4 * j + 3]));
+        l[j] = a + other_half(a);
+    }
+    if (SPLIT) {   // partial result of this key range: un-normalised O (scaled by 2^-M), M, l
+        float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * W1_FWD_PART_FLOATS;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const int r = wave * (32 * QB) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t w = {o[j][db][4 * g], o[j][db][4 * g + 1], o[j][db][4 * g + 2], o[j][db][4 * g + 3]};
+                    *reinterpret_cast<f32x4_t*>(pb + r * HD + db * 32 + 8 * g + 4 * hi) = w;
+                }
+            if (hi == 0) { pb[256 * HD + r] = -nm[j]; pb[256 * HD + 256 + r] = l[j]; }
+        }
+        return;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < S) {
+            bad = bad || !(l[j] >= W1_L_MIN && l[j] < INFINITY);
+            const float inv = 1.f / l[j];
+            bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t w;
+                    w[0] = pack_bf16x2(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv);
+                    w[1] = pack_bf16x2(o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+                }
+            if (hi == 0) LSE2[(int64_t)bh * S + q] = -nm[j] + __builtin_amdgcn_logf(l[j]);  // v_log_f32 is log2
+        }
+    }
+    if (__any(bad) && lane == 0) flags[vid] = 1;
+}
+
+// combine the key-range chunks of the split forward tasks (all chunks share M): one wave per query row, lane = d
+__global__ __launch_bounds__(256) void w1_fwd_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_qt, bf16_t* __restrict__ O, TStride so,
+                                                             float* __restrict__ LSE2, int* __restrict__ flags, int S, int H) {
+    const int lane = threadIdx.x & 63, r = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6), tl = blockIdx.x >> 6;
+    const int vid = task0 + tl, bh = vid / n_qt, qt = vid % n_qt;
+    const int q = qt * 256 + r;
+    if (q >= S) return;
+    const float* pb = part + (size_t)tl * nsplit * W1_FWD_PART_FLOATS;
+    float acc = 0.f, L = 0.f;
+    for (int c = 0; c < nsplit; ++c) {
+        const float* pc = pb + (size_t)c * W1_FWD_PART_FLOATS;
+        acc += pc[r * HD + lane];
+        L += pc[256 * HD + 256 + r];
+    }
+    const int b = bh / H, h = bh % H;
+    O[(size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + lane] = f32_to_bf16(acc / L);
+    if (lane == 0) {
+        LSE2[(int64_t)bh * S + q] = pb[256 * HD + r] + __builtin_amdgcn_logf(L);
+        if (!(L >= W1_L_MIN && L < INFINITY)) flags[vid] = 1;
+    }
+}
+
+// =====================================================================================================
 // Backward, dK / dV:  dV = P^T dO,  dK = scale * dS^T Q      (workgroup = 256 keys = 4 waves x 2 key blocks; streams Q | dO tiles)
 // The main loop is tools/gen_w1_asm.py::DkvLoop (w1_dkv_loop.inc).  `stats` = fp32 [B, H, 2, S]: plane 0 = -lse2, plane 1 = -delta
 // (w1_bwd_prep_kernel); the 64 rows' statistics of a tile travel next to it by LDS-DMA and enter the score chains as srcC.
@@ -452,6 +638,62 @@ int32_t vgpa_attn_bwd_dkv_w1(const void* q, const void* k, const void* v, const 
         VGPA_CHECK_LAUNCH();
     }
     return VGPA_OK;
+}
+
+
+// Forward on the w1 structure: arguments and results as vgpa_attn_fwd_ws; the workspace (>= vgpa_attn_fwd_w1_workspace_bytes) is REQUIRED:
+// it holds max_k |k|^2 per (batch, head), one redo flag per 256-row strip and the tail-split partials.
+size_t vgpa_attn_fwd_w1_workspace_bytes(int64_t B, int64_t H, int64_t S) {
+    const int64_t n_qt = (S + 255) / 256, tasks = n_qt * B * H;
+    int64_t parts = w1_slots();
+    if (tasks * W1_MAX_SPLIT < parts) parts = tasks * W1_MAX_SPLIT;
+    const size_t head = (((size_t)(B * H) + (size_t)tasks) * 4 + 255) / 256 * 256;
+    return head + (size_t)parts * W1_FWD_PART_FLOATS * sizeof(float);
+}
+int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
+                         const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
+                         int32_t split_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    (void)scale;
+    if (!q || !k || !v || !o || !lse2 || !workspace || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
+#define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
+    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides) || !al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(workspace))
+        return VGPA_ERR_INVALID;
+#undef SOK
+    const int n_qt = (int)((S + 255) / 256);
+    const int64_t tasks = (int64_t)n_qt * B * H;
+    if (tasks > 0x7fffffff || B * H > 65535) return VGPA_ERR_INVALID;
+    const size_t head = (((size_t)(B * H) + (size_t)tasks) * 4 + 255) / 256 * 256;
+    if (ws_bytes < head) return VGPA_ERR_WORKSPACE;
+    unsigned* kmax2 = (unsigned*)workspace;
+    int* flags = (int*)workspace + B * H;
+    float* part = (float*)((char*)workspace + head);
+    if (hipMemsetAsync(workspace, 0, head, stream) != hipSuccess) return VGPA_ERR_LAUNCH;
+    VGPA_LAUNCH(w1_kmax_kernel, dim3(16, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)k, mk(k_strides), (int)S, (int)H, kmax2);
+    VGPA_CHECK_LAUNCH();
+    int64_t n_main = tasks;
+    int nsplit = 1;
+    split_plan(tasks, (int)((S + TILE - 1) / TILE), split_mode, W1_MAX_SPLIT, &n_main, &nsplit, w1_slots());
+    const int64_t n_tail = tasks - n_main;
+    if (n_tail > 0 && ws_bytes < head + (size_t)n_tail * nsplit * W1_FWD_PART_FLOATS * sizeof(float)) {
+        if (split_mode >= 2) return VGPA_ERR_WORKSPACE;
+        n_main = tasks;
+    }
+    if (n_main > 0) {
+        VGPA_LAUNCH((attn_fwd_w1_kernel<false>), dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (bf16_t*)o, lse2, (const unsigned*)kmax2, flags, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, 0, 1,
+                    (float*)nullptr);
+        VGPA_CHECK_LAUNCH();
+    }
+    if (n_main < tasks) {
+        VGPA_LAUNCH((attn_fwd_w1_kernel<true>), dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                    (const bf16_t*)v, (bf16_t*)o, lse2, (const unsigned*)kmax2, flags, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S,
+                    (int)H, n_qt, (int)n_main, nsplit, part);
+        VGPA_CHECK_LAUNCH();
+        VGPA_LAUNCH(w1_fwd_merge_kernel, dim3((unsigned)(n_tail * 64)), dim3(256), 0, stream, (const float*)part, nsplit, (int)n_main, n_qt, (bf16_t*)o,
+                    mk(o_strides), lse2, flags, (int)S, (int)H);
+        VGPA_CHECK_LAUNCH();
+    }
+    return vgpa_internal_attn_fwd_redo(q, k, v, o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, tasks, flags, stream);
 }
 
 }  // extern "C"

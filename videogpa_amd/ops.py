@@ -646,6 +646,13 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
     lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     ov = o.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
     split_mode = ATTN_SPLIT_MODE if split_mode is None else split_mode
+    if "fwd" in ATTN_W1:
+        ws_bytes = _lib.query("vgpa_attn_fwd_w1_workspace_bytes", B, H, S)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
+            "vgpa_attn_fwd_w1", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
+            float(scale), int(split_mode), ws, ws_bytes, _stream()))
+        return o, lse
     ws_bytes = _lib.query("vgpa_attn_fwd_workspace_bytes", B, H, S) if split_mode != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
     _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
