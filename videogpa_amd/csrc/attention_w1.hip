@@ -259,12 +259,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
     const uint32_t krem = (uint32_t)(kend - tb * TILE);                   // valid keys from tile tb on (of this chunk)
     const uint32_t hi4 = 4u * (uint32_t)hi;
     f32x16_t o[QB][2];
-    u32x8_t lv;   // l[j][0..3]
+    float lv0, lv1;   // row sums of the two q-blocks (every lane holds its column's complete sum)
     uint32_t t0, t1, t2, t3;
+    uint64_t c0, c1;   // s_memtime at the loop's start and end (read by tools/w1_clock.py through -DW1_CLOCKS builds)
     asm volatile(
 #include "w1_fwd_loop.inc"
-        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "={a[0:15]}"(o[0][0]), "={a[16:31]}"(o[0][1]), "={a[32:47]}"(o[1][0]), "={a[48:63]}"(o[1][1]),
-          "={v[128:135]}"(lv), "+{v[152:155]}"(voff)
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), [c0] "=&s"(c0), [c1] "=&s"(c1), "={a[0:15]}"(o[0][0]), "={a[16:31]}"(o[0][1]), "={a[32:47]}"(o[1][0]), "={a[48:63]}"(o[1][1]),
+          "={v128}"(lv0), "={v129}"(lv1), "+{v[152:155]}"(voff)
         : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [krem] "s"(krem),
           "{a[64:79]}"(qf0), "{a[80:95]}"(qf1), "{v136}"(nm[0]), "{v137}"(nm[1]), "{v[144:151]}"(la8), "{v156}"(hi4)
         : "memory", "scc", "vcc",
@@ -273,12 +274,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
 #pragma unroll
     for (int j = 0; j < QB; ++j) { asm volatile("" : "+v"(o[j][0])); asm volatile("" : "+v"(o[j][1])); }
 
-    float l[QB];
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        const float a = (__uint_as_float(lv[4 * j]) + __uint_as_float(lv[4 * j + 1])) + (__uint_as_float(lv[4 * j + 2]) + __uint_as_float(lv[4 * j + 3]));
-        l[j] = a + other_half(a);
-    }
+    const float l[QB] = {lv0, lv1};
     if (SPLIT) {   // partial result of this key range: un-normalised O (scaled by 2^-M), M, l
         float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * W1_FWD_PART_FLOATS;
 #pragma unroll
@@ -315,7 +311,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
             if (hi == 0) LSE2[(int64_t)bh * S + q] = -nm[j] + __builtin_amdgcn_logf(l[j]);  // v_log_f32 is log2
         }
     }
+#ifdef W1_CLOCKS   // diagnostic build: the redo flags carry the loop's cycle count instead (every strip is then redone -- results stay right)
+    if (threadIdx.x == 0) flags[vid] = (int)(c1 - c0);
+    (void)bad;
+#else
     if (__any(bad) && lane == 0) flags[vid] = 1;
+#endif
 }
 
 // combine the key-range chunks of the split forward tasks (all chunks share M): one wave per query row, lane = d

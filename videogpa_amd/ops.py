@@ -620,8 +620,10 @@ LOG2E = 1.4426950408889634
 ATTN_BWD_FUSED = _os.environ.get("VGPA_ATTN_BWD", "split") == "fused"
 # tail-round treatment of the attention launches (vgpa_attn_*_ws split_mode): -1 automatic (default), 0 off
 ATTN_SPLIT_MODE = int(_os.environ.get("VGPA_ATTN_SPLIT", "-1"))
-# kernels taken from the "w1" family (csrc/attention_w1.hip: one wave per SIMD, LDS-DMA, hand-scheduled loops): any of dq, dkv, fwd
-ATTN_W1 = set(x for x in _os.environ.get("VGPA_ATTN_W1", "").split(",") if x)
+# Attention kernels come from the "w1" family (csrc/attention_w1.hip: one wave per SIMD, LDS-DMA rings, generated hand-scheduled
+# main loops).  VGPA_ATTN_W1 = comma list out of {fwd, dq, dkv} selects which (default all three; "none" = the 2-waves-per-SIMD
+# kernels of attention.hip, which stay in the library as the redo path of the forward and for A/B runs).
+ATTN_W1 = set(x for x in _os.environ.get("VGPA_ATTN_W1", "fwd,dq,dkv").split(",") if x and x != "none")
 
 
 def prescale_q(q, scale=None):
@@ -695,9 +697,9 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
             "vgpa_attn_bwd_dkv_w1", q, k, v, do, stats, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
             _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
     else:
-      _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
-        "vgpa_attn_bwd_dkv_ws", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
-        _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
+        _timed("attn_bwd_dkv_kernel", 6.0 * S * S * Dh * B * H, lambda: _lib.call(
+            "vgpa_attn_bwd_dkv_ws", q, k, v, do, lse, delta, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
+            _bhs_strides(dk), _bhs_strides(dv), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
     _timed("attn_bwd_dq_kernel", 2.0 * S * S * Dh * B * H, lambda: _lib.call(
         "vgpa_attn_bwd_dq_w1" if "dq" in ATTN_W1 else "vgpa_attn_bwd_dq_ws", q, k, v, do, lse, delta, dq, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(do),
         _bhs_strides(dq), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
