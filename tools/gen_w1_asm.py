@@ -485,17 +485,18 @@ class FwdLoop:
     """forward:  a wave owns two 32-row q-blocks j (Q fragments and O^T accumulators in AGPRs) and streams 64-key K|V tiles; per
        32-key half-tile g:
          A(g): S[g&1][j] = -M[q] + K_g Q_j^T                     8 MFMAs; -M[q] is the srcC of the first k-step (loop-invariant tuple)
-         B(g): P = exp2(S), PK[g&1][j] = bf16(P)                  48 VALU
-         C(g): O^T[j] += V_g^T P   and   L[j] += 1^T P            8 + 4 MFMAs: the row sums ride the matrix pipe (an all-ones A
-               operand), which has room, instead of 32 VALU adds per half-step on the issue-bound VALU side; every row of the L
-               tile holds the sum, of the SAME bf16-rounded P the numerator uses
+         B(g): P = exp2(S), l[j] += rowsum(P), PK[g&1][j] = bf16(P)   80 VALU (4 partial sums per q-block keep the add chains short).
+               (Measured alternative: the row sums as 4 extra MFMAs against an all-ones operand instead of the 32 adds -- same
+               time, the kernel is power-limited, not issue-limited -- but l then sums the bf16-ROUNDED P and lse2 loses three
+               digits (1e-3 instead of 1e-6); the fp32 sums stay.)
+         C(g): O^T[j] += V_g^T P                                  8 MFMAs on transpose-read V fragments
        half-step(g) issues C(g-1) | A(g+1) | B(g).  M[q] = |q| max_k |k| bounds every score of the row from above (the caller
        computes it), so P <= 1 and the loop carries no running maximum, no rescale and no branch.  Keys past the end must not
-       count in L: while fewer than 64 keys remain (the ragged last tile and the drain step) a small block in front of each
+       count in l: while fewer than 64 keys remain (the ragged last tile and the drain step) a small block in front of each
        half-step rewrites the srcC tuples to -inf for the missing keys -- otherwise the loop is uniform; S starts as -inf (P = 0).
 
-       register map   a[0:63] O[j][db]   a[64:95] qf[j][ks]   a[96:127] fragment ring (8 x 4)   a[128:159] L[j]   a[160:163] ones
-                      v[0:63] S[p][j]   v[64:95] PK[p][j][cc]   v[96:127] srcC tuples (j = 0, 1)   v136 v137 -M[q]
+       register map   a[0:63] O[j][db]   a[64:95] qf[j][ks]   a[96:127] fragment ring (8 x 4)
+                      v[0:63] S[p][j]   v[64:95] PK[p][j][cc]   v[96:127] srcC tuples (j = 0, 1)   v[128:135] l[j][0..3]   v136 v137 -M[q]
                       v[144:151] lane LDS offsets   v[152:155] LDS-DMA source offsets (K0 K1 V0 V1)   v156 4 * (lane >> 5)   v157 -inf"""
 
     LA = 144
@@ -526,18 +527,16 @@ class FwdLoop:
             em.ds(f"ds_read_b128 {ar(r, 4)}, v{self.LA + f - 4} offset:{slotA * 16384 + kbA * 4096}", tag)
 
     def mfmas(self, pa, pc):
-        """C: for each key sub-block cc: O[j][db0], O[j][db1] and L[j] (6 MFMAs, every accumulator once); then the score chains"""
         out = []
-        for cc in range(2):
-            for db in range(2):
-                for j in range(2):
-                    d = ar(32 * j + 16 * db, 16)
-                    out.append((f"{MFMA} {d}, {ar(self.frag_reg(2 * cc + db), 4)}, {vr(self.PK(pc, j, cc), 4)}, {d}", 2 * cc + db))
-            for j in range(2):
-                d = ar(128 + 16 * j, 16)
-                out.append((f"{MFMA} {d}, {ar(160, 4)}, {vr(self.PK(pc, j, cc), 4)}, {d}", None))
-        for ks in range(4):
-            for j in range(2):
+        for i in range(16):
+            j = i & 1
+            if i < 8:
+                c = i >> 1
+                cc, db = c >> 1, c & 1
+                d = ar(32 * j + 16 * db, 16)
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(c), 4)}, {vr(self.PK(pc, j, cc), 4)}, {d}", c))
+            else:
+                ks = (i - 8) >> 1
                 d = vr(self.S(pa, j), 16)
                 c = vr(96 + 16 * j, 16) if ks == 0 else d
                 out.append((f"{MFMA} {d}, {ar(self.frag_reg(4 + ks), 4)}, {ar(64 + 16 * j + 4 * ks, 4)}, {c}", 4 + ks))
@@ -551,11 +550,15 @@ class FwdLoop:
             j, p = u >> 3, u & 7
             s0 = self.S(pb, j) + 2 * p
             w = self.PK(pb, j, p >> 2) + (p & 3)
-            return [f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"], f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}"
+            l0, l1 = 128 + 4 * j + ((2 * p) & 3), 128 + 4 * j + ((2 * p + 1) & 3)
+            return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                    [f"v_add_f32 v{l0}, v{l0}, v{s0}", f"v_add_f32 v{l1}, v{l1}, v{s0 + 1}"],
+                    f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
         ops = list(unit(0)[0])
         for t in range(16):
             x = unit(t + 1)[0] if t + 1 < 16 else [None, None]
-            ops += [o for o in (x[0], x[1], unit(t)[1]) if o is not None]
+            m = unit(t)[1]
+            ops += [o for o in (m[0], x[0], m[1], x[1], unit(t)[2]) if o is not None]
         return ops
 
     def mask_block(self, em, kb, krem, tmp, label):
@@ -571,14 +574,10 @@ class FwdLoop:
         em.raw(f"{label}:")
 
     def half_step(self, em, slotA, kbA, slotC, kbC, pa, nxt, fill_first=()):
-        ms = self.mfmas(pa, pa)
-        need = {}
-        for i, (_, f) in enumerate(ms):
-            if f is not None and f not in need:
-                need[f] = i
+        need = {f: 2 * f for f in range(8)}
         post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
         em.retag({("n", f): f for f in range(4)})
-        schedule(em, ms, lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
                  pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
 
     def generate(self):
@@ -588,15 +587,12 @@ class FwdLoop:
         em.raw(f"s_mov_b32 {SAVE_M0}, m0")
         em.raw(f"s_mov_b32 {CNT}, {NITER}")
         em.raw(f"s_mov_b32 {KREM}, {KREM0}")
-        for i in list(range(64)) + list(range(128, 160)):
+        for i in range(64):
             em.raw(f"v_accvgpr_write_b32 a{i}, 0")
-        em.raw("v_mov_b32 v157, 0x3f803f80")                      # bf16 (1, 1)
-        for i in range(160, 164):
-            em.raw(f"v_accvgpr_write_b32 a{i}, v157")
         em.raw("v_mov_b32 v157, 0xff800000")                      # -inf
         for r in range(32, 64):                                   # S[1] = -inf: the pipeline's first B stage adds nothing
             em.raw(f"v_mov_b32 v{r}, v157")
-        for r in range(64, 80):                                   # PK[0]
+        for r in list(range(64, 80)) + list(range(128, 136)):    # PK[0], l
             em.raw(f"v_mov_b32 v{r}, 0")
         for j in range(2):                                        # srcC tuples = -M[q]
             for r in range(16):
@@ -632,8 +628,6 @@ class FwdLoop:
         em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
         em.raw("s_nop 7")
         em.raw("s_nop 7")
-        em.raw("v_accvgpr_read_b32 v128, a128")                   # row sums (any row of the L tiles)
-        em.raw("v_accvgpr_read_b32 v129, a144")
         em.raw(f"s_mov_b32 m0, {SAVE_M0}")
         return em.text() + "\n"
 
@@ -653,7 +647,7 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_dkv_loop.inc": lambda: DkvLoop().generate(),
            "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),
-           "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 163)])}
+           "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 127)])}
 
 
 def main():

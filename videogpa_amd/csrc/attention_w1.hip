@@ -158,11 +158,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 // Forward:  O = softmax(scale * Q K^T) V ;  lse2 = log2 sum_k exp2(scale*log2e * q.k)        (q arrives pre-scaled by scale*log2e)
 // The main loop is tools/gen_w1_asm.py::FwdLoop (w1_fwd_loop.inc).  Scores are shifted by M[q] = |q| * max_k |k| (>= every score of
 // the row), so the loop needs no running maximum.  A row whose true maximum lies more than ~100 (log2) below that bound would
-// underflow: such strips are flagged (flags[task] = 1) and redone by the online-softmax kernel of attention.hip
+// underflow, and a bound above W1_M_MAX would cost precision (the fp32 accumulators start at -M): such strips are flagged
+// (flags[task] = 1) and redone by the online-softmax kernel of attention.hip
 // (vgpa_internal_attn_fwd_redo), so the result never depends on the bound being tight.
 // =====================================================================================================
 #define W1_FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64] (un-normalised), M[256], l[256] -- layout of attention.hip's split forward
 #define W1_L_MIN 7.8886e-31f                  // 2^-100: below this the row's sum is too close to underflow -> redo
+// With the shift at the row BOUND the largest weight of a row is exp2(s_max - M), not 1, so it carries a bf16 rounding error in the
+// numerator (2^-9 relative) that the fp32 denominator does not share; over a few dozen keys these errors average out, over one or
+// two they do not (S = 1: O off by up to 0.4 %).  Rows that short are not a performance case: below this length every strip goes to
+// the online-softmax kernel.
+#define W1_FWD_MIN_S 128
+#define W1_M_MAX 160.0f                       // a bound this large (log2 units) costs precision: the scores are accumulated on top of -M in fp32 -> redo
 
 // max_k |k| per (batch, head): kmax2[bh] = max over keys of sum_d k^2 (fp32 bits compared as integers: non-negative floats)
 __global__ __launch_bounds__(256) void w1_kmax_kernel(const bf16_t* __restrict__ K, TStride sk, int S, int H, unsigned* __restrict__ kmax2) {
@@ -259,13 +266,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
     const uint32_t krem = (uint32_t)(kend - tb * TILE);                   // valid keys from tile tb on (of this chunk)
     const uint32_t hi4 = 4u * (uint32_t)hi;
     f32x16_t o[QB][2];
-    float lv0, lv1;   // row sums of the two q-blocks (every lane holds its column's complete sum)
+    u32x8_t lv;   // l[j][0..3]: four partial row sums per q-block
     uint32_t t0, t1, t2, t3;
     uint64_t c0, c1;   // s_memtime at the loop's start and end (read by tools/w1_clock.py through -DW1_CLOCKS builds)
     asm volatile(
 #include "w1_fwd_loop.inc"
         : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), [c0] "=&s"(c0), [c1] "=&s"(c1), "={a[0:15]}"(o[0][0]), "={a[16:31]}"(o[0][1]), "={a[32:47]}"(o[1][0]), "={a[48:63]}"(o[1][1]),
-          "={v128}"(lv0), "={v129}"(lv1), "+{v[152:155]}"(voff)
+          "={v[128:135]}"(lv), "+{v[152:155]}"(voff)
         : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [krem] "s"(krem),
           "{a[64:79]}"(qf0), "{a[80:95]}"(qf1), "{v136}"(nm[0]), "{v137}"(nm[1]), "{v[144:151]}"(la8), "{v156}"(hi4)
         : "memory", "scc", "vcc",
@@ -274,7 +281,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
 #pragma unroll
     for (int j = 0; j < QB; ++j) { asm volatile("" : "+v"(o[j][0])); asm volatile("" : "+v"(o[j][1])); }
 
-    const float l[QB] = {lv0, lv1};
+    float l[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const float a = (__uint_as_float(lv[4 * j]) + __uint_as_float(lv[4 * j + 1])) + (__uint_as_float(lv[4 * j + 2]) + __uint_as_float(lv[4 * j + 3]));
+        l[j] = a + other_half(a);   // the other 16 key rows of every 32-key block live in lane ^ 32
+    }
     if (SPLIT) {   // partial result of this key range: un-normalised O (scaled by 2^-M), M, l
         float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * W1_FWD_PART_FLOATS;
 #pragma unroll
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
     for (int j = 0; j < QB; ++j) {
         const int q = q0 + 32 * j + (lane & 31);
         if (q < S) {
-            bad = bad || !(l[j] >= W1_L_MIN && l[j] < INFINITY);
+            bad = bad || !(l[j] >= W1_L_MIN && l[j] < INFINITY) || !(-nm[j] <= W1_M_MAX);
             const float inv = 1.f / l[j];
             bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
 #pragma unroll
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(256) void w1_fwd_merge_kernel(const float* __restri
     O[(size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + lane] = f32_to_bf16(acc / L);
     if (lane == 0) {
         LSE2[(int64_t)bh * S + q] = pb[256 * HD + r] + __builtin_amdgcn_logf(L);
-        if (!(L >= W1_L_MIN && L < INFINITY)) flags[vid] = 1;
+        if (!(L >= W1_L_MIN && L < INFINITY) || !(pb[256 * HD + r] <= W1_M_MAX)) flags[vid] = 1;
     }
 }
 
@@ -668,6 +680,11 @@ int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, f
     unsigned* kmax2 = (unsigned*)workspace;
     int* flags = (int*)workspace + B * H;
     float* part = (float*)((char*)workspace + head);
+    if (S < W1_FWD_MIN_S) {   // a handful of keys per row: the online-softmax kernel (its top weight is exactly 1; see W1_FWD_MIN_S)
+        if (hipMemsetAsync(workspace, 0xff, head, stream) != hipSuccess) return VGPA_ERR_LAUNCH;   // every strip flagged
+        return vgpa_internal_attn_fwd_redo(q, k, v, o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, tasks,
+                                           flags, stream);
+    }
     if (hipMemsetAsync(workspace, 0, head, stream) != hipSuccess) return VGPA_ERR_LAUNCH;
     VGPA_LAUNCH(w1_kmax_kernel, dim3(16, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)k, mk(k_strides), (int)S, (int)H, kmax2);
     VGPA_CHECK_LAUNCH();
