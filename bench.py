@@ -299,18 +299,44 @@ def main():
             kd = kernels[dom]
             # traffic: HBM bytes per launch from the PMC pass of the same command (profiles/, collected per the guide's
             # recipe: separate --pmc runs, FETCH_SIZE/WRITE_SIZE with the gfx950 corrections), when a summary is present
-            traffic = None
+            pmc_all = {}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 with open(pmc) as f:
-                    traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+                    pmc_all = json.load(f)
+            traffic = pmc_all.get(dom, {}).get("hbm_bytes_per_launch")
+
+            def roof(name):
+                k = kernels[name]
+                r = {"kernel": name, "bound": k["bound"], "achieved": k.get("achieved_tflops", k.get("achieved_gbs")),
+                     "peak": PEAK_BF16_DENSE_TFLOPS if k["bound"] == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if k["bound"] == "mfma" else "GB/s",
+                     "frac": k["frac"], "avg_launch_ms": k["avg_ms"], "share_of_step": k["total_ms_per_step"] / ms,
+                     "traffic": pmc_all.get(name, {}).get("hbm_bytes_per_launch")}
+                for key in ("mfma_busy", "clock_mhz"):        # from the round's PMC pass (tools/profile_round.sh), when present
+                    if key in pmc_all.get(name, {}):
+                        r[key] = pmc_all[name][key]
+                return r
             if kd["bound"] == "mfma":
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["achieved_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS,
                                    "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"],
                                    "note": "largest hand-written kernel of the step; the vendor GEMMs are listed under kernels"}
+                for key in ("mfma_busy", "clock_mhz"):
+                    if key in pmc_all.get(dom, {}):
+                        out["roofline"][key] = pmc_all[dom][key]
             else:
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_gbs"], "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"]}
+            # the weakest hand-written kernel that matters (>= 5 % of the step), so that `roofline` cannot hide it
+            big = [k for k in own if kernels[k]["total_ms_per_step"] >= 0.05 * ms]
+            if big:
+                out["roofline_worst"] = roof(min(big, key=lambda k: kernels[k]["frac"]))
+            if "attn_bwd_dkv_kernel" in kernels and "attn_bwd_dq_kernel" in kernels:
+                a, b2 = kernels["attn_bwd_dkv_kernel"], kernels["attn_bwd_dq_kernel"]
+                fl = a["algorithmic_flops_per_launch"] + b2["algorithmic_flops_per_launch"]       # 8 S^2 d B H: the whole attention backward
+                t_ms = a["avg_ms"] + b2["avg_ms"]
+                out["attention_bwd_pair"] = {"algorithmic_flops_per_launch": fl, "avg_ms": t_ms, "achieved_tflops": fl / t_ms / 1e9,
+                                             "frac": fl / t_ms / 1e9 / PEAK_BF16_DENSE_TFLOPS,
+                                             "note": "dK/dV + dQ launches together against the algorithmic 8 S^2 d FLOPs (their S / dP recomputes are overhead)"}
             out["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_step)
