@@ -197,7 +197,43 @@ def patch_embed(sd, cfg, text, video):
     return emb
 
 
-def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_rotary_emb=None, capture=None):
+class _RoundedSDPA(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v in the oracle's own precision EXCEPT for the two roundings every bf16 flash attention makes:
+    the weights P are rounded to bf16 where they multiply V (forward) and dO (dV), and dS = P o (dP - delta) is rounded to bf16 where
+    it multiplies K (dQ) and Q (dK); the softmax normaliser and P inside dS stay unrounded.  This is the "rounding-injected oracle"
+    of tests/test_gpu_cfg1.py: what is left between it and the HIP path is the kernels' arithmetic, not their arithmetic TYPE.
+    Heads are processed in chunks (the S x S matrix is recomputed in the backward, never stored)."""
+
+    CHUNK = 4
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        scale = q.shape[-1] ** -0.5
+        o = torch.empty_like(q)
+        for h0 in range(0, q.shape[1], _RoundedSDPA.CHUNK):
+            sl = slice(h0, h0 + _RoundedSDPA.CHUNK)
+            p = torch.softmax((q[:, sl] @ k[:, sl].transpose(-1, -2)) * scale, dim=-1)
+            o[:, sl] = p.bfloat16().to(p.dtype) @ v[:, sl]
+        ctx.save_for_backward(q, k, v, o)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o = ctx.saved_tensors
+        scale = q.shape[-1] ** -0.5
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        for h0 in range(0, q.shape[1], _RoundedSDPA.CHUNK):
+            sl = slice(h0, h0 + _RoundedSDPA.CHUNK)
+            p = torch.softmax((q[:, sl] @ k[:, sl].transpose(-1, -2)) * scale, dim=-1)
+            delta = (do[:, sl] * o[:, sl]).sum(-1, keepdim=True)
+            ds = (p * (do[:, sl] @ v[:, sl].transpose(-1, -2) - delta)).bfloat16().to(p.dtype)
+            dv[:, sl] = p.bfloat16().to(p.dtype).transpose(-1, -2) @ do[:, sl]
+            dq[:, sl] = (ds @ k[:, sl]) * scale
+            dk[:, sl] = (ds.transpose(-1, -2) @ q[:, sl]) * scale
+        return dq, dk, dv
+
+
+def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_rotary_emb=None, capture=None, round_p_ds=False):
     b = f"transformer_blocks.{i}."
     Lt = enc.shape[1]
     H, hd = cfg.num_attention_heads, cfg.attention_head_dim
@@ -223,7 +259,7 @@ def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_r
         cos, sin = image_rotary_emb
         q = torch.cat([q[:, :, :Lt], apply_rotary_emb(q[:, :, Lt:], cos, sin)], dim=2)
         k = torch.cat([k[:, :, :Lt], apply_rotary_emb(k[:, :, Lt:], cos, sin)], dim=2)
-    o = F.scaled_dot_product_attention(q, k, v)
+    o = _RoundedSDPA.apply(q, k, v) if round_p_ds else F.scaled_dot_product_attention(q, k, v)
     o = o.transpose(1, 2).reshape(B, -1, H * hd)
     if capture is not None:
         capture.update(q=q, k=k, v=v, attn=o)
@@ -241,7 +277,7 @@ def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_r
 
 
 def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, lora_scale=2.0,
-            image_rotary_emb=None):
+            image_rotary_emb=None, round_p_ds=False):
     """hidden_states [B,F,C,H,W], encoder_hidden_states [B,L,4096], timestep [B] -> sample [B,F,C_out,H,W]."""
     B, Fr, C, H, W = hidden_states.shape
     p = cfg.patch_size
@@ -255,7 +291,7 @@ def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, 
     Lt = encoder_hidden_states.shape[1]
     enc, hid = x[:, :Lt], x[:, Lt:]
     for i in range(cfg.num_layers):
-        hid, enc = block_forward(sd, cfg, i, hid, enc, emb, lora, lora_scale, image_rotary_emb)
+        hid, enc = block_forward(sd, cfg, i, hid, enc, emb, lora, lora_scale, image_rotary_emb, round_p_ds=round_p_ds)
 
     hid = layer_norm(torch.cat([enc, hid], dim=1), sd["norm_final.weight"], sd["norm_final.bias"], cfg.norm_eps)[:, Lt:]
     m = F.linear(F.silu(emb), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
@@ -271,7 +307,7 @@ def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, 
     return out
 
 
-def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta=1.0, lora_scale=2.0):
+def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta=1.0, lora_scale=2.0, round_p_ds=False):
     """One preference-pair step as train/CogVideoX-5B/03_train.py:116-157 does it.
 
     x_win/x_lose arrive as the dataset stores them, [B,C,F,H,W] (train/dataset.py:228-229), and are
@@ -282,11 +318,11 @@ def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta
     xl = x_lose.permute(0, 2, 1, 3, 4)
     xw_n = scheduler.add_noise(abar, xw, noise, t)
     xl_n = scheduler.add_noise(abar, xl, noise, t)
-    v_w = forward(sd, cfg, xw_n, prompt_emb, t, lora, lora_scale)
-    v_l = forward(sd, cfg, xl_n, prompt_emb, t, lora, lora_scale)
+    v_w = forward(sd, cfg, xw_n, prompt_emb, t, lora, lora_scale, round_p_ds=round_p_ds)
+    v_l = forward(sd, cfg, xl_n, prompt_emb, t, lora, lora_scale, round_p_ds=round_p_ds)
     with torch.no_grad():
-        v_wr = forward(sd, cfg, xw_n, prompt_emb, t, None)
-        v_lr = forward(sd, cfg, xl_n, prompt_emb, t, None)
+        v_wr = forward(sd, cfg, xw_n, prompt_emb, t, None, round_p_ds=round_p_ds)
+        v_lr = forward(sd, cfg, xl_n, prompt_emb, t, None, round_p_ds=round_p_ds)
     tw = scheduler.get_velocity(abar, xw, noise, t)
     tl = scheduler.get_velocity(abar, xl, noise, t)
     out = dpo.dpo_loss(v_w, v_l, v_wr, v_lr, tw, tl, beta=beta)

@@ -1,28 +1,31 @@
 """Full-width parity at BASELINE.json configs[0] geometry: D = 3072, 48 heads, 2 transformer blocks, 13f x 64 x 64 paired
 latents (S = 13 538 tokens), LoRA r = 8 (and r = 64: the rp = 64 / 192 kernels of the headline config).  The HIP
 pair-step (train/CogVideoX-5B/03_train.py:116-157 through CogVideoXDPOTrainer._shared_step, every kernel through the
-C-ABI) runs on the seeded inputs of tests/cfg1_common.py and is compared with the fp32 CPU-oracle results committed as
-tests/golden/cfg1_<variant>.pt (made by tests/golden/make_cfg1_golden.py in the build container).
+C-ABI) runs on the seeded inputs of tests/cfg1_common.py and is compared with the fp32 oracle: the committed CPU results
+tests/golden/cfg1_<variant>.pt (tests/golden/make_cfg1_golden.py) for the loss, the rewards and the predictions, and -- because the
+golden holds only 256 samples and the norm of each gradient -- the SAME oracle code run in fp32 in this process for the full gradient
+tensors (first checked against the golden's samples: cosine >= 0.99999, norm within 1e-4).
 
 Tolerances (the HIP path computes in bf16, the oracle in fp32 on the same bf16-rounded weights / inputs):
-  loss                  |d| <= 1e-3 (north_star) -- measured ~1e-6
+  loss                  |d| <= 1e-3 (north_star) -- measured ~3e-4
   rewards (= -mean err) |d| <= 2e-4 + 1 % relative; reward_margin (their difference, 1e-3 of the rewards) |d| <= 1e-3
   v_pred samples        |d| <= 3 % of the prediction range (bf16 activations through 2 blocks)
-  LoRA grads, per tensor: norm within 5 %, sampled entries within 5 % of the tensor's max |grad|, cosine >= 0.99 -- OR
-                        within 3 x the error of the bf16 FLOOR of the tensor's family (to_q / to_k x A / B of one block; the other
-                        adapters of a block), whichever is larger.  Measured: every tensor but the last block's q / k family
-                        passes the fixed 5 % / 0.99 bounds with room (cos >= 0.995), where plain torch bf16 does not (cos 0.95-0.99).
-                        In the r8 variant (B ~ N(0, 1e-3)) that family's gradient norm is 6e-5: below the bf16 noise of ANY
-                        implementation (torch bf16: norm off by 48 %, cos 0.88) -- the factor 3 covers the run-to-run spread of
-                        a noise-dominated quantity; it is not a statement about signal.  A family whose torch-bf16 floor is itself
-                        below cos 0.95 is checked for direction (cos > 0.5) and magnitude (norm within a factor 2) only.
-
-The bf16 floor: the same step run by the ORACLE'S OWN CODE (plain torch ops) on the GPU with bf16 weights and activations,
-compared with the same fp32 golden.  It is needed for one family of tensors: the to_q / to_k adapters of the LAST block.
-Their gradient is a heavily cancelling sum (|dQ| is 20x smaller than |dK| there, profiles/r02_cfg1_attention_bwd_diag.txt),
-and any bf16 flash-attention backward rounds P and dS to bf16 before the dQ / dK products: re-computing the HIP kernel's
-dQ in fp32 torch from the same inputs with ONLY those two roundings added reproduces its error to 5 digits
-(cos 0.945049 vs 0.945045), i.e. the deviation is the arithmetic type, not the kernel.
+  LoRA grads, EVERY tensor, both variants: relative error e = |g - g_fp32| / |g_fp32| (whole tensor)
+                            e_hip <= max(REL_FIXED, FLOOR_FACTOR * e_torch_bf16)
+                        where e_torch_bf16 is the error of the oracle's own code run with bf16 weights / activations on the same GPU
+                        (plain torch autograd: what the reference's bf16-mixed training computes).  REL_FIXED = 0.08 (cosine 0.997)
+                        covers every well-conditioned tensor with room; the floor term exists for ONE family, the to_q / to_k adapters
+                        of the LAST block, whose gradient is a heavily cancelling sum (|dQ| 20x below |dK|) that amplifies ANY bf16
+                        perturbation of its inputs -- torch bf16 itself is 30-70 % off there.  The statement tested is therefore: the
+                        HIP path is never further from fp32 than 1.25 x plain torch bf16, and within 8 % wherever that is achievable.
+                        (Round 2 tested cosines against 3 x the floor with a "noise-dominated" escape; that escape is gone.)
+  attention backward, kernel level (test_cfg1_attention_backward_matches_rounding_injected_recompute): every attention-backward
+                        launch of the step is recorded and dQ / dK / dV of six (batch, head) slices each are recomputed in fp32 from
+                        the SAME inputs with only the two roundings every bf16 flash attention makes (P -> bf16 for dV, dS -> bf16 for
+                        dQ / dK): cosine >= 0.999, norm within 1 % -- the tight statement about the kernels themselves.
+  Reported, not asserted: the gradients against the rounding-injected oracle at MODEL level (oracle/cogvideox.py::_RoundedSDPA);
+                        measured, it does not explain the last block's q / k family (cos 0.79-0.95): that error comes from the bf16
+                        rounding of the attention's INPUTS, not of P / dS.
 """
 import json
 import math
@@ -45,24 +48,26 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def _bf16_floor(variant, gold):
-    """Plain-torch bf16 run of the step on the GPU (oracle code) -> per-tensor (norm_rel, sample_err/max, cos) vs the golden."""
+REL_FIXED, FLOOR_FACTOR = 0.08, 1.25
+
+
+def _oracle_on_gpu(variant, dtype, round_p_ds=False):
+    """The oracle's own code on the GPU: fp32 (the reference for whole gradient tensors), fp32 with the P / dS roundings injected, or
+    bf16 weights / activations (plain torch bf16: the floor)  -> (loss, {name: grad fp32 on the CPU})."""
     from oracle import scheduler as osch
     cfg = c1.config()
-    sd = {k: v.cuda() for k, v in c1.base_state_dict(cfg).items()}
+    sd = {k: v.to(dtype).cuda() for k, v in c1.base_state_dict(cfg).items()}
     lora, _ = c1.lora_state_dict(cfg, variant)
     lora = {k: v.cuda().requires_grad_(True) for k, v in lora.items()}
-    xw, xl, prompt, t, noise = c1.inputs()
-    out = ocv.dpo_pair_step(sd, cfg, lora, osch.alphas_cumprod().cuda(), xw.cuda(), xl.cuda(), prompt.cuda(), t.cuda(), noise.cuda(), beta=1.0)
+    xw, xl, prompt, t, noise = (v.to(dtype) if v.is_floating_point() else v for v in c1.inputs())
+    abar = osch.alphas_cumprod().cuda()
+    out = ocv.dpo_pair_step(sd, cfg, lora, abar, xw.cuda(), xl.cuda(), prompt.cuda(), t.cuda(), noise.cuda(), beta=1.0, round_p_ds=round_p_ds)
     out["loss"].backward()
-    floor = {}
-    for k, p in lora.items():
-        ref = gold["lora_grads"][k]
-        g = p.grad.float().cpu()
-        got, rs = g.flatten()[c1.sample_index(g.numel(), k)].double(), ref["samples"].double()
-        floor[k] = (abs(g.double().norm().item() / float(ref["norm"]) - 1), (got - rs).abs().max().item() / float(ref["absmax"]),
-                    float((got * rs).sum() / (got.norm() * rs.norm()).clamp_min(1e-300)))
-    return floor, float(out["loss"])
+    loss = float(out["loss"].detach())
+    grads = {k: p.grad.float().cpu() for k, p in lora.items()}
+    del out, sd, lora
+    torch.cuda.empty_cache()
+    return loss, grads
 
 
 def _hip_step(variant):
@@ -136,42 +141,80 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
 
     del preds
     torch.cuda.empty_cache()
-    floor, floor_loss = _bf16_floor(variant, gold)
-    report["loss_torch_bf16"] = floor_loss
-    worst = {"norm_rel": 0.0, "sample_err_over_max": 0.0, "cos_min": 1.0}
+    ref_loss, ref_grads = _oracle_on_gpu(variant, torch.float32)
+    floor_loss, floor_grads = _oracle_on_gpu(variant, torch.bfloat16)
+    ro_loss, ro_grads = _oracle_on_gpu(variant, torch.float32, round_p_ds=True)
+    report.update(loss_oracle_fp32_here=ref_loss, loss_torch_bf16=floor_loss, loss_rounded_oracle=ro_loss)
+    check(abs(ref_loss - float(gold["loss"])) < 1e-5, ("in-process fp32 oracle vs golden loss", ref_loss, float(gold["loss"])))
+    check(abs(ro_loss - float(gold["loss"])) < 2e-4, ("rounding-injected oracle drifted from the golden", ro_loss, float(gold["loss"])))
+    worst = {"rel_err_hip": 0.0, "rel_err_over_bound": 0.0}
     per_tensor = {}
-    assert set(grads) == set(gold["lora_grads"])
+    assert set(grads) == set(gold["lora_grads"]) == set(ref_grads)
+
+    def rel(a, r):
+        return float((a.double() - r.double()).norm() / r.double().norm())
+
+    def cosine(a, r):
+        a, r = a.double().flatten(), r.double().flatten()
+        return float((a * r).sum() / (a.norm() * r.norm()).clamp_min(1e-300))
+
     for k, g in grads.items():
-        ref = gold["lora_grads"][k]
+        r = ref_grads[k]
+        # the in-process fp32 oracle IS the golden: same samples, same norm
+        gs = gold["lora_grads"][k]
         idx = c1.sample_index(g.numel(), k)
-        got = g.flatten()[idx].double()
-        rs = ref["samples"].double()
-        amax = float(ref["absmax"])
-        nrel = abs(g.double().norm().item() / float(ref["norm"]) - 1)
-        serr = (got - rs).abs().max().item() / amax
-        cos = float((got * rs).sum() / (got.norm() * rs.norm()).clamp_min(1e-300))
-        # the floor of a tensor's family: rounding noise is random, so q / k x A / B of one block share the worst of their four floors
-        fam = [f for kk, f in floor.items() if kk.split(".attn1.")[0] == k.split(".attn1.")[0]
-               and (("to_q" in kk or "to_k" in kk) == ("to_q" in k or "to_k" in k))]
-        fn, fs, fc = max(f[0] for f in fam), max(f[1] for f in fam), min(f[2] for f in fam)
-        per_tensor[k.replace("base_model.model.transformer_blocks.", "")] = {"hip": (round(nrel, 5), round(serr, 5), round(cos, 6)),
-                                                                              "torch_bf16_floor": (round(fn, 5), round(fs, 5), round(fc, 6))}
-        worst["norm_rel"] = max(worst["norm_rel"], nrel)
-        worst["sample_err_over_max"] = max(worst["sample_err_over_max"], serr)
-        worst["cos_min"] = min(worst["cos_min"], cos)
-        if fc < 0.95:
-            # noise-dominated family (plain torch bf16 itself is below cos 0.95 against fp32: the r8 variant's last-block q / k adapters,
-            # gradient norm 6e-5): only direction and order of magnitude are meaningful, for either implementation
-            check(math.isfinite(nrel) and nrel < 1.0 and cos > 0.5, (k, "noise-dominated family", nrel, cos, fn, fc))
-            continue
-        check(math.isfinite(nrel) and nrel < max(0.05, 3 * fn), (k, "norm", nrel, fn))
-        check(serr < max(0.05, 3 * fs), (k, "sample", serr, fs))
-        check(1 - cos < max(0.01, 3 * (1 - fc)), (k, "cos", cos, fc))
+        check(cosine(r.flatten()[idx], gs["samples"]) > 0.99999 and abs(r.double().norm().item() / float(gs["norm"]) - 1) < 1e-4,
+              (k, "in-process fp32 oracle vs golden samples", cosine(r.flatten()[idx], gs["samples"])))
+        e_hip, e_floor = rel(g, r), rel(floor_grads[k], r)
+        bound = max(REL_FIXED, FLOOR_FACTOR * e_floor)
+        per_tensor[k.replace("base_model.model.transformer_blocks.", "")] = {
+            "rel_err_hip": round(e_hip, 5), "rel_err_torch_bf16": round(e_floor, 5), "bound": round(bound, 5), "cos_hip": round(cosine(g, r), 6),
+            "cos_torch_bf16": round(cosine(floor_grads[k], r), 6), "cos_hip_vs_rounding_injected_oracle": round(cosine(g, ro_grads[k]), 6)}
+        worst["rel_err_hip"] = max(worst["rel_err_hip"], e_hip)
+        worst["rel_err_over_bound"] = max(worst["rel_err_over_bound"], e_hip / bound)
+        check(math.isfinite(e_hip) and e_hip <= bound, (k, "relative error vs fp32 oracle", e_hip, "bound", bound, "torch bf16", e_floor))
     report["lora_grads_worst"] = worst
-    report["lora_grads_per_tensor (norm_rel, sample_err/max, cos)"] = per_tensor
+    report["lora_grads_per_tensor"] = per_tensor
     report["failed_checks"] = [str(f) for f in fails]
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"cfg1_parity_{variant}.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
     assert not fails, fails
+
+
+def test_cfg1_attention_backward_matches_rounding_injected_recompute():
+    """Kernel-level, at full width: every attention-backward launch of the cfg1 HIP step (r64) is recorded and, for six (batch, head)
+    slices each, dQ / dK / dV are recomputed in fp32 torch from the SAME bf16 inputs with only the kernels' two roundings (P, dS to
+    bf16) injected.  What is left is summation order and the exp2 / lse path: cosine >= 0.999, norm within 1 %."""
+    from videogpa_amd import ops
+    rec = []
+    orig = ops.attention_bwd_raw
+
+    def spy(q, k, v, o, do, lse, dq, dk, dv, **kw):
+        orig(q, k, v, o, do, lse, dq, dk, dv, **kw)
+        rec.append(tuple(t.clone() for t in (q, k, v, o, do, dq, dk, dv)))
+    ops.attention_bwd_raw = spy
+    try:
+        _hip_step("r64")
+    finally:
+        ops.attention_bwd_raw = orig
+    assert len(rec) == 2                      # one launch per block (win and lose batched)
+    log2e, scale = 1.4426950408889634, 0.125
+    worst = {"cos": 1.0, "norm": 0.0}
+    for li, (q, k, v, o, do, dq, dk, dv) in enumerate(rec):
+        for b in range(q.shape[0]):
+            for h in (0, 17, 47):
+                qf = q[b, h].float() / (scale * log2e)          # the kernels take q pre-multiplied by scale * log2(e)
+                kf, vf, of, dof = k[b, h].float(), v[b, h].float(), o[b, h].float(), do[b, h].float()
+                p = torch.softmax((qf @ kf.t()) * scale, dim=-1)
+                delta = (dof * of).sum(-1, keepdim=True)
+                ds = (p * (dof @ vf.t() - delta)).bfloat16().float()
+                ref = {"dq": (ds @ kf) * scale, "dk": (ds.t() @ qf) * scale, "dv": p.bfloat16().float().t() @ dof}
+                for name, got in (("dq", dq[b, h]), ("dk", dk[b, h]), ("dv", dv[b, h])):
+                    a, r = got.double().flatten(), ref[name].double().flatten()
+                    cos = float((a * r).sum() / (a.norm() * r.norm()))
+                    nrm = abs(float(a.norm() / r.norm()) - 1)
+                    worst["cos"], worst["norm"] = min(worst["cos"], cos), max(worst["norm"], nrm)
+                    assert cos >= 0.999 and nrm <= 0.01, (li, b, h, name, cos, nrm)
+    print(json.dumps({"attention_backward_vs_rounding_injected_recompute": worst}))
