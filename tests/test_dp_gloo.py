@@ -184,14 +184,15 @@ class _FakeTrainer(torch.nn.Module):
                              process_group=process_group)
 
 
-def _engine_worker(rank, world, port, out_dir):
+def _engine_worker(rank, world, port, out_dir, overlap=None, tag="eng"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from videogpa_amd import ops
     from videogpa_amd.trainer import DPOEngine
     tr = _FakeTrainer(accumulate=2)
     e0 = ops.ADAPTER_EPOCH
-    eng = DPOEngine(tr)                                         # broadcasts rank 0's parameters
+    eng = DPOEngine(tr, overlap=overlap)                        # broadcasts rank 0's parameters
+    assert eng.overlap == (True if overlap is None else overlap)    # more than one rank: the optimizer step is overlapped by default
     assert ops.ADAPTER_EPOCH == e0 + 1
     assert all(torch.equal(p.detach(), q.detach()) for p, q in zip(tr.params, _make_params(seed=0)))
     data = _data(8)
@@ -202,8 +203,14 @@ def _engine_worker(rank, world, port, out_dir):
         if "lr" in logs:
             synced.append(logs["sync"].clone())
             lrs.append(logs["lr"])
+    if eng.overlap:                                             # the second window's step is still in flight: it lands at flush()
+        assert tr.global_step == 1 and len(synced) == 1 and eng._pending is not None
+        last = eng.flush()
+        synced.append(last["sync"].clone())
+        lrs.append(last["lr"])
+    assert eng._pending is None and eng.flush() is eng.last      # idempotent
     assert tr.global_step == 2 and len(synced) == 2 and ops.ADAPTER_EPOCH == e0 + 3
-    torch.save({"param": eng.opt.flat.flat.clone(), "synced": torch.stack(synced)}, os.path.join(out_dir, f"eng{rank}.pt"))
+    torch.save({"param": eng.opt.flat.flat.clone(), "synced": torch.stack(synced), "lrs": torch.tensor(lrs)}, os.path.join(out_dir, f"{tag}{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -232,3 +239,15 @@ def test_dpo_engine_two_ranks_accumulation_and_synced_scalars(tmp_path):
         assert torch.allclose(r[0]["param"][o:o + p.numel()].view_as(p), p.detach(), rtol=0, atol=1e-6)
     assert torch.allclose(r[0]["synced"][:, 0], torch.tensor(ref), rtol=1e-5, atol=1e-6)            # loss: mean over ranks and micro-steps
     assert torch.allclose(r[0]["synced"][:, 1], 3 * torch.tensor(ref), rtol=1e-5, atol=1e-6)        # reward margin rides the same tail
+
+
+def test_overlapped_optimizer_step_is_bit_identical_to_the_immediate_one(tmp_path):
+    """DPOEngine(overlap=True) applies the optimizer step of a window inside the NEXT micro-step (after its reference pass, or right
+    after training_step for trainers without that hook) so that the all-reduce hides under compute: parameters, rank-mean scalars
+    and learning rates must equal the immediate form bit for bit, on both ranks."""
+    world = 2
+    for overlap, tag in ((True, "ov"), (False, "im")):
+        mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path), overlap, tag), nprocs=world, join=True)
+    for rank in range(world):
+        a, b = torch.load(tmp_path / f"ov{rank}.pt"), torch.load(tmp_path / f"im{rank}.pt")
+        assert torch.equal(a["param"], b["param"]) and torch.equal(a["synced"], b["synced"]) and torch.equal(a["lrs"], b["lrs"])

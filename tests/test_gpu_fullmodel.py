@@ -1,0 +1,138 @@
+"""The full 42-block models of BASELINE configs[1] (CogVideoX-5B T2V) and configs[2] (CogVideoX-5B-I2V) at S = 17 776 through the
+engine, checked by what holds regardless of the random weights (SURVEY 8c known answers): with the adapters' B = 0 (the PEFT
+initialisation) policy == reference bit for bit, so the Diffusion-DPO loss is ln 2 to 1e-6 after 42 layers, the gradient reaches only
+lora_B, everything is finite -- plus the memory the reference's I2V batch size needs, and one engine step through a real RCCL
+communicator.  -m gpu only; these three tests take the whole GPU (up to ~270 GB)."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _build(model_cfg, layers=42, seed=0):
+    from videogpa_amd import transformer as vtr
+    from videogpa_amd.transformer import CogVideoXTransformer3DModel
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device("cuda"):
+            model = CogVideoXTransformer3DModel(**dict(getattr(vtr, model_cfg), num_layers=layers))
+    finally:
+        torch.set_default_dtype(prev)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("norm.weight") or n == "norm_final.weight" or ".norm_q.weight" in n or ".norm_k.weight" in n:
+                p.fill_(1.0)
+            elif n.endswith(".bias"):
+                p.zero_()
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+    return model
+
+
+def _ln2_step(trainer, batch, n_lora):
+    torch.cuda.reset_peak_memory_stats()
+    out = trainer._shared_step(batch)
+    assert abs(out.loss.item() - math.log(2.0)) < 1e-6, out.loss.item()          # B = 0: policy == reference through all 42 blocks
+    out.loss.backward()
+    torch.cuda.synchronize()
+    named = {n: p for n, p in trainer.transformer.named_parameters() if p.requires_grad}
+    assert len(named) == n_lora and all(p.grad is not None and torch.isfinite(p.grad).all() for p in named.values())
+    assert all(float(p.grad.abs().max()) == 0.0 for n, p in named.items() if ".lora_A." in n)      # dA = dT^T x with dT = dy B = 0
+    nz = sum(float(p.grad.abs().max()) > 0.0 for n, p in named.items() if ".lora_B." in n)
+    assert nz >= (n_lora // 2) - 4, nz              # every lora_B (a few may underflow to exact zero in bf16 at this depth)
+    return torch.cuda.max_memory_allocated() / 2 ** 30
+
+
+def test_cfg2_full_42_block_pair_step_is_ln2_at_b0():
+    """BASELINE configs[1]: CogVideoX-5B T2V, 42 blocks, paired latents [1,2,13,16,60,90] (S = 17 776), LoRA r = 64 on q/k/v/out."""
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    tr = CogVideoXDPOTrainer({"lora_rank": 64, "lora_alpha": 128, "beta": 1.0, "seed": 7}, transformer=_build("COGVIDEOX_5B"))
+    tr.train()
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    batch = {"x_pair": (0.7 * torch.randn(1, 2, 13, 16, 60, 90, generator=g, device="cuda")).to(torch.bfloat16),
+             "prompt_emb": (0.2 * torch.randn(1, 226, 4096, generator=g, device="cuda")).to(torch.bfloat16)}
+    gb = _ln2_step(tr, batch, n_lora=42 * 8)
+    assert gb < 200.0, gb
+    print(f"cfg2 pair-step peak memory {gb:.1f} GB")
+
+
+def test_cfg3_i2v_batch_2_fits_and_is_ln2_at_b0():
+    """BASELINE configs[2] at the reference's I2V batch size (train/CogVideoX-I2V-5B/03_train.py:59-60: batch_size 2, no accumulation):
+    TWO pairs per step = four 17 776-token sequences through 42 blocks with every activation kept resident.  Must fit the 288 GB part."""
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    tr = CogVideoXDPOTrainer({"lora_rank": 64, "lora_alpha": 128, "beta": 1.0, "batch_size": 2, "accumulate_grad_batches": 1, "seed": 7},
+                             transformer=_build("COGVIDEOX_5B_I2V"))
+    tr.train()
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    batch = {"x_pair": (0.7 * torch.randn(2, 2, 13, 16, 60, 90, generator=g, device="cuda")).to(torch.bfloat16),
+             "prompt_emb": (0.2 * torch.randn(2, 226, 4096, generator=g, device="cuda")).to(torch.bfloat16),
+             "image_latent": (0.7 * torch.randn(2, 1, 16, 60, 90, generator=g, device="cuda")).to(torch.bfloat16)}
+    gb = _ln2_step(tr, batch, n_lora=42 * 8)
+    assert gb < 280.0, gb
+    print(f"cfg3 batch-2 pair-step peak memory {gb:.1f} GB")
+
+
+def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):
+    """DPOEngine with VGPA_FORCE_DIST=1 on one rank: the flat [gradients | scalars] SUM all-reduce really goes through RCCL (backend
+    "nccl" on ROCm) on the side stream, the optimizer step is applied overlapped (after the next micro-step's reference pass), and the
+    result equals the engine without any communicator bit for bit."""
+    import torch.distributed as dist
+    from oracle import cogvideox as ocv
+    from videogpa_amd.lora import LoraConfig, get_peft_model
+    from videogpa_amd.trainer import CogVideoXDPOTrainer, DPOEngine
+    from videogpa_amd.transformer import CogVideoXTransformer3DModel
+    kw = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=32, text_embed_dim=48, sample_width=8, sample_height=8,
+              sample_frames=9, max_text_seq_length=6)
+    cfg = ocv.CogVideoXConfig(**kw)
+    sd = {k: v.to(torch.bfloat16) for k, v in ocv.init_state_dict(cfg, seed=0, std=0.05, mod_std=0.2).items()}
+    g = torch.Generator().manual_seed(3)
+    batches = [{"x_pair": (0.7 * torch.randn(1, 2, 3, 16, 8, 8, generator=g)).to(torch.bfloat16).cuda(),
+                "prompt_emb": (0.5 * torch.randn(1, 6, 48, generator=g)).to(torch.bfloat16).cuda()} for _ in range(4)]
+
+    def run(force):
+        monkeypatch.setenv("VGPA_FORCE_DIST", "1" if force else "0")
+        model = CogVideoXTransformer3DModel(use_rotary_positional_embeddings=True, **kw)
+        model.load_state_dict(sd, strict=True)
+        torch.manual_seed(11)      # PEFT's kaiming-uniform lora_A
+        pm = get_peft_model(model.to(device="cuda", dtype=torch.bfloat16), LoraConfig(r=4, lora_alpha=8, target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+        with torch.no_grad():
+            gb = torch.Generator(device="cuda").manual_seed(5)
+            for n, p in pm.named_parameters():
+                if ".lora_B." in n:
+                    p.normal_(0.0, 0.05, generator=gb)
+        tr = CogVideoXDPOTrainer({"beta": 1.0, "accumulate_grad_batches": 2, "learning_rate": 1e-3, "warmup_steps": 0, "max_steps": 10, "seed": 2}, transformer=pm)
+        tr.train()
+        eng = DPOEngine(tr)
+        assert eng.overlap == force
+        seen = []
+        for b in batches:
+            logs = eng.micro_step(b)
+            if "sync" in logs:
+                seen.append(logs["sync"].clone())
+        last = eng.flush()
+        if force:
+            seen.append(last["sync"].clone())
+        assert tr.global_step == 2 and len(seen) == 2
+        return eng.opt.flat.flat.clone(), torch.stack(seen)
+
+    plain = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rccl = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(plain[0], rccl[0]) and torch.equal(plain[1], rccl[1])

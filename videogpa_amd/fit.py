@@ -14,26 +14,47 @@ from .loader import PairedPrefetcher
 from .trainer import DEFAULT_CONFIG, CogVideoXDPOTrainer, DPOEngine
 
 
-def save_checkpoint(engine: DPOEngine, path: str, val: Optional[Dict[str, float]] = None) -> None:
+def save_checkpoint(engine: DPOEngine, path: str, val: Optional[Dict[str, float]] = None, position: Optional[Dict[str, int]] = None) -> None:
     """Adapter (PEFT format) + optimizer state (flat Adam moments, step count) + trainer step: enough to resume.  The
     reference's ModelCheckpoint pickles the whole LightningModule incl. the two frozen 5B copies (SURVEY B-13); the
     frozen base is not state, so it is not written here."""
+    engine.flush()          # a checkpoint never holds an optimizer step that is still in flight
     os.makedirs(path, exist_ok=True)
     engine.trainer.transformer.save_pretrained(path)
     sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in engine.opt.state_dict().items()}
-    sd.update(global_step=engine.trainer.global_step, micro=engine.micro, val=val)
+    sd.update(global_step=engine.trainer.global_step, micro=engine.micro, val=val, position=dict(position or {}))
+    # the (t, eps) stream of THIS rank: without it a resumed run would replay the timesteps and noise of steps 0..k.  Other ranks
+    # write their own generator state next to it (rank 0 owns optimizer.pt).
+    rng = engine.trainer._rng
+    if rng is not None:
+        torch.save(rng.get_state(), os.path.join(path, f"rng_rank{dist.get_rank() if dist.is_initialized() else 0}.pt"))
     tmp = os.path.join(path, "optimizer.pt.tmp")
     torch.save(sd, tmp)
     os.replace(tmp, os.path.join(path, "optimizer.pt"))
 
 
-def load_checkpoint(engine: DPOEngine, path: str) -> None:
+def save_rng_state(engine: DPOEngine, path: str) -> None:
+    """What the ranks other than 0 contribute to a checkpoint: their own (t, eps) generator state."""
+    rng = engine.trainer._rng
+    if rng is not None:
+        os.makedirs(path, exist_ok=True)
+        torch.save(rng.get_state(), os.path.join(path, f"rng_rank{dist.get_rank() if dist.is_initialized() else 0}.pt"))
+
+
+def load_checkpoint(engine: DPOEngine, path: str) -> Dict[str, int]:
+    """-> the data position {"epoch", "batch"} the run had reached (zeros for checkpoints written before positions were saved)."""
     sd = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
     dev = engine.opt.flat.flat.device
     engine.opt.load_state_dict({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()
                                 if k in ("exp_avg", "exp_avg_sq", "param", "step_count")})
     engine.trainer.global_step = int(sd["global_step"])
     engine.micro = int(sd["micro"])
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    rp = os.path.join(path, f"rng_rank{rank}.pt")
+    if os.path.exists(rp):
+        engine.trainer.rng(dev).set_state(torch.load(rp, map_location="cpu"))
+    pos = sd.get("position") or {}
+    return {"epoch": int(pos.get("epoch", 0)), "batch": int(pos.get("batch", 0))}
 
 
 @torch.no_grad()
@@ -77,35 +98,51 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
     trainer = CogVideoXDPOTrainer(cfg, transformer=transformer, image_encoder=image_encoder).cuda()
     trainer.train()
     engine = DPOEngine(trainer)
+    pos = {"epoch": 0, "batch": 0}
     if cfg.get("resume_from"):
-        load_checkpoint(engine, cfg["resume_from"])
+        pos = load_checkpoint(engine, cfg["resume_from"])       # adapters, Adam moments, step counters, this rank's (t, eps) stream, data position
     step_target = cfg["max_steps"]
     every = int(cfg.get("checkpoint_every_n_steps", 1000))          # ModelCheckpoint(every_n_train_steps=1000), 03_train.py:268-275
-    epoch = 0
-    t0 = time.time()
+    epoch, skip = pos["epoch"], pos["batch"]
+    t0, start_step = time.time(), trainer.global_step
     last_ckpt = trainer.global_step
     while trainer.global_step < step_target:
         local = [train_idx[i] for i in shard_indices(len(train_idx), rank, world, epoch=epoch)]
+        local = local[skip * cfg["batch_size"]:]                    # a resumed run continues inside the epoch it was in
         loader = DataLoader(Subset(dataset, local), batch_size=cfg["batch_size"], shuffle=False, num_workers=cfg.get("num_workers", 4),
                             collate_fn=collate_paired, drop_last=False)
+        batch_in_epoch = skip
+        skip = 0
         for batch in PairedPrefetcher(loader):
             logs = engine.micro_step(batch)
+            batch_in_epoch += 1
+            # with the all-reduce overlapped the step lands one micro-step late: land it now when something waits for it
+            due = trainer.global_step + (1 if engine._pending is not None else 0)
+            if engine._pending is not None and (due >= step_target or (every > 0 and due % every == 0)):
+                logs.update(engine.flush())
             if rank == 0 and "lr" in logs and trainer.global_step % cfg.get("log_every_n_steps", 10) == 0:
-                sps = trainer.global_step * world * cfg["batch_size"] * cfg["accumulate_grad_batches"] / max(1e-9, time.time() - t0)
+                sps = (trainer.global_step - start_step) * world * cfg["batch_size"] * cfg["accumulate_grad_batches"] / max(1e-9, time.time() - t0)
                 sync = logs["sync"].tolist()          # rank-mean of the step's scalars (rode the gradient all-reduce)
                 log(f"step {trainer.global_step}: loss {sync[0]:.6f} margin {sync[1]:.3e} acc {sync[2]:.2f} "
                     f"lr {logs['lr']:.3e} samples/s {sps:.3f} max_mem {torch.cuda.max_memory_reserved() / 2 ** 30:.1f} GB")
             if "lr" in logs and every > 0 and trainer.global_step % every == 0 and trainer.global_step != last_ckpt:
                 last_ckpt = trainer.global_step
                 val = validate(trainer, dataset, val_idx, cfg, rank, world) if val_idx else None
+                ckpt_dir = os.path.join(cfg["output_dir"], "checkpoints", f"step={trainer.global_step}") if cfg.get("output_dir") else None
                 if rank == 0:
                     if val is not None:
                         log(f"step {trainer.global_step}: " + " ".join(f"{k} {v:.6f}" for k, v in val.items()))
-                    if cfg.get("output_dir"):
-                        save_checkpoint(engine, os.path.join(cfg["output_dir"], "checkpoints", f"step={trainer.global_step}"), val)
+                    if ckpt_dir:
+                        save_checkpoint(engine, ckpt_dir, val, position={"epoch": epoch, "batch": batch_in_epoch})
+                elif ckpt_dir:
+                    save_rng_state(engine, ckpt_dir)
             if trainer.global_step >= step_target:
                 break
-        epoch += 1
+        else:
+            epoch += 1
+            continue
+        break
+    engine.flush()
     if rank == 0 and cfg.get("output_dir"):
         trainer.transformer.save_pretrained(os.path.join(cfg["output_dir"], "final_lora"))
     return trainer

@@ -273,7 +273,7 @@ class _ResidualLNFn(torch.autograd.Function):
         LoRA down-projections into the tail and runs ONE GEMM over K = D+n_pad); dy_pad: the same for the gradient of y."""
         _req(x, torch.bfloat16), _req(ln_w, torch.float32), _req(ln_b, torch.float32)
         B, S, D = x.shape
-        n = torch.empty(B, S, D + n_pad, dtype=x.dtype, device=x.device)[..., :D] if n_pad else torch.empty_like(x)
+        n = _padded_empty((B, S), D, n_pad, x.dtype, x.device) if n_pad else torch.empty_like(x)
         mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         sv, s1v, st, s1t, mstride = _mod_ptrs(mod)
@@ -305,7 +305,7 @@ class _ResidualLNFn(torch.autograd.Function):
         _, s1v, _, s1t, mstride = _mod_ptrs(mod)
         dyp = ctx.dy_pad
         if ctx.has_y:
-            dy = torch.empty(B, S, D + dyp, dtype=xs.dtype, device=xs.device)[..., :D] if dyp else torch.empty_like(xs)
+            dy = _padded_empty((B, S), D, dyp, xs.dtype, xs.device) if dyp else torch.empty_like(xs)
             gv, gt, gstride = gates[:, 0], gates[:, 1], gates.stride(0)
         else:
             dy, gv, gt, gstride = None, None, None, 0
@@ -472,11 +472,23 @@ def bump_adapter_epoch():
     ADAPTER_EPOCH += 1
 
 
+def _padded_empty(shape, D, pad, dtype, device):
+    """A fresh [..., D + pad] buffer whose tail is zero, marked as a padded operand buffer; returns its [..., :D] head view.  The
+    producers of LoRA-carrying GEMM operands (residual_ln, attention, their backwards) allocate through this; `_padded_base`
+    recognises ONLY buffers made here (a caller's slice of some wider tensor is never written into)."""
+    buf = torch.empty(*shape, D + pad, dtype=dtype, device=device)
+    buf[..., D:].zero_()          # fresh tensor, no autograd history: the reference pass's LoRA tail is zero without touching a view later
+    buf._vgpa_pad = (D, pad)
+    return buf[..., :D]
+
+
 def _padded_base(t2, width):
-    """If the 2-D tensor `t2` [M, K] is the head of a contiguous [M, width] buffer (made by residual_ln / attention /
-    QK-norm backward with a pad), return that buffer as [M, width]; else None."""
+    """If the 2-D tensor `t2` [M, K] is the head of a buffer made by `_padded_empty` with total width `width`, return that buffer as
+    [M, width]; else None."""
     b = t2._base
-    if b is None or b.shape[-1] != width or not b.is_contiguous() or b.data_ptr() != t2.data_ptr() or b.numel() != t2.shape[0] * width:
+    if b is None or getattr(b, "_vgpa_pad", None) != (t2.shape[-1], width - t2.shape[-1]):
+        return None
+    if b.shape[-1] != width or not b.is_contiguous() or b.data_ptr() != t2.data_ptr() or b.numel() != t2.shape[0] * width:
         return None
     return b.view(-1, width)
 
@@ -541,13 +553,12 @@ class _LinearLoraExtFn(torch.autograd.Function):
         M = x2.shape[0]
         x_ext = _padded_base(x2, K + R)
         if x_ext is None:
-            x_ext = torch.empty(M, K + R, dtype=x.dtype, device=x.device)
+            x_ext = torch.zeros(M, K + R, dtype=x.dtype, device=x.device) if not enabled else torch.empty(M, K + R, dtype=x.dtype, device=x.device)
             x_ext[:, :K].copy_(x2)
         xv, tv = x_ext[:, :K], x_ext[:, K:]
         if enabled:
-            lora_down(xv, ext.A_cat, out=tv)
-        else:
-            tv.zero_()
+            lora_down(xv, ext.A_cat, out=tv)       # raw kernel write into the tail (no autograd version bump on the producer's buffer)
+        # disabled (reference pass): the tail of a `_padded_empty` buffer is zero since its allocation
         y = _gemm(x_ext, ext.W_ext, bias)
         ctx.save_for_backward(x_ext)
         ctx.ext, ctx.enabled, ctx.xshape, ctx.scalings = ext, enabled, x.shape, scalings
@@ -562,13 +573,11 @@ class _LinearLoraExtFn(torch.autograd.Function):
         M = dy2.shape[0]
         dy_ext = _padded_base(dy2, N + R) if dy2.stride(1) == 1 else None
         if dy_ext is None:
-            dy_ext = torch.empty(M, N + R, dtype=dy.dtype, device=dy.device)
+            dy_ext = torch.zeros(M, N + R, dtype=dy.dtype, device=dy.device) if not enabled else torch.empty(M, N + R, dtype=dy.dtype, device=dy.device)
             dy_ext[:, :N].copy_(dy2)
         if enabled:
             for j, i in enumerate(act):
                 lora_down(dy_ext[:, i * Dn:(i + 1) * Dn], ext.sBt[j], out=dy_ext[:, N + j * rp:N + (j + 1) * rp])      # dT_i = dy_i (s B_i)
-        else:
-            dy_ext[:, N:].zero_()
         dx = _gemm(dy_ext, ext.Wt_ext)                                                                                # dy W + dT A
         out_grads = [None] * len(ctx.needs_input_grad[5:])
         if enabled:
@@ -642,9 +651,7 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
     scale = Dh ** -0.5 if scale is None else scale
     if not q_prescaled:
         q = prescale_q(q, scale)
-    o = torch.empty(B, S, H * Dh + o_pad, dtype=torch.bfloat16, device=q.device)
-    if o_pad:
-        o = o[..., :H * Dh]
+    o = _padded_empty((B, S), H * Dh, o_pad, torch.bfloat16, q.device) if o_pad else torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=q.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
     ov = o.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
     split_mode = ATTN_SPLIT_MODE if split_mode is None else split_mode
@@ -737,7 +744,7 @@ class _QKNormAttentionFn(torch.autograd.Function):
         do = do.contiguous()
         qkv5 = qkv.view(B, S, 3, H, Dh)
         q_in, k_in, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        dqkv = torch.empty(B, S, W + grad_pad, dtype=qkv.dtype, device=qkv.device)[..., :W] if grad_pad else torch.empty_like(qkv)
+        dqkv = _padded_empty((B, S), W, grad_pad, qkv.dtype, qkv.device) if grad_pad else torch.empty_like(qkv)
         d5 = dqkv.unflatten(-1, (3, H, Dh))
         dq_in, dk_in, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         dqn = torch.empty_like(qn)

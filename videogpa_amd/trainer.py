@@ -87,7 +87,11 @@ class CogVideoXDPOTrainer(nn.Module):
                                      target_modules=cfg["lora_target_modules"])
             self.transformer = get_peft_model(transformer, lora_config)
         if cfg.get("enable_gradient_checkpointing"):
-            self.transformer.enable_gradient_checkpointing(stride=int(cfg.get("gradient_checkpointing_stride", 1)))
+            stride = int(cfg.get("gradient_checkpointing_stride", 1))
+            if stride != 1:     # the stride is this package's extension; a diffusers / PEFT model takes no arguments here
+                self.transformer.enable_gradient_checkpointing(stride=stride)
+            else:
+                self.transformer.enable_gradient_checkpointing()
         self.ref_transformer = None
         if separate_ref:  # the reference's layout: a second frozen copy (:110-111)
             import copy
@@ -107,6 +111,7 @@ class CogVideoXDPOTrainer(nn.Module):
         self.start_time = None
         self.global_step = 0
         self._rng = None
+        self.after_reference = None     # hook between the frozen-reference pass and the policy pass (set by DPOEngine)
 
     def rng(self, device):
         """Per-rank generator of the (t, eps) stream: seed + rank, so data-parallel ranks draw different noise
@@ -141,6 +146,8 @@ class CogVideoXDPOTrainer(nn.Module):
         prompt2 = prompt_emb.repeat_interleave(2, dim=0)
         t2 = timesteps.repeat_interleave(2)
         v_ref = self._ref_forward(hs, prompt2, t2)
+        if self.after_reference is not None:       # DPOEngine: the previous optimizer step lands here, its all-reduce hidden under the pass above
+            self.after_reference()
         v_pol = self.transformer(hs, encoder_hidden_states=prompt2, timestep=t2, return_dict=True).sample
         v_pol = v_pol.reshape(B, 2, *v_pol.shape[1:])
         v_ref = v_ref.reshape(B, 2, *v_ref.shape[1:])
@@ -254,22 +261,61 @@ class CogVideoXDPOTrainer(nn.Module):
 
 
 class DPOEngine:
-    """Micro-step / optimizer-step driver: accumulation, flat-gradient all-reduce, fused clip + AdamW."""
+    """Micro-step / optimizer-step driver: accumulation, flat-gradient all-reduce, fused clip + AdamW.
 
-    def __init__(self, trainer: CogVideoXDPOTrainer, process_group=None):
+    With `overlap` (default: whenever there is more than one rank) the optimizer step of an accumulation window is NOT applied where
+    the window ends: the SUM all-reduce of [gradients | logged scalars] is issued on the side stream right after the last backward, and
+    the update is applied inside the NEXT micro-step, between its frozen-reference pass (which does not read the adapters) and its
+    policy pass (`trainer.after_reference`).  The collective is thereby hidden under a quarter of a step of compute; every policy pass
+    still sees exactly the adapters it would see without the reordering, so results are bit-identical (tests/test_dp_gloo.py).
+    `flush()` applies a step that is still pending (end of training, before a checkpoint or a validation pass, before reading
+    `last`)."""
+
+    _NO_WORK = object()
+
+    def __init__(self, trainer: CogVideoXDPOTrainer, process_group=None, overlap=None):
         self.trainer = trainer
         self.opt = trainer.configure_optimizers(process_group)
         self.accum = int(trainer.config.get("accumulate_grad_batches", 1))
         self.micro = 0
         # every rank must start from rank 0's adapter values (DDP does this broadcast at construction)
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        if multi:
             dist.broadcast(self.opt.flat.flat, src=0, group=process_group)
         ops.bump_adapter_epoch()          # parameters were re-homed into the flat buffer (and possibly overwritten by rank 0's)
         self.opt.zero_grad()
+        self.overlap = (multi or os.environ.get("VGPA_FORCE_DIST") == "1") if overlap is None else bool(overlap)
+        self._pending = None              # all-reduce handle (or _NO_WORK) of an optimizer step that has not been applied yet
+        self.last = {}                    # lr / rank-mean scalars of the most recently applied optimizer step
+        self._fresh = False
+        self._hooked = self.overlap and hasattr(trainer, "after_reference")
+        if self._hooked:
+            trainer.after_reference = self._finish
+
+    def _finish(self):
+        if self._pending is None:
+            return
+        work, self._pending = self._pending, None
+        tail = self.opt.flat.tail
+        lr = self.opt.step(None if work is DPOEngine._NO_WORK else work)
+        # mean over ranks and micro-steps; a device tensor (read it only when logging)
+        self.last = {"lr": lr, "sync": (tail[:3] / tail[3:4]).clone(), "sync_keys": ("train/loss", "train/reward_margin", "train/reward_accuracy")}
+        self._fresh = True
+        self.opt.zero_grad()
+        self.trainer.global_step += 1
+
+    def flush(self) -> Dict[str, Any]:
+        """Apply the optimizer step that is still in flight (if any); returns the scalars of the last applied step."""
+        self._finish()
+        self._fresh = False
+        return self.last
 
     def micro_step(self, batch) -> Dict[str, Any]:
-        loss, logs = self.trainer.training_step(batch, self.micro)
+        if not self._hooked:
+            self._finish()                                               # a trainer without the hook: the step lands before its forward
+        loss, logs = self.trainer.training_step(batch, self.micro)      # hooked: a pending step is applied after the reference pass
+        self._finish()                                                   # (a training_step that never reached the hook)
         (loss / self.accum).backward()
         # the three scalars the reference logs with sync_dist=True (train/CogVideoX-5B/03_train.py:164-173) go into the tail
         # of the gradient buffer and are reduced by the SAME all-reduce: no extra collective, no host sync
@@ -279,11 +325,11 @@ class DPOEngine:
         tail[3:4].add_(1.0)
         self.micro += 1
         if self.micro % self.accum == 0:
-            pending = self.opt.all_reduce_grads()
-            logs["lr"] = self.opt.step(pending)
-            # mean over ranks and micro-steps; a device tensor (read it only when logging)
-            logs["sync"] = (tail[:3] / tail[3:4]).clone()
-            logs["sync_keys"] = ("train/loss", "train/reward_margin", "train/reward_accuracy")
-            self.opt.zero_grad()
-            self.trainer.global_step += 1
+            work = self.opt.all_reduce_grads()
+            self._pending = DPOEngine._NO_WORK if work is None else work
+            if not self.overlap:
+                self._finish()
+        if self._fresh:                   # an optimizer step was applied during this call: hand its scalars to the caller
+            logs.update(self.last)
+            self._fresh = False
         return logs

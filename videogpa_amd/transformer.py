@@ -63,8 +63,9 @@ class Transformer3DModelOutput(SimpleNamespace):
 def _f32(t):
     """fp32 copy of a (frozen) norm / modulation parameter for the kernels, cached on the parameter while it is unchanged."""
     c = getattr(t, "_vgpa_f32", None)
-    if c is None or c[0] != t._version or c[1].device != t.device:
-        c = (t._version, t.detach().float().contiguous())
+    key = (t._version, t.data_ptr(), t.dtype, t.device)     # data_ptr: `param.data = other` keeps the version number
+    if c is None or c[0] != key:
+        c = (key, t.detach().float().contiguous())
         t._vgpa_f32 = c
     return c[1]
 
