@@ -97,13 +97,13 @@ int32_t vgpa_qknorm_rope_fwd(const void* q_in, const void* k_in, void* q_out, vo
                              const int64_t* kin_strides, const int64_t* qout_strides, const int64_t* kout_strides,
                              const float* wq, const float* bq, const float* wk, const float* bk, const float* rope_cos,
                              const float* rope_sin, int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim,
-                             float eps, float q_out_scale, vgpa_stream_t stream);
+                             float eps, float q_out_scale, int32_t rope_mode, vgpa_stream_t stream);
 int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void* q_in, const void* k_in, void* dq_in,
                              void* dk_in, const int64_t* dqout_strides, const int64_t* dkout_strides,
                              const int64_t* qin_strides, const int64_t* kin_strides, const int64_t* dqin_strides,
                              const int64_t* dkin_strides, const float* wq, const float* wk, const float* rope_cos,
                              const float* rope_sin, int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim,
-                             float eps, vgpa_stream_t stream);
+                             float eps, int32_t rope_mode, vgpa_stream_t stream);
 
 /* ---- 3D full attention, non-causal, head_dim 64 (F.scaled_dot_product_attention in the same processor) ----------
  * CONTRACT: q is PRE-MULTIPLIED by scale*log2(e) in every entry point below; dq is the gradient w.r.t. the unscaled q.

@@ -1,0 +1,57 @@
+"""CPU restatement of the reference-held VGGT attention path (test infrastructure only -- see oracle/__init__.py):
+
+  rope2d            vggt/layers/rope.py:60-188   RotaryPositionEmbedding2D (frequency 100): features [0, d/2) rotate with y, [d/2, d) with x,
+                                                 rotate-half pairing inside each half
+  attention         vggt/layers/attention.py:20-72   fused qkv Linear, LayerNorm(head_dim) on q and k (nn.LayerNorm: eps 1e-5), RoPE,
+                                                 softmax(q k^T / sqrt(d)) v, proj
+  block             vggt/layers/block.py:30-108  x + ls1(attn(norm1(x))) ; x + ls2(mlp(norm2(x))), Mlp = fc1 -> GELU (erf) -> fc2
+  frame_global_pair vggt/models/aggregator.py:260-306  frame attention on (B*S, P, C), global attention on (B, S*P, C)
+
+Pinned: tests/test_oracle_golden.py::test_vggt_attention_* checks every function against tests/golden/vggt_attention.pt, which
+tests/golden/make_golden.py::golden_vggt_attention made by importing the reference modules."""
+import torch
+import torch.nn.functional as F
+
+
+def rope2d(t, pos, frequency=100.0):
+    """t [B, H, N, d], pos [B, N, 2] integer (y, x)."""
+    d = t.shape[-1]
+    half = d // 2
+    inv = 1.0 / (frequency ** (torch.arange(0, half, 2, dtype=torch.float32) / half))
+
+    def one(feat, p):
+        ang = p.to(torch.float32)[:, :, None] * inv[None, None, :]          # [B, N, half/2]
+        ang = torch.cat([ang, ang], dim=-1).to(feat.dtype)[:, None]          # [B, 1, N, half]
+        x1, x2 = feat[..., : half // 2], feat[..., half // 2:]
+        return feat * ang.cos() + torch.cat([-x2, x1], dim=-1) * ang.sin()
+    return torch.cat([one(t[..., :half], pos[..., 0]), one(t[..., half:], pos[..., 1])], dim=-1)
+
+
+def attention(x, p, heads, pos=None, prefix=""):
+    B, N, C = x.shape
+    hd = C // heads
+    qkv = F.linear(x, p[prefix + "qkv.weight"], p[prefix + "qkv.bias"]).reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = F.layer_norm(q, (hd,), p[prefix + "q_norm.weight"], p[prefix + "q_norm.bias"], 1e-5)
+    k = F.layer_norm(k, (hd,), p[prefix + "k_norm.weight"], p[prefix + "k_norm.bias"], 1e-5)
+    if pos is not None:
+        q, k = rope2d(q, pos), rope2d(k, pos)
+    a = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, N, C)
+    return F.linear(o, p[prefix + "proj.weight"], p[prefix + "proj.bias"])
+
+
+def block(x, p, heads, pos=None):
+    h = F.layer_norm(x, (x.shape[-1],), p["norm1.weight"], p["norm1.bias"], 1e-5)
+    x = x + p["ls1.gamma"] * attention(h, p, heads, pos, prefix="attn.")
+    h = F.layer_norm(x, (x.shape[-1],), p["norm2.weight"], p["norm2.bias"], 1e-5)
+    h = F.linear(F.gelu(F.linear(h, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
+    return x + p["ls2.gamma"] * h
+
+
+def frame_global_pair(tokens, p_frame, p_global, heads, B, S, pos):
+    """tokens [B*S, P, C], pos [B*S, P, 2] -> (frame block output [B*S, P, C], global block output [B, S*P, C])."""
+    P, C = tokens.shape[1], tokens.shape[2]
+    t1 = block(tokens, p_frame, heads, pos)
+    t2 = block(t1.view(B, S * P, C), p_global, heads, pos.view(B, S * P, 2))
+    return t1, t2

@@ -320,6 +320,71 @@ def golden_scorer2():
     print("scorer2.pt written:", {k: len(v) for k, v in out.items()})
 
 
+def golden_vggt_attention():
+    """tests/golden/vggt_attention.pt: the reference-HELD QK-norm attention (vggt/layers/attention.py:20-72: fused qkv, LayerNorm(64) on
+    q and k, optional RotaryPositionEmbedding2D vggt/layers/rope.py:60-188, SDPA, proj) and the aggregator's block around it
+    (vggt/layers/block.py:30-108: LayerNorm, attention, LayerScale, Mlp) run by IMPORTING the reference, fp32 on CPU, head_dim 64:
+    forward outputs and the gradients of the input and of every parameter.  All values are bf16-representable on the input side,
+    so a bf16 implementation differs by its arithmetic only.  This pins the attention kernel family against code the reference
+    itself ships (the CogVideoX attention lives in un-vendored diffusers)."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from vggt.layers.attention import Attention
+    from vggt.layers.block import Block
+    from vggt.layers.rope import RotaryPositionEmbedding2D
+    torch.manual_seed(20260930)
+    g = torch.Generator().manual_seed(77)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    out = {"attention": [], "block": []}
+    for N, use_rope, dim, heads, Bx in ((37, False, 128, 2, 2), (261, False, 128, 2, 1), (261, True, 128, 2, 1), (1374, True, 64, 1, 1)):
+        att = Attention(dim, num_heads=heads, qk_norm=True, rope=RotaryPositionEmbedding2D(frequency=100.0) if use_rope else None)
+        with torch.no_grad():
+            for p in att.parameters():
+                p.copy_(rb(torch.randn(p.shape, generator=g) * (0.08 if p.ndim == 2 else 0.3) + (1.0 if p.ndim == 1 and p.shape[0] == 64 else 0.0)))
+        x = rb(torch.randn(Bx, N, dim, generator=g)).requires_grad_(True)
+        pos = None
+        if use_rope:   # what the aggregator feeds (vggt/models/aggregator.py:215-224): 0 for the special tokens, grid position + 1 for patches
+            side = int((N - 5) ** 0.5)
+            yy, xx = torch.meshgrid(torch.arange(side), torch.arange(side), indexing="ij")
+            grid = torch.stack([yy.flatten(), xx.flatten()], -1) + 1
+            pos = torch.cat([torch.zeros(N - side * side, 2, dtype=torch.long), grid], 0)[None].expand(Bx, -1, -1).contiguous()
+        y = att(x, pos=pos)
+        gy = rb(torch.randn(y.shape, generator=g))
+        y.backward(gy)
+        out["attention"].append({"N": N, "dim": dim, "heads": heads, "rope": use_rope, "pos": None if pos is None else pos[0].to(torch.int16),
+                                 "x": x.detach().to(torch.bfloat16), "grad_out": gy.to(torch.bfloat16),      # bf16-representable: stored as bf16
+                                 "params": {k: v.detach().to(torch.bfloat16) for k, v in att.named_parameters()}, "y": y.detach(),
+                                 "grad_x": x.grad.clone(), "grad_params": {k: v.grad.clone() for k, v in att.named_parameters()}})
+    # one frame + one global block of the alternating-attention aggregator on [B=1, S=3 frames, P tokens]: frame attention sees
+    # (B*S, P, C), global attention (B, S*P, C) (vggt/models/aggregator.py:260-306)
+    dim, heads = 128, 2
+    Bq, Sq, side = 1, 3, 6
+    P = 5 + side * side
+    rope = RotaryPositionEmbedding2D(frequency=100.0)
+    blocks = [Block(dim, heads, mlp_ratio=2.0, qkv_bias=True, proj_bias=True, ffn_bias=True, init_values=0.01, qk_norm=True, rope=rope) for _ in range(2)]
+    with torch.no_grad():
+        for b in blocks:
+            for n, p in b.named_parameters():
+                if "gamma" in n:
+                    p.copy_(rb(0.5 + 0.1 * torch.randn(p.shape, generator=g)))
+                else:
+                    p.copy_(rb(torch.randn(p.shape, generator=g) * (0.08 if p.ndim == 2 else 0.3) + (1.0 if "norm" in n and n.endswith("weight") else 0.0)))
+    tokens = rb(torch.randn(Bq * Sq, P, dim, generator=g)).requires_grad_(True)
+    yy, xx = torch.meshgrid(torch.arange(side), torch.arange(side), indexing="ij")
+    pos = torch.cat([torch.zeros(5, 2, dtype=torch.long), torch.stack([yy.flatten(), xx.flatten()], -1) + 1], 0)[None].expand(Bq * Sq, -1, -1).contiguous()
+    t1 = blocks[0](tokens, pos=pos)                                                   # frame attention
+    t2 = blocks[1](t1.view(Bq, Sq * P, dim), pos=pos.view(Bq, Sq * P, 2))             # global attention
+    gy = rb(torch.randn(t2.shape, generator=g))
+    t2.backward(gy)
+    out["block"] = {"B": Bq, "S": Sq, "P": P, "dim": dim, "heads": heads, "pos": pos[0].to(torch.int16), "tokens": tokens.detach().to(torch.bfloat16),
+                    "grad_out": gy.to(torch.bfloat16), "params": [{k: v.detach().to(torch.bfloat16) for k, v in b.named_parameters()} for b in blocks],
+                    "frame_out": t1.detach(), "global_out": t2.detach(), "grad_tokens": tokens.grad.clone(),
+                    # gradients of the MLP matrices are plain GEMMs outside this path: their norms only
+                    "grad_params": [{k: (v.grad.clone() if "mlp.fc" not in k or v.ndim == 1 else v.grad.norm()) for k, v in b.named_parameters()} for b in blocks]}
+    torch.save(out, os.path.join(HERE, "vggt_attention.pt"))
+    print("vggt_attention.pt:", len(out["attention"]), "attention cases + 1 frame/global block pair")
+
+
 def golden_adapter_config_keys():
     """Key set PEFT wrote for the released adapters (checkpoints/VideoGPA-T2V-lora/adapter_config.json)."""
     cfg = json.load(open(os.path.join(REF, "checkpoints/VideoGPA-T2V-lora/adapter_config.json")))
@@ -332,3 +397,4 @@ if __name__ == "__main__":
     golden_dataset()
     golden_scorer()
     golden_scorer2()
+    golden_vggt_attention()

@@ -120,3 +120,45 @@ def test_lpips_and_consistency_wrappers_match_reference(golden_dir):
     for c in g["consistency"]:
         sc_, mo_ = scorer.consistency_score(c["gt"], c["rep"], c["extrinsics"].numpy(), _STANDIN_NET, c["ratio"])
         assert abs(sc_ - c["score"]) <= 2e-6 * max(1.0, abs(c["score"])) and mo_ == c["motion"], (sc_, c["score"], mo_, c["motion"])
+
+
+# ---------------------------------------------------------------- reference-held attention (VGGT): pins the attention kernel family
+def _vggt_params(d):
+    return {k: v.float().requires_grad_(True) for k, v in d.items()}
+
+
+def test_vggt_attention_oracle_matches_reference(golden_dir):
+    """oracle/vggt.py::attention / rope2d against outputs of vggt/layers/attention.py + rope.py (imported by make_golden.py): forward and
+    every gradient to 2e-5 of the tensor's range (fp32 on both sides, different summation order)."""
+    from oracle import vggt as ov
+    gold = torch.load(os.path.join(golden_dir, "vggt_attention.pt"))
+    for c in gold["attention"]:
+        p = _vggt_params(c["params"])
+        x = c["x"].float().requires_grad_(True)
+        pos = None if c["pos"] is None else c["pos"].long()[None].expand(x.shape[0], -1, -1)
+        y = ov.attention(x, p, c["heads"], pos)
+        y.backward(c["grad_out"].float())
+        assert (y - c["y"]).abs().max().item() <= 2e-5 * c["y"].abs().max().item()
+        assert (x.grad - c["grad_x"]).abs().max().item() <= 2e-5 * c["grad_x"].abs().max().item()
+        gscale = max(g.abs().max().item() for g in c["grad_params"].values())     # k_norm.bias has a mathematically ZERO gradient (softmax shift invariance)
+        for k, g in c["grad_params"].items():
+            assert (p[k].grad - g).abs().max().item() <= 3e-5 * max(g.abs().max().item(), 1e-2 * gscale), (c["N"], k)
+
+
+def test_vggt_frame_global_block_pair_oracle_matches_reference(golden_dir):
+    from oracle import vggt as ov
+    c = torch.load(os.path.join(golden_dir, "vggt_attention.pt"))["block"]
+    pf, pg = _vggt_params(c["params"][0]), _vggt_params(c["params"][1])
+    tok = c["tokens"].float().requires_grad_(True)
+    pos = c["pos"].long()[None].expand(c["B"] * c["S"], -1, -1).contiguous()
+    t1, t2 = ov.frame_global_pair(tok, pf, pg, c["heads"], c["B"], c["S"], pos)
+    t2.backward(c["grad_out"].float())
+    assert (t1 - c["frame_out"]).abs().max().item() <= 2e-5 * c["frame_out"].abs().max().item()
+    assert (t2 - c["global_out"]).abs().max().item() <= 2e-5 * c["global_out"].abs().max().item()
+    assert (tok.grad - c["grad_tokens"]).abs().max().item() <= 3e-5 * c["grad_tokens"].abs().max().item()
+    for p, gp in ((pf, c["grad_params"][0]), (pg, c["grad_params"][1])):
+        for k, g in gp.items():
+            if g.ndim == 0:
+                assert abs(p[k].grad.norm().item() / g.item() - 1) < 1e-4, k
+            else:
+                assert (p[k].grad - g).abs().max().item() <= 5e-5 * g.abs().max().item() + 2e-6, k

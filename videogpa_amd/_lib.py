@@ -31,8 +31,8 @@ SIGNATURES = {
     "vgpa_gate_residual": (I32, [P, P, P, P, I64, I64, I64, I64, I64, P, P]),
     "vgpa_gelu_tanh_fwd": (I32, [P, I64, P, P]),
     "vgpa_gelu_tanh_bwd": (I32, [P, P, I64, P, P]),
-    "vgpa_qknorm_rope_fwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, F32, P]),
-    "vgpa_qknorm_rope_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
+    "vgpa_qknorm_rope_fwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, F32, I32, P]),
+    "vgpa_qknorm_rope_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, I32, P]),
     "vgpa_attn_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_fwd_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn_fwd_ws": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),

@@ -4,8 +4,12 @@
 // image_rotary_emb is given, i.e. the generate path generate/CogVideoX-5B.py:72-77); oracle:
 // oracle/cogvideox.py::block_forward / apply_rotary_emb.
 //
+// The same kernels serve the VGGT aggregator's attention (vggt/layers/attention.py:50-72: LayerNorm(64) on q and k, eps 1e-5, then
+// RotaryPositionEmbedding2D, vggt/layers/rope.py:154-188), whose rotation pairs features (i, i + 16) inside each 32-feature half
+// (vertical / horizontal) instead of (2j, 2j + 1): rope_mode 1.
+//
 // HBM-bound: 8 lanes own one (token, head) vector of 64 (16 B per lane), statistics by 3 xor-shuffles, fp32 math,
-// one bf16 rounding at the store.  RoPE pairs (2j, 2j+1) are lane-local.  Input is read where the fused QKV GEMM
+// one bf16 rounding at the store.  RoPE pairs (2j, 2j+1) are lane-local; the half-split partner (i +- 16) sits two lanes over.  Input is read where the fused QKV GEMM
 // left it ([B,S,3,H,64], any strides); output strides are free as well, so no separate permute kernel exists.
 #include "common.h"
 
@@ -24,7 +28,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
                                                                 const float* __restrict__ bq, const float* __restrict__ wk,
                                                                 const float* __restrict__ bk, const float* __restrict__ rope_cos,
                                                                 const float* __restrict__ rope_sin, int text_len, int B, int H, int S,
-                                                                float eps, float q_out_scale) {
+                                                                float eps, float q_out_scale, int rope_mode) {
     const int64_t nvec = (int64_t)B * S * H;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t vid = gid >> 3;
@@ -52,7 +56,17 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
     float y[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = (x[j] - mean) * rstd * w[c8 * 8 + j] + bb[c8 * 8 + j];
-    if (rope_cos && s >= text_len) {
+    if (rope_cos && rope_mode == 1) {   // half-split pairs (i, i + 16) of each 32-feature half: out = y cos + rotate_half(y) sin
+        const bool on = s >= text_len;   // the partner exchange is executed by every lane of the 8-lane group
+        const float* cp = rope_cos + (int64_t)(on ? s - text_len : 0) * 64 + c8 * 8;
+        const float* sp = rope_sin + (int64_t)(on ? s - text_len : 0) * 64 + c8 * 8;
+        const float sgn = (c8 & 2) ? 1.f : -1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float partner = __shfl_xor(y[j], 2, 64);
+            if (on) y[j] = y[j] * cp[j] + sgn * partner * sp[j];
+        }
+    } else if (rope_cos && s >= text_len) {
         const float* cp = rope_cos + (int64_t)(s - text_len) * 64 + c8 * 8;
         const float* sp = rope_sin + (int64_t)(s - text_len) * 64 + c8 * 8;
 #pragma unroll
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
                                                                 QStride sg_k, QStride si_q, QStride si_k, QStride sd_q, QStride sd_k,
                                                                 const float* __restrict__ wq, const float* __restrict__ wk,
                                                                 const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                                                                int text_len, int B, int H, int S, float eps) {
+                                                                int text_len, int B, int H, int S, float eps, int rope_mode) {
     const int64_t nvec = (int64_t)B * S * H;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t vid = gid >> 3;
@@ -94,7 +108,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
     float g[8], x[8];
     unpack8(*reinterpret_cast<const u32x4_t*>(gp + c8 * 8), g);
     unpack8(*reinterpret_cast<const u32x4_t*>(ip + c8 * 8), x);
-    if (rope_cos && s >= text_len) {  // transpose of the rotation
+    if (rope_cos && rope_mode == 1) {   // transpose of the half-split rotation: dy[d] = g[d] cos[d] -+ g[partner] sin[partner]
+        const bool on = s >= text_len;
+        const int64_t row = (int64_t)(on ? s - text_len : 0) * 64;
+        const float* cp = rope_cos + row + c8 * 8;
+        const float* spp = rope_sin + row + (c8 ^ 2) * 8;
+        const float sgn = (c8 & 2) ? -1.f : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float partner = __shfl_xor(g[j], 2, 64);
+            if (on) g[j] = g[j] * cp[j] + sgn * partner * spp[j];
+        }
+    } else if (rope_cos && s >= text_len) {  // transpose of the rotation
         const float* cp = rope_cos + (int64_t)(s - text_len) * 64 + c8 * 8;
         const float* sp = rope_sin + (int64_t)(s - text_len) * 64 + c8 * 8;
 #pragma unroll
@@ -132,19 +157,21 @@ static inline QStride qmk(const int64_t* st) { QStride t; t.b = st[0]; t.h = st[
 extern "C" {
 
 // q_out = q_out_scale * RoPE(LayerNorm_64(q_in)), k_out = RoPE(LayerNorm_64(k_in)); every tensor is a bf16 [B,H,S,64] view given by element strides
-// {batch, head, token}.  rope_cos/rope_sin: fp32 [S - text_len, 64] (pair-repeated, SURVEY A-2) or NULL.
+// {batch, head, token}.  rope_cos/rope_sin: fp32 [S - text_len, 64] or NULL; rope_mode 0: interleaved pairs (2j, 2j+1), tables
+// pair-repeated (diffusers apply_rotary_emb, SURVEY A-2); rope_mode 1: pairs (i, i+16) inside each 32-feature half, tables = the
+// [cos(y-angles) x2 | cos(x-angles) x2] rows RotaryPositionEmbedding2D builds (vggt/layers/rope.py:103-112,154-188).
 int32_t vgpa_qknorm_rope_fwd(const void* q_in, const void* k_in, void* q_out, void* k_out, const int64_t* qin_strides,
                              const int64_t* kin_strides, const int64_t* qout_strides, const int64_t* kout_strides, const float* wq,
                              const float* bq, const float* wk, const float* bk, const float* rope_cos, const float* rope_sin,
                              int64_t text_len, int64_t B, int64_t H, int64_t S, int64_t head_dim, float eps, float q_out_scale,
-                             hipStream_t stream) {
+                             int32_t rope_mode, hipStream_t stream) {
     if (!q_in || !k_in || !q_out || !k_out || !wq || !bq || !wk || !bk || head_dim != 64 || B <= 0 || H <= 0 || S <= 0) return VGPA_ERR_INVALID;
     if (!qs_ok(qin_strides) || !qs_ok(kin_strides) || !qs_ok(qout_strides) || !qs_ok(kout_strides)) return VGPA_ERR_INVALID;
-    if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
+    if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S || (rope_mode != 0 && rope_mode != 1)) return VGPA_ERR_INVALID;
     const int64_t threads = 2 * B * S * H * 8;
     VGPA_LAUNCH(qknorm_rope_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)q_in,
                        (const bf16_t*)k_in, (bf16_t*)q_out, (bf16_t*)k_out, qmk(qin_strides), qmk(kin_strides), qmk(qout_strides),
-                       qmk(kout_strides), wq, bq, wk, bk, rope_cos, rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps, q_out_scale);
+                       qmk(kout_strides), wq, bq, wk, bk, rope_cos, rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps, q_out_scale, (int)rope_mode);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -154,16 +181,16 @@ int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void*
                              const int64_t* dqout_strides, const int64_t* dkout_strides, const int64_t* qin_strides,
                              const int64_t* kin_strides, const int64_t* dqin_strides, const int64_t* dkin_strides, const float* wq,
                              const float* wk, const float* rope_cos, const float* rope_sin, int64_t text_len, int64_t B, int64_t H,
-                             int64_t S, int64_t head_dim, float eps, hipStream_t stream) {
+                             int64_t S, int64_t head_dim, float eps, int32_t rope_mode, hipStream_t stream) {
     if (!dq_out || !dk_out || !q_in || !k_in || !dq_in || !dk_in || !wq || !wk || head_dim != 64 || B <= 0 || H <= 0 || S <= 0) return VGPA_ERR_INVALID;
     if (!qs_ok(dqout_strides) || !qs_ok(dkout_strides) || !qs_ok(qin_strides) || !qs_ok(kin_strides) || !qs_ok(dqin_strides) || !qs_ok(dkin_strides))
         return VGPA_ERR_INVALID;
-    if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S) return VGPA_ERR_INVALID;
+    if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S || (rope_mode != 0 && rope_mode != 1)) return VGPA_ERR_INVALID;
     const int64_t threads = 2 * B * S * H * 8;
     VGPA_LAUNCH(qknorm_rope_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dq_out,
                        (const bf16_t*)dk_out, (const bf16_t*)q_in, (const bf16_t*)k_in, (bf16_t*)dq_in, (bf16_t*)dk_in, qmk(dqout_strides),
                        qmk(dkout_strides), qmk(qin_strides), qmk(kin_strides), qmk(dqin_strides), qmk(dkin_strides), wq, wk, rope_cos,
-                       rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps);
+                       rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps, (int)rope_mode);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

@@ -717,7 +717,7 @@ class _QKNormAttentionFn(torch.autograd.Function):
     QK-norm (+ optional 3D RoPE on tokens >= text_len) -> flash attention; backward returns dqkv in the same layout."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad):
+    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad, rope_mode=0):
         """o_pad / grad_pad: the attention output / the gradient of qkv are returned as heads of buffers that much wider (the
         LoRA tails of the projections on either side, see LoraExt)."""
         _req(qkv, torch.bfloat16)
@@ -729,16 +729,16 @@ class _QKNormAttentionFn(torch.autograd.Function):
         kn = torch.empty_like(qn)
         _timed("qknorm_rope_fwd", 8.0 * B * H * S * Dh, lambda: _lib.call(
             "vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
-            wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), _stream()), "byte")
+            wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), int(rope_mode), _stream()), "byte")
         o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad)
         ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
-        ctx.meta = (text_len, H, eps, grad_pad)
+        ctx.meta = (text_len, H, eps, grad_pad, int(rope_mode))
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin = ctx.saved_tensors
-        text_len, H, eps, grad_pad = ctx.meta
+        text_len, H, eps, grad_pad, rope_mode = ctx.meta
         B, S, W = qkv.shape
         Dh = W // (3 * H)
         do = do.contiguous()
@@ -755,10 +755,22 @@ class _QKNormAttentionFn(torch.autograd.Function):
         _timed("qknorm_rope_bwd", 12.0 * B * H * S * Dh, lambda: _lib.call(
             "vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
             _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
-            float(eps), _stream()), "byte")
-        return dqkv, None, None, None, None, None, None, None, None, None, None, None
+            float(eps), rope_mode, _stream()), "byte")
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0):
+def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0, rope_mode=0):
+    """rope = (cos, sin) fp32 [S - text_len, 64]; rope_mode 0: interleaved pairs (diffusers' CogVideoX), 1: half-split pairs inside each
+    32-feature half (VGGT's RotaryPositionEmbedding2D, tables from `rope2d_tables`)."""
     cos, sin = (None, None) if rope is None else rope
-    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad)
+    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad, rope_mode)
+
+
+def rope2d_tables(pos, head_dim=64, frequency=100.0):
+    """cos / sin rows [N, head_dim] fp32 of vggt/layers/rope.py:103-112,154-188 for integer positions pos [N, 2] = (y, x): features
+    [0, d/2) rotate with y, [d/2, d) with x; inside a half, feature i and i + d/4 share the angle pos * frequency^(-2i / (d/2))."""
+    half = head_dim // 2
+    inv = 1.0 / (frequency ** (torch.arange(0, half, 2, device=pos.device).float() / half))
+    ang = pos.float()[:, :, None] * inv[None, None, :]                 # [N, 2, half/2]
+    ang = torch.cat([ang, ang], dim=-1).reshape(pos.shape[0], head_dim)  # [y-angles x2 | x-angles x2]
+    return ang.cos().contiguous(), ang.sin().contiguous()
