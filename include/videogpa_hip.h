@@ -166,11 +166,14 @@ int32_t vgpa_attn_bwd_dq_ws(const void* q, const void* k, const void* v, const v
                             void* dq, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                             const int64_t* do_strides, const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,
                             float scale, int32_t split_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+#ifdef VGPA_VARIANTS /* measured-slower experiment (one-kernel backward, dQ by fp32 atomics): exported by variant builds only
+                      * (tools/build_variant.sh); dq_f32 = fp32 [B,H,S,64] contiguous, zeroed by the caller */
 int32_t vgpa_attn_bwd_fused(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
                             float* dq_f32, void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides,
                             const int64_t* v_strides, const int64_t* do_strides, const int64_t* dk_strides,
                             const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
                             vgpa_stream_t stream);
+#endif
 int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq,
                       void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                       const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
@@ -188,6 +191,10 @@ int32_t vgpa_lora_up_add(void* Y, int64_t ldy, const void* T, int64_t ldt, const
                          int64_t N, int64_t rp, int32_t accumulate, vgpa_stream_t stream);
 int32_t vgpa_lora_grad(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M,
                        int64_t P, int64_t Q, vgpa_stream_t stream);
+/* the same product, bit-reproducible: per-row-range partials in the caller's workspace + an ordered merge; G is overwritten */
+size_t vgpa_lora_grad_workspace_bytes(int64_t M, int64_t P, int64_t Q);
+int32_t vgpa_lora_grad_ws(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M,
+                          int64_t P, int64_t Q, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 
 /* ---- optimizer on one flat fp32 buffer of all LoRA parameters: gradient_clip_val=1.0 + torch.optim.AdamW,
  * train/CogVideoX-5B/03_train.py:208-213,266.  norm_out[0] = grad_scale * ||grad||_2. */

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     src = open(os.path.join(ROOT, "include", "videogpa_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef VGPA_VARIANTS.*?#endif", "", src, flags=re.S)      # entry points of variant builds (tools/build_variant.sh) only
     return set(re.findall(r"\b(vgpa_[a-z0-9_]+)\s*\(", src))
 
 

@@ -273,6 +273,20 @@ def test_lora_kernels_raw(ops, M, K, r, n):
     assert (gr2.double().cpu() - ref2).abs().max().item() < 2e-3 * ref2.abs().max().item() + 1e-4
 
 
+def test_lora_grad_is_bit_reproducible_at_the_headline_shape(ops):
+    """The token-contracted adapter gradients (dB = s dy^T T, dA = dT^T x at M = 2 x 17 776 rows) go through per-row-range partials and
+    an ordered merge (vgpa_lora_grad_ws): repeated launches must agree bit for bit (the atomics form did not), and with fp64."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    M = 2 * 17776
+    dy = torch.randn(M, 3072, generator=g, device="cuda").to(torch.bfloat16)
+    t = torch.randn(M, 192, generator=g, device="cuda").to(torch.bfloat16)
+    a = [ops.lora_grad(dy, t[:, 64:128], 2.0) for _ in range(3)]
+    b = [ops.lora_grad(t, dy) for _ in range(3)]
+    assert all(torch.equal(a[0], x) for x in a[1:]) and all(torch.equal(b[0], x) for x in b[1:])
+    ref = 2.0 * (dy[:, :256].double().t() @ t[:, 64:128].double())
+    assert (a[0][:256].double() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
 def test_linear_lora_function_vs_torch(ops):
     g = torch.Generator().manual_seed(5)
     Bt, S, K, Dn, r = 2, 77, 128, 128, 8
@@ -307,7 +321,11 @@ def test_linear_lora_function_vs_torch(ops):
 
 
 def test_attention_bwd_fused_variant_matches_split(ops):
-    """The optional one-kernel backward (dQ through fp32 atomics) against the default split kernels."""
+    """The optional one-kernel backward (dQ through fp32 atomics) against the default split kernels.  The kernel is a measured-slower
+    experiment and lives in variant builds only (tools/build_variant.sh, VGPA_LIB=...): skipped on the product library."""
+    from videogpa_amd import _lib
+    if not _lib.has("vgpa_attn_bwd_fused"):
+        pytest.skip("variant build only")
     g = torch.Generator().manual_seed(123)
     B, H, S = 1, 2, 700
     q, k, v, do = (torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16).cuda() for _ in range(4))

@@ -51,11 +51,12 @@ SIGNATURES = {
     "vgpa_attn_bwd_split_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn_bwd_dkv_ws": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_dq_ws": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
-    "vgpa_attn_bwd_fused": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
     "vgpa_lora_down": (I32, [P, I64, P, P, I64, I64, I64, I64, P]),
     "vgpa_lora_up_add": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, I32, P]),
     "vgpa_lora_grad": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P]),
+    "vgpa_lora_grad_workspace_bytes": (SZ, [I64, I64, I64]),
+    "vgpa_lora_grad_ws": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P, SZ, P]),
     "vgpa_project_points_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_project_points": (I32, [P, P, P, F32, P, P, P, I32, I64, I64, I64, I64, P, P, P, SZ, P]),
     "vgpa_conf_threshold_workspace_bytes": (SZ, []),
@@ -71,6 +72,11 @@ SIGNATURES = {
     "vgpa_frame_mse": (I32, [P, I32, I32, I32, P, I32, I32, I32, I64, I64, I64, I64, P, P, SZ, P]),
     "vgpa_motion_score": (I32, [P, I32, I64, P, P]),
     "vgpa_epipolar_sampson": (I32, [P, P, P, I64, P, P, P]),
+}
+
+# exported only by variant builds (tools/build_variant.sh -> VGPA_LIB=...): measured-slower experiments kept out of the product library
+OPTIONAL_SIGNATURES = {
+    "vgpa_attn_bwd_fused": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
 }
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "workspace too small"}
@@ -89,6 +95,11 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the .so is stale: fail loudly
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in OPTIONAL_SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = lib
     return _lib
 
@@ -111,3 +122,8 @@ def call(name, *args):
 
 def query(name, *args):
     return getattr(load(), name)(*args)
+
+
+def has(name):
+    """Is an optional (variant-build) entry point present in the loaded library?"""
+    return hasattr(load(), name)

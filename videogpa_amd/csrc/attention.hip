@@ -51,6 +51,7 @@
 #endif
 #define PSUM_TRIGGER 1024.0f   // a half-lane tile sum above this (or inf/NaN) means some score outgrew the running max by > ~2^5
 
+#ifdef VGPA_VARIANTS   // the first-generation three-block forward (phase-stamp diagnostics): variant builds only
 // QB = 32-row query blocks per wave.
 // Softmax bookkeeping is kept off the VALU (the kernel is VALU-issue bound at head_dim 64):
 //  * Q arrives pre-scaled by scale*log2(e) (vgpa_qknorm_rope_fwd's q_out_scale; one rounding), and -m (running max)
@@ -268,6 +269,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && QB == 1) ? 4 : 2) void attn_fw
         }
     }
 }
+
+#endif  // VGPA_VARIANTS
 
 // =====================================================================================================
 // Forward, software-pipelined (what vgpa_attn_fwd launches; the kernel above is kept as -DFWD_V1 for the phase-stamp
@@ -602,6 +605,7 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
     if (lane == 0) LSE2[(int64_t)bh * S + q] = M + __builtin_amdgcn_logf(L);
 }
 
+#ifdef VGPA_VARIANTS   // measured-slower experiment: variant builds only
 // =====================================================================================================
 // Forward, PING-PONG (selected by VGPA_ATTN_FWD=pp).  The forward is VALU-issue bound at head_dim 64: per 64 x 64 score tile a
 // wave has ~1150 matrix-pipe cycles (36 MFMAs) and ~1300-1450 VALU cycles (64 exp, 64 adds, 32 packs per lane), and inside ONE wave
@@ -935,6 +939,8 @@ __global__ __launch_bounds__(64 * PP_NW, 2) void attn_fwd_pp_kernel(const bf16_t
         }
     }
 }
+
+#endif  // VGPA_VARIANTS
 
 // =====================================================================================================
 // delta[b,h,q] = sum_d dO[q,d] * O[q,d]
@@ -1338,6 +1344,7 @@ __global__ __launch_bounds__(256) void attn_dkv_merge_kernel(const float* __rest
     dV[(size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)key * sdv.s + lane] = f32_to_bf16(av);
 }
 
+#ifdef VGPA_VARIANTS   // measured-slower experiment: variant builds only
 // =====================================================================================================
 // Backward, fused:  dK, dV AND dQ in one sweep (5 matrix products per score block instead of the 7 of the split
 // dK/dV + dQ pair).  Workgroup = 8 waves = 256 keys; wave w keeps dK^T, dV^T of its 32 keys in registers exactly as
@@ -1551,6 +1558,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
     }
 }
 
+#endif  // VGPA_VARIANTS
+
 #ifndef DQ_QB
 #define DQ_QB 2    // query blocks (of 32 rows) per wave in the dQ kernel
 #endif
@@ -1594,6 +1603,7 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
     if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides)) return VGPA_ERR_INVALID;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
+#ifdef VGPA_VARIANTS
     static const int use_pp = [] { const char* e = getenv("VGPA_ATTN_FWD"); return (e && e[0] == 'p' && e[1] == 'p') ? 1 : 0; }();
     if (use_pp) {   // ping-pong kernel: 512 query rows per workgroup, no tail split
         const int n_qt_pp = (int)((S + 64 * PP_NW - 1) / (64 * PP_NW));
@@ -1604,6 +1614,7 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
         VGPA_CHECK_LAUNCH();
         return VGPA_OK;
     }
+#endif
     const int n_qt = (int)((S + FWD_QB * FWD_NW * 32 - 1) / (FWD_QB * FWD_NW * 32));
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
@@ -1635,10 +1646,14 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
         return VGPA_OK;
     }
 #endif
+#ifdef VGPA_VARIANTS
     VGPA_LAUNCH((attn_fwd_kernel<FWD_QB, FWD_NW>), dim3((unsigned)nblk), dim3(64 * FWD_NW), FWD_DYN_LDS, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                 (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
+#else
+    return VGPA_ERR_INVALID;   // other blockings exist in variant builds only
+#endif
 }
 
 int32_t vgpa_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
@@ -1797,6 +1812,7 @@ int32_t vgpa_attn_bwd_dq_ws(const void* q, const void* k, const void* v, const v
                             split_mode, workspace, ws_bytes, stream);
 }
 
+#ifdef VGPA_VARIANTS
 // fused backward: dK, dV (bf16 views) and dQ accumulated into dq_f32 -- fp32 [B,H,S,64] contiguous, ZEROED BY THE CALLER.
 int32_t vgpa_attn_bwd_fused(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
                             float* dq_f32, void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides,
@@ -1813,6 +1829,8 @@ int32_t vgpa_attn_bwd_fused(const void* q, const void* k, const void* v, const v
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
+
+#endif  // VGPA_VARIANTS
 
 // the whole backward (delta -> dK/dV -> dQ) with a caller-provided workspace for delta
 int32_t vgpa_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(bf16_t* __restrict__ Y
 // =====================================================================================================
 __global__ __launch_bounds__(256) void lora_grad_kernel(const bf16_t* __restrict__ U, int64_t ldu, const bf16_t* __restrict__ V, int64_t ldv,
                                                           float* __restrict__ G, int64_t ldg, float s, int64_t M, int P, int Q,
-                                                          int64_t rows_per_split, int n_qt) {
+                                                          int64_t rows_per_split, int n_qt, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];   // U[2], V[2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int pb = wave & 1, qb = wave >> 1;
@@ -220,12 +220,27 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const bf16_t* __restrict
     }
     const int q = q0 + qb * 32 + (lane & 31);
     if (q < Q) {
+        // deterministic form: this row range's partial goes to its own [P, Q] slab, lora_grad_merge_kernel adds the slabs in order
+        float* slab = part ? part + (int64_t)blockIdx.y * P * Q : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = p0 + pb * 32 + acc_row(r, hi);
-            if (p < P) atomicAdd(&G[(int64_t)p * ldg + q], s * acc[r]);
+            if (p < P) {
+                if (slab) slab[(int64_t)p * Q + q] = acc[r];
+                else atomicAdd(&G[(int64_t)p * ldg + q], s * acc[r]);
+            }
         }
     }
+}
+
+// G[p, q] = s * sum over the row-range slabs, in slab order (fixed summation order: bit-reproducible)
+__global__ __launch_bounds__(256) void lora_grad_merge_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ G, int64_t ldg, float s,
+                                                                int P, int Q) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)P * Q) return;
+    float a = 0.f;
+    for (int c = 0; c < nsplit; ++c) a += part[(int64_t)c * P * Q + i];
+    G[(i / Q) * ldg + (i % Q)] = s * a;
 }
 
 static inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -270,20 +285,55 @@ int32_t vgpa_lora_up_add(void* Y, int64_t ldy, const void* T, int64_t ldt, const
     return VGPA_OK;
 }
 
-// G[P,Q] (fp32, row stride ldg, caller-zeroed) += s * U[M,P]^T V[M,Q]   (bf16 operands, P, Q multiples of 8)
+static void lora_grad_plan(int64_t M, int64_t P, int64_t Q, int* n_pt, int* n_qt, int64_t* rows, int64_t* splits) {
+    *n_pt = (int)((P + 63) / 64);
+    *n_qt = (int)((Q + 63) / 64);
+    int64_t sp = 1024 / ((int64_t)*n_pt * *n_qt);
+    if (sp < 1) sp = 1;
+    const int64_t max_splits = (M + 255) / 256;
+    if (sp > max_splits) sp = max_splits;
+    int64_t r = (M + sp - 1) / sp;
+    r = (r + 63) / 64 * 64;
+    *rows = r;
+    *splits = (M + r - 1) / r;
+}
+
+// G[P,Q] (fp32, row stride ldg, caller-zeroed) += s * U[M,P]^T V[M,Q]   (bf16 operands, P, Q multiples of 8); fp32 atomics: the
+// result is reproducible only to rounding.  vgpa_lora_grad_ws is the deterministic form.
 int32_t vgpa_lora_grad(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M, int64_t P, int64_t Q,
                        hipStream_t stream) {
     if (!U || !V || !G || M <= 0 || P <= 0 || Q <= 0 || P % 8 || Q % 8 || ldu % 8 || ldv % 8 || !a16(U) || !a16(V)) return VGPA_ERR_INVALID;
-    const int n_pt = (int)((P + 63) / 64), n_qt = (int)((Q + 63) / 64);
-    int64_t splits = 1024 / ((int64_t)n_pt * n_qt);
-    if (splits < 1) splits = 1;
-    const int64_t max_splits = (M + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    int64_t rows = (M + splits - 1) / splits;
-    rows = (rows + 63) / 64 * 64;
-    splits = (M + rows - 1) / rows;
+    int n_pt, n_qt;
+    int64_t rows, splits;
+    lora_grad_plan(M, P, Q, &n_pt, &n_qt, &rows, &splits);
     VGPA_LAUNCH(lora_grad_kernel, dim3((unsigned)(n_pt * n_qt), (unsigned)splits), dim3(256), 0, stream, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
-                G, ldg, s, M, (int)P, (int)Q, rows, n_qt);
+                G, ldg, s, M, (int)P, (int)Q, rows, n_qt, (float*)nullptr);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// The same product, bit-reproducible: every row range writes its partial [P, Q] into the caller's workspace
+// (>= vgpa_lora_grad_workspace_bytes) and a merge kernel adds the partials in a fixed order.  G is overwritten (no zeroing needed).
+size_t vgpa_lora_grad_workspace_bytes(int64_t M, int64_t P, int64_t Q) {
+    if (M <= 0 || P <= 0 || Q <= 0) return 0;
+    int n_pt, n_qt;
+    int64_t rows, splits;
+    lora_grad_plan(M, P, Q, &n_pt, &n_qt, &rows, &splits);
+    return (size_t)splits * (size_t)P * (size_t)Q * sizeof(float);
+}
+int32_t vgpa_lora_grad_ws(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M, int64_t P,
+                          int64_t Q, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!U || !V || !G || !workspace || M <= 0 || P <= 0 || Q <= 0 || P % 8 || Q % 8 || ldu % 8 || ldv % 8 || !a16(U) || !a16(V) || !a16(workspace))
+        return VGPA_ERR_INVALID;
+    int n_pt, n_qt;
+    int64_t rows, splits;
+    lora_grad_plan(M, P, Q, &n_pt, &n_qt, &rows, &splits);
+    if (ws_bytes < (size_t)splits * (size_t)P * (size_t)Q * sizeof(float)) return VGPA_ERR_WORKSPACE;
+    VGPA_LAUNCH(lora_grad_kernel, dim3((unsigned)(n_pt * n_qt), (unsigned)splits), dim3(256), 0, stream, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
+                G, ldg, s, M, (int)P, (int)Q, rows, n_qt, (float*)workspace);
+    VGPA_CHECK_LAUNCH();
+    VGPA_LAUNCH(lora_grad_merge_kernel, dim3((unsigned)((P * Q + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, (int)splits, G, ldg, s,
+                (int)P, (int)Q);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

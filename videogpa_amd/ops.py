@@ -399,9 +399,11 @@ def lora_grad(u, v, s=1.0):
     """fp32 G[P,Q] = s * u[M,P]^T @ v[M,Q] (contraction over tokens)."""
     M, P = u.shape
     Q = v.shape[1]
-    g = torch.zeros(P, Q, dtype=torch.float32, device=u.device)
-    _timed("lora_grad_kernel", 2.0 * M * (P + Q), lambda: _lib.call("vgpa_lora_grad", u, u.stride(0), v, v.stride(0), g, Q, float(s), M, P, Q, _stream()),
-           "byte")
+    g = torch.empty(P, Q, dtype=torch.float32, device=u.device)
+    ws_bytes = _lib.query("vgpa_lora_grad_workspace_bytes", M, P, Q)       # per-row-range partials + ordered merge: bit-reproducible
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device)
+    _timed("lora_grad_kernel", 2.0 * M * (P + Q), lambda: _lib.call("vgpa_lora_grad_ws", u, u.stride(0), v, v.stride(0), g, Q, float(s), M, P, Q,
+                                                                     ws, ws_bytes, _stream()), "byte")
     return g
 
 
