@@ -196,6 +196,15 @@ size_t vgpa_lora_grad_workspace_bytes(int64_t M, int64_t P, int64_t Q);
 int32_t vgpa_lora_grad_ws(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M,
                           int64_t P, int64_t Q, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 
+/* ---- feed-forward GEMM with fused epilogue: diffusers FeedForward(activation_fn="gelu-approximate") inside CogVideoXBlock
+ * (the reference reaches it through diffusers cogvideox_transformer_3d.py; train/CogVideoX-5B/utils.py:255-289 drives the blocks).
+ * C[M, N] = epi(X[M, K] W[N, K]^T + bias[N]), bf16 in / fp32 accumulate / bf16 out; N % 128 == 0, K % 64 == 0, ld* in elements.
+ *   epilogue 0: identity   1: gelu_tanh (aux != NULL: the bf16 pre-activation is also stored to aux)   2: C = acc * gelu_tanh'(aux) */
+#ifdef VGPA_VARIANTS   /* probe: profiles/r03_gemm_probe.txt */
+int32_t vgpa_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc, void* aux,
+                       int64_t ldaux, int32_t M, int32_t N, int32_t K, int32_t epilogue, vgpa_stream_t stream);
+#endif
+
 /* ---- optimizer on one flat fp32 buffer of all LoRA parameters: gradient_clip_val=1.0 + torch.optim.AdamW,
  * train/CogVideoX-5B/03_train.py:208-213,266.  norm_out[0] = grad_scale * ||grad||_2. */
 size_t vgpa_grad_norm_workspace_bytes(void);

@@ -10,6 +10,8 @@ python -m videogpa_amd.build >/dev/null
 mkdir -p var /tmp/vobj_$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function \
   -I include -I videogpa_amd/csrc -DVGPA_VARIANTS "$@" -c videogpa_amd/csrc/attention.hip -o /tmp/vobj_$name/attention.o
-objs=$(ls videogpa_amd/csrc/_obj/*.o | grep -v attention.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/vobj_$name/attention.o -o var/lib_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function \
+  -I include -I videogpa_amd/csrc -DVGPA_VARIANTS "$@" -c videogpa_amd/csrc/gemm_w1.hip -o /tmp/vobj_$name/gemm_w1.o
+objs=$(ls videogpa_amd/csrc/_obj/*.o | grep -v "/attention.o\|/gemm_w1.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/vobj_$name/attention.o /tmp/vobj_$name/gemm_w1.o -o var/lib_$name.so
 echo "built var/lib_$name.so"

@@ -632,6 +632,82 @@ class FwdLoop:
         return em.text() + "\n"
 
 
+# --------------------------------------------------------------------------------------------------------------------- GEMM loop
+class GemmLoop:
+    """C^T tile = W A^T for a 256 (M) x 128 (N) output tile, operands both K-contiguous (x [M, K], W [N, K]: y = x W^T), BK = 64 per
+       stage, 4 waves as 2 (M) x 2 (N): a wave owns 128 x 64 of the tile = 2 (n) x 4 (m) accumulator blocks, D[n][m] (column m on the
+       lanes, so a lane ends up with runs of 4 consecutive n = 8-byte pieces of a C row).
+       LDS stage (48 KiB, ring of 3): A panel = 4 sub-tiles of [64 rows][64 k] at +0, W panel = 2 sub-tiles at +32768, every sub-tile
+       in the attn_w1.h image; each wave brings 8 pieces of A sub-tile `wave` and 4 pieces of W sub-tile wave/2 per stage.
+       register map   a[0:127] acc[ni][mi]   a[128:175] fragment ring: 2 sets x (W n0 n1, A m0..m3)
+                      v[0:11] LDS-DMA source offsets (8 A pieces, 4 W pieces; + 128 bytes per stage)
+                      v[12:35] lane read offsets [stage][A ks0..3, W ks0..3] (wave's panel offset and the stage base folded in)"""
+
+    def frag(self, setno, i):          # i: 0,1 = W n-block; 2..5 = A m-block
+        return 128 + 24 * setno + 4 * i
+
+    def issue_set(self, em, stage, ks, setno, tag):
+        for i in range(6):
+            isW = i < 2
+            blk = i if isW else i - 2                     # 32-row block inside the wave's panel
+            base = 12 + 8 * stage + (4 if isW else 0) + ks
+            em.ds(f"ds_read_b128 {ar(self.frag(setno, i), 4)}, v{base} offset:{4096 * blk}", tag)
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT = "%0", "%1"
+        RA, RW, WBA, WBW, NITER = "%[ra]", "%[rw]", "%[wba]", "%[wbw]", "%[niter]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        for i in range(128):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        em.raw("L_w1gemm_loop_%=:")
+        for st in range(3):
+            # stage `st` landed for every wave (this wave's 12 pieces of the NEXT stage may still fly); everyone is past stage st-1
+            em.raw("s_waitcnt vmcnt(12)")
+            em.raw("s_barrier")
+            nxt = (st + 2) % 3
+            dma = []
+            for k in range(12):
+                isW = k >= 8
+                dst = nxt * 49152 + (32768 if isW else 0) + (k - 8 if isW else k) * 1024
+                dma.append([f"s_add_u32 m0, {WBW if isW else WBA}, {dst}"])
+                dma.append([f"buffer_load_dwordx4 v{k}, {RW if isW else RA}, 0 offen lds", f"v_add_u32 v{k}, 128, v{k}"])
+            self.issue_set(em, st, 0, 0, ("s", 0))
+            slot = 0
+            for ks in range(4):
+                setno = ks & 1
+                if ks + 1 < 4:
+                    pass
+                em.wait_tag(("s", ks))
+                mf = []
+                for ni in range(2):
+                    for mi in range(4):
+                        d = ar((ni * 4 + mi) * 16, 16)
+                        mf.append(f"{MFMA} {d}, {ar(self.frag(setno, ni), 4)}, {ar(self.frag(setno, 2 + mi), 4)}, {d}")
+                for i, text in enumerate(mf):
+                    em.raw(text)
+                    if i == 1 and ks + 1 < 4:      # the next k-step's fragments go to the other register set (its readers are done)
+                        self.issue_set(em, st, ks + 1, setno ^ 1, ("s", ks + 1))
+                    if slot < len(dma):
+                        for t in dma[slot]:
+                            em.raw(t)
+                        slot += 1
+            assert slot == len(dma)
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if st < 2:
+                em.raw("s_cbranch_scc1 L_w1gemm_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1gemm_loop_%=")
+        em.raw("L_w1gemm_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 def clobbers(ranges, aranges=()):
     regs = []
     for lo, hi in ranges:
@@ -646,6 +722,8 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_dq_clobbers.inc": lambda: clobbers([(0, 159)], [(128, 151)]),
            "w1_dkv_loop.inc": lambda: DkvLoop().generate(),
            "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)]),
+           "w1_gemm_loop.inc": lambda: GemmLoop().generate(),
+           "w1_gemm_clobbers.inc": lambda: clobbers([], [(128, 175)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),
            "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 127)])}
 

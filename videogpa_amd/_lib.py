@@ -77,6 +77,7 @@ SIGNATURES = {
 # exported only by variant builds (tools/build_variant.sh -> VGPA_LIB=...): measured-slower experiments kept out of the product library
 OPTIONAL_SIGNATURES = {
     "vgpa_attn_bwd_fused": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
+    "vgpa_gemm_bf16": (I32, [P, I64, P, I64, P, P, I64, P, I64, I32, I32, I32, I32, P]),
 }
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "workspace too small"}
