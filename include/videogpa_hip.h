@@ -205,6 +205,14 @@ int32_t vgpa_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, c
                        int64_t ldaux, int32_t M, int32_t N, int32_t K, int32_t epilogue, vgpa_stream_t stream);
 #endif
 
+/* ---- VGGT input preprocessing: utils/model_utils.py:16-85 preprocess_images_from_numpy (PIL bicubic resize to width 518 /
+ * longer side 518, ToTensor, centre crop or white pad).  frames uint8 [T, H, W, 3] -> out float32 [T, 3, out_h, out_w].
+ * mode 0 = "crop", 1 = "pad".  vgpa_preprocess_shape is host arithmetic only (:36-48, :54-71). */
+int32_t vgpa_preprocess_shape(int32_t H, int32_t W, int32_t mode, int32_t* out_h, int32_t* out_w);
+size_t vgpa_preprocess_workspace_bytes(int32_t T, int32_t H, int32_t W, int32_t mode);
+int32_t vgpa_preprocess_frames(const void* frames, int32_t T, int32_t H, int32_t W, int32_t mode, float* out, void* workspace,
+                               size_t ws_bytes, vgpa_stream_t stream);
+
 /* ---- optimizer on one flat fp32 buffer of all LoRA parameters: gradient_clip_val=1.0 + torch.optim.AdamW,
  * train/CogVideoX-5B/03_train.py:208-213,266.  norm_out[0] = grad_scale * ||grad||_2. */
 size_t vgpa_grad_norm_workspace_bytes(void);

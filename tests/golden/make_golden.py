@@ -385,6 +385,54 @@ def golden_vggt_attention():
     print("vggt_attention.pt:", len(out["attention"]), "attention cases + 1 frame/global block pair")
 
 
+def golden_preprocess():
+    """tests/golden/preprocess.npz: the VGGT input preprocessing, utils/model_utils.py:16-85.  That module imports torchvision (not
+    installed here), so it cannot be imported as a whole; its one non-trivial step is PIL's bicubic `Image.resize` (:51), which IS
+    installed (Pillow 12.2.0) and is called here for real, exactly as :35,:51 call it.  Around it the fixture records the function's
+    own arithmetic: sizes from :36-48, ToTensor's /255 (:52) left to the consumer (the arrays are stored as uint8 = the tensor
+    times 255, exact for the white pad value 1.0 too), centre crop :54-56, white pad :58-71."""
+    from PIL import Image
+    rng = np.random.default_rng(518)
+    out = {}
+    cases = [("land_crop", 1, 90, 256, "crop"), ("port_crop", 1, 400, 300, "crop"), ("land_pad", 2, 90, 256, "pad"), ("port_pad", 1, 256, 90, "pad"),
+             ("same_crop", 1, 98, 518, "crop"), ("up_crop", 2, 37, 53, "crop"), ("half_even_dn", 1, 175, 518, "crop"), ("half_even_up", 1, 189, 518, "pad")]
+    for name, T, H, W, mode in cases:
+        yy, xx = np.mgrid[0:H, 0:W]
+        frames = []
+        for t in range(T):   # smooth structure + hard edges + noise, so that ringing, clipping at 0 / 255 and rounding are all exercised
+            base = 127 + 120 * np.sin(xx / (3.0 + t) + yy / 7.0)[..., None] * np.array([1.0, -1.0, 0.5])
+            base = base + 90 * ((xx // 16 + yy // 16) % 2)[..., None] - 45
+            base = base + rng.normal(0, 25, (H, W, 3))
+            frames.append(np.clip(base, 0, 255).astype(np.uint8))
+        frames = np.stack(frames)
+        res = []
+        for f in frames:
+            img = Image.fromarray(f, "RGB")
+            width, height = img.size
+            if mode == "pad":
+                if width >= height:
+                    nw = 518; nh = round(height * (nw / width) / 14) * 14
+                else:
+                    nh = 518; nw = round(width * (nh / height) / 14) * 14
+            else:
+                nw = 518; nh = round(height * (nw / width) / 14) * 14
+            r = np.asarray(img.resize((nw, nh), Image.Resampling.BICUBIC))
+            if mode == "crop" and nh > 518:
+                s0 = (nh - 518) // 2
+                r = r[s0:s0 + 518]
+            if mode == "pad":
+                hp, wp = 518 - r.shape[0], 518 - r.shape[1]
+                if hp > 0 or wp > 0:
+                    t_ = torch.nn.functional.pad(torch.from_numpy(r.copy()).permute(2, 0, 1), (wp // 2, wp - wp // 2, hp // 2, hp - hp // 2), mode="constant", value=255)
+                    r = t_.permute(1, 2, 0).numpy()
+            res.append(r.transpose(2, 0, 1))
+        out[name + "__frames"] = frames
+        out[name + "__expect_u8"] = np.stack(res)
+        out[name + "__mode"] = np.array(mode)
+    np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
+    print("preprocess.npz", {k: v.shape for k, v in out.items() if k.endswith("expect_u8")})
+
+
 def golden_adapter_config_keys():
     """Key set PEFT wrote for the released adapters (checkpoints/VideoGPA-T2V-lora/adapter_config.json)."""
     cfg = json.load(open(os.path.join(REF, "checkpoints/VideoGPA-T2V-lora/adapter_config.json")))
@@ -398,3 +446,4 @@ if __name__ == "__main__":
     golden_scorer()
     golden_scorer2()
     golden_vggt_attention()
+    golden_preprocess()

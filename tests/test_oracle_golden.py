@@ -3,6 +3,8 @@ train/loss.py, train/dataset.py, utils/projection_utils.py, metrics/consistency_
 import json
 import os
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -162,3 +164,24 @@ def test_vggt_frame_global_block_pair_oracle_matches_reference(golden_dir):
                 assert abs(p[k].grad.norm().item() / g.item() - 1) < 1e-4, k
             else:
                 assert (p[k].grad - g).abs().max().item() <= 5e-5 * g.abs().max().item() + 2e-6, k
+
+
+def test_preprocess_oracle_matches_pil_fixture(golden_dir):
+    """oracle/preprocess.py (Pillow's 8-bit bicubic resample restated + utils/model_utils.py:36-71) against the fixture made by
+    calling PIL itself: bit-exact, every case (down / up scaling, crop, pad, unchanged axis, both round-half-to-even directions)."""
+    import numpy as np
+    from oracle import preprocess as pp
+    z = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    names = sorted({k.split("__")[0] for k in z.files})
+    assert len(names) == 8
+    for n in names:
+        frames, want, mode = z[n + "__frames"], z[n + "__expect_u8"], str(z[n + "__mode"])
+        got = pp.preprocess_u8(frames, mode)
+        assert got.shape == want.shape and np.array_equal(got, want), n
+        f = pp.preprocess_images_from_numpy(frames, mode)
+        assert f.shape == (1,) + want.shape and f.dtype == np.float32 and f.max() <= 1.0
+    assert pp.output_size(175, 518, "crop") == (518, 168) and pp.output_size(189, 518, "crop") == (518, 196)   # 12.5 -> 12, 13.5 -> 14
+    with pytest.raises(ValueError):
+        pp.preprocess_u8(np.zeros((2, 8, 8), np.uint8))
+    with pytest.raises(ValueError):
+        pp.preprocess_u8(np.zeros((1, 8, 8, 3), np.uint8), "stretch")

@@ -57,6 +57,9 @@ SIGNATURES = {
     "vgpa_lora_grad": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P]),
     "vgpa_lora_grad_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_lora_grad_ws": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P, SZ, P]),
+    "vgpa_preprocess_shape": (I32, [I32, I32, I32, P, P]),
+    "vgpa_preprocess_workspace_bytes": (SZ, [I32, I32, I32, I32]),
+    "vgpa_preprocess_frames": (I32, [P, I32, I32, I32, I32, P, P, SZ, P]),
     "vgpa_project_points_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_project_points": (I32, [P, P, P, F32, P, P, P, I32, I64, I64, I64, I64, P, P, P, SZ, P]),
     "vgpa_conf_threshold_workspace_bytes": (SZ, []),

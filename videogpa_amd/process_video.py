@@ -24,9 +24,13 @@ from . import scorer
 
 
 class VideoProcessor:
-    def __init__(self, metrics, model_name=None, device=None, backbone=None, backbone_fn=None, frame_sampler=None):
+    def __init__(self, metrics, model_name=None, device=None, backbone=None, backbone_fn=None, frame_sampler=None, vggt_model=None):
         """First four arguments as the reference's (pipelines/process_video.py:17-29).  Where the reference loads VGGT-1B / DA3 weights
-        itself, this class takes `backbone_fn` (and `frame_sampler` for paths): third-party networks and video decoding stay the caller's."""
+        itself, this class takes `backbone_fn` (and `frame_sampler` for paths): third-party networks and video decoding stay the caller's.
+        `vggt_model(images [1,T,3,h,518]) -> predictions` is the bare VGGT network: with it the wrapper of utils/model_utils.py:89-122
+        (device preprocessing in front, batch squeeze and pose decoding behind) runs here instead of inside `backbone_fn`."""
+        if vggt_model is not None and backbone_fn is None:
+            backbone_fn = lambda frames: self._run_vggt(vggt_model, frames)
         self.device = device or "cuda"
         self.metrics = metrics
         self.backbone = self._resolve_backbone(backbone, model_name)
@@ -62,6 +66,18 @@ class VideoProcessor:
             raise RuntimeError("VideoProcessor needs frame_sampler(video_path, n_frames) -> uint8 [T,H,W,3] (video decoding is host I/O; "
                                "or pass the frame array itself instead of a path)")
         return self.frame_sampler(video_path, num_frames)
+
+    def _run_vggt(self, model, frames):
+        """utils/model_utils.py:89-122 around the external network: preprocess on the device (:98), forward, drop the batch axis (:111-116)"""
+        from .model_utils import prepare_inputs
+        images = prepare_inputs(np.asarray(frames) if not torch.is_tensor(frames) else frames, device=self.device)
+        with torch.no_grad():
+            preds = dict(model(images))
+        preds["images"] = images
+        preds = {k: (v.squeeze(0) if torch.is_tensor(v) and v.ndim > 0 and v.shape[0] == 1 else v) for k, v in preds.items()}
+        if "world_points" in preds:       # :116-117
+            preds["world_points_from_depth"] = preds["world_points"]
+        return preds
 
     def _process_vggt(self, frames, thresholds):
         preds = dict(self.backbone_fn(frames))
