@@ -205,6 +205,18 @@ int32_t vgpa_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, c
                        int64_t ldaux, int32_t M, int32_t N, int32_t K, int32_t epilogue, vgpa_stream_t stream);
 #endif
 
+/* ---- head_dim-128 attention with separate query / key lengths: the self- and cross-attention of the Wan2.2-TI2V-5B denoiser
+ * (train/Wan2.2-TI2V-5B/03_train.py:150-163; WanModel comes from the un-vendored Wan2.2 checkout: 24 heads x 128, text length 512).
+ * q, o, d_o, dq: [B, H, Sq, 128] views; k, v, dk, dv: [B, H, Skv, 128] views; *_strides = element strides {batch, head, token},
+ * last dim contiguous.  lse2 [B, H, Sq] fp32 = log2-domain log-sum-exp written by the forward.  delta: fp32 scratch [B*H*Sq]. */
+int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
+                         const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
+                         vgpa_stream_t stream);
+int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
+                         void* dv, float* delta, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                         const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                         const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, vgpa_stream_t stream);
+
 /* ---- VGGT input preprocessing: utils/model_utils.py:16-85 preprocess_images_from_numpy (PIL bicubic resize to width 518 /
  * longer side 518, ToTensor, centre crop or white pad).  frames uint8 [T, H, W, 3] -> out float32 [T, 3, out_h, out_w].
  * mode 0 = "crop", 1 = "pad".  vgpa_preprocess_shape is host arithmetic only (:36-48, :54-71). */

@@ -1,0 +1,396 @@
+// Attention for head_dim 128 with separate query / key lengths: the two attention shapes of the Wan2.2-TI2V-5B denoiser
+// (train/Wan2.2-TI2V-5B/03_train.py:150-163 builds it; self-attention 24 heads x 128 over the video tokens, cross-attention of the
+// video tokens over the 512 text tokens), forward and backward.  Same mathematics and operand conventions as attention.hip
+// (softmax in the exp2 domain, fp32 statistics, lse2 = m + log2(l) kept for the backward, delta = rowsum(dO o O)), first version of
+// the blocking: 4 waves x 32 stationary rows per workgroup, the streamed operand as [64 x 128] tiles through registers into a
+// double-buffered padded LDS image (pitch 136: the 16-byte row-fragment reads are conflict-free), compiler-scheduled.
+//   forward :  S^T = K Q^T (q on the lanes) -> online softmax per lane -> O^T += V^T P^T
+//   dQ      :  dQ^T += K^T dS^T,  dS^T = P^T o (dP^T - delta),  dP^T = V dO^T
+//   dK, dV  :  key on the lanes:  S = Q K^T,  dV^T += dO^T P,  dK^T += Q^T dS          (statistics per row from an LDS tile)
+// Rows past the end of a ragged tile read as zeros through the buffer descriptor; keys past Skv are masked in the forward only
+// (in the backward their K / V rows are zero or their results are not stored).
+#include "mfma_tiles.h"
+
+#define D128 128
+#define P128 136
+#define T128 (64 * P128)   // elements of one [64 x 128] LDS tile
+
+__device__ __forceinline__ rsrc_t rsrc128(const bf16_t* base /* uniform */, uint32_t row_stride, int S) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, ((uint32_t)(S - 1) * row_stride + (uint32_t)D128) * 2u, 0x00020000);
+}
+// 256 threads x 4 chunks of 16 B: chunk c = tid + 256 j -> row c >> 4, column chunk c & 15.  The whole offset rides in the VGPR:
+// the descriptor's range check does not see the scalar offset.
+__device__ __forceinline__ void tile128_load(rsrc_t rs, uint32_t row_stride, int row0, u32x4_t (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t c = threadIdx.x + 256u * j;
+        r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (((uint32_t)row0 + (c >> 4)) * row_stride + (c & 15u) * 8u) * 2u, 0, 0);
+    }
+}
+__device__ __forceinline__ void tile128_store(bf16_t* lds, const u32x4_t (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t c = threadIdx.x + 256u * j;
+        *reinterpret_cast<u32x4_t*>(lds + (c >> 4) * P128 + (c & 15u) * 8u) = r[j];
+    }
+}
+__device__ __forceinline__ bf16x8_t frag_row128(const bf16_t* lds, int rowbase, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(lds + (rowbase + (lane & 31)) * P128 + ks * 16 + (lane >> 5) * 8);
+}
+__device__ __forceinline__ bf16x8_t frag_tr128(const bf16_t* lds, int rowbase, int colbase, int lane) {   // see frag_tr in mfma_tiles.h
+    const int hi = lane >> 5;
+    const bf16_t* p = lds + (rowbase + 4 * hi + ((lane & 15) >> 2)) * P128 + colbase + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr_t;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr_t)(p));
+    const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr_t)(p + 8 * P128));
+    bf16x8_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = lo[i]; r[i + 4] = hi4[i]; }
+    return r;
+}
+__device__ __forceinline__ void load_row_frags128(const bf16_t* base, uint32_t row_stride, int row, int S, int lane, bf16x8_t (&f)[8]) {
+    int r = row + (lane & 31);
+    r = r < S ? r : S - 1;
+    const bf16_t* p = base + ((size_t)r * row_stride + (size_t)((lane >> 5) * 8));
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(p + ks * 16);
+}
+// store this lane's column of four transposed accumulator blocks (rows d = 32 db + acc_row(r, hi)) as bf16, scaled
+__device__ __forceinline__ void store_col128(bf16_t* row_ptr, const f32x16_t (&a)[4], float scale, int hi) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2_t w;
+            w[0] = pack_bf16x2(a[db][4 * g] * scale, a[db][4 * g + 1] * scale);
+            w[1] = pack_bf16x2(a[db][4 * g + 2] * scale, a[db][4 * g + 3] * scale);
+            *reinterpret_cast<u32x2_t*>(row_ptr + db * 32 + 8 * g + 4 * hi) = w;
+        }
+}
+
+// ===================================================================================================== forward
+__global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               bf16_t* __restrict__ O, float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
+                                                               int Sq, int Skv, int H, int n_qt, float c) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][T128];
+    const int bh = blockIdx.x / n_qt, qt = blockIdx.x % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, wave = threadIdx.x >> 6;
+    const int q0 = qt * 128 + wave * 32;
+    bf16x8_t qf[8];
+    load_row_frags128(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0, Sq, lane, qf);
+    const rsrc_t krs = rsrc128(K + ((size_t)b * sk.b + (size_t)h * sk.h), sk.s, Skv);
+    const rsrc_t vrs = rsrc128(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, Skv);
+    f32x16_t o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int nt = (Skv + 63) / 64;
+    u32x4_t kr[4], vr[4];
+    tile128_load(krs, sk.s, 0, kr);
+    tile128_load(vrs, sv.s, 0, vr);
+    tile128_store(lds[0][0], kr);
+    tile128_store(lds[0][1], vr);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            tile128_load(krs, sk.s, (t + 1) * 64, kr);
+            tile128_load(vrs, sv.s, (t + 1) * 64, vr);
+        }
+        const bf16_t* Kt = lds[cur][0];
+        const bf16_t* Vt = lds[cur][1];
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) s[kb] = mfma32(frag_row128(Kt, 32 * kb, ks, lane), qf[ks], s[kb]);
+        }
+        const int krem = Skv - t * 64;   // valid keys of this tile
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float x = s[kb][i] * c;
+                if (krem < 64 && 32 * kb + acc_row(i, hi) >= krem) x = -INFINITY;
+                s[kb][i] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, other_half(mx));
+        const float mn = fmaxf(m, mx);           // finite: every tile holds at least one valid key
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ls = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][i] - mn);
+                s[kb][i] = p;
+                ls += p;
+            }
+        l = l * alpha + ls;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bf16x8_t pk = pack_frag(s[kb], 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) o[db] = mfma32(frag_tr128(Vt, 32 * kb + 16 * cc, 32 * db, lane), pk, o[db]);
+            }
+        if (t + 1 < nt) {
+            tile128_store(lds[cur ^ 1][0], kr);
+            tile128_store(lds[cur ^ 1][1], vr);
+        }
+        __syncthreads();
+    }
+    l += other_half(l);
+    const int q = q0 + (lane & 31);
+    if (q < Sq) {
+        store_col128(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), o, 1.f / l, hi);
+        if (hi == 0) LSE2[(size_t)bh * Sq + q] = m + __builtin_amdgcn_logf(l);   // v_log_f32 is log2
+    }
+}
+
+// ===================================================================================================== backward
+// delta[b,h,q] = sum_d dO O : 16 lanes per row, 16 B each
+__global__ __launch_bounds__(256) void attn128_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, TStride sdo, TStride so, int S, int H,
+                                                              int64_t total, float* __restrict__ delta) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = gid >> 4;
+    const int c16 = (int)(gid & 15);
+    float acc = 0.f;
+    if (row < total) {
+        const int q = (int)(row % S);
+        const int64_t bh = row / S;
+        const int h = (int)(bh % H), b = (int)(bh / H);
+        float a[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h + (size_t)q * sdo.s + c16 * 8)), a);
+        unpack8(*reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c16 * 8)), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if (row < total && c16 == 0) delta[row] = acc;
+}
+
+__global__ __launch_bounds__(256, 1) void attn128_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                              const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                              bf16_t* __restrict__ dQ, TStride sq, TStride sk, TStride sv, TStride sdo, TStride sdq, int Sq,
+                                                              int Skv, int H, int n_qt, float c, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][T128];
+    const int bh = blockIdx.x / n_qt, qt = blockIdx.x % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, wave = threadIdx.x >> 6;
+    const int q0 = qt * 128 + wave * 32;
+    bf16x8_t qf[8], dof[8];
+    load_row_frags128(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0, Sq, lane, qf);
+    load_row_frags128(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0, Sq, lane, dof);
+    int qc = q0 + (lane & 31);
+    qc = qc < Sq ? qc : Sq - 1;
+    const float lse = LSE2[(size_t)bh * Sq + qc], dl = DELTA[(size_t)bh * Sq + qc];
+    const rsrc_t krs = rsrc128(K + ((size_t)b * sk.b + (size_t)h * sk.h), sk.s, Skv);
+    const rsrc_t vrs = rsrc128(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, Skv);
+    f32x16_t dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+    const int nt = (Skv + 63) / 64;
+    u32x4_t kr[4], vr[4];
+    tile128_load(krs, sk.s, 0, kr);
+    tile128_load(vrs, sv.s, 0, vr);
+    tile128_store(lds[0][0], kr);
+    tile128_store(lds[0][1], vr);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            tile128_load(krs, sk.s, (t + 1) * 64, kr);
+            tile128_load(vrs, sv.s, (t + 1) * 64, vr);
+        }
+        const bf16_t* Kt = lds[cur][0];
+        const bf16_t* Vt = lds[cur][1];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) s = mfma32(frag_row128(Kt, 32 * kb, ks, lane), qf[ks], s);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) dp = mfma32(frag_row128(Vt, 32 * kb, ks, lane), dof[ks], dp);
+            // keys past Skv: their K rows are zero, so whatever dS they get adds nothing below
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] * c - lse) * (dp[i] - dl);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bf16x8_t dsk = pack_frag(s, 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) dq[db] = mfma32(frag_tr128(Kt, 32 * kb + 16 * cc, 32 * db, lane), dsk, dq[db]);
+            }
+        }
+        if (t + 1 < nt) {
+            tile128_store(lds[cur ^ 1][0], kr);
+            tile128_store(lds[cur ^ 1][1], vr);
+        }
+        __syncthreads();
+    }
+    const int q = q0 + (lane & 31);
+    if (q < Sq) store_col128(dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s), dq, scale, hi);
+}
+
+__global__ __launch_bounds__(256, 1) void attn128_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                               bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, TStride sq, TStride sk, TStride sv,
+                                                               TStride sdo, TStride sdk, TStride sdv, int Sq, int Skv, int H, int n_kt, float c, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][T128];      // [buffer][Q | dO]
+    __shared__ __attribute__((aligned(16))) float stats[2][2][64];       // [buffer][lse2 | delta]
+    const int bh = blockIdx.x / n_kt, kt = blockIdx.x % n_kt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, wave = threadIdx.x >> 6;
+    const int k0 = kt * 128 + wave * 32;
+    bf16x8_t kf[8], vf[8];
+    load_row_frags128(K + ((size_t)b * sk.b + (size_t)h * sk.h), sk.s, k0, Skv, lane, kf);
+    load_row_frags128(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, k0, Skv, lane, vf);
+    const rsrc_t qrs = rsrc128(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, Sq);
+    const rsrc_t drs = rsrc128(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, Sq);
+    const float* lse_bh = LSE2 + (size_t)bh * Sq;
+    const float* dl_bh = DELTA + (size_t)bh * Sq;
+    f32x16_t dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+    const int nt = (Sq + 63) / 64;
+    u32x4_t qr[4], dr[4];
+    float st = 0.f;
+    // rows past Sq: lse2 = +huge makes P = 0 there
+    auto load_stat = [&](int row0) {
+        if (threadIdx.x < 128) {
+            const int r = row0 + (int)(threadIdx.x & 63);
+            st = threadIdx.x < 64 ? (r < Sq ? lse_bh[r] : 1e30f) : (r < Sq ? dl_bh[r] : 0.f);
+        }
+    };
+    auto store_stat = [&](int buf) {
+        if (threadIdx.x < 128) stats[buf][threadIdx.x >> 6][threadIdx.x & 63] = st;
+    };
+    tile128_load(qrs, sq.s, 0, qr);
+    tile128_load(drs, sdo.s, 0, dr);
+    load_stat(0);
+    tile128_store(lds[0][0], qr);
+    tile128_store(lds[0][1], dr);
+    store_stat(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            tile128_load(qrs, sq.s, (t + 1) * 64, qr);
+            tile128_load(drs, sdo.s, (t + 1) * 64, dr);
+            load_stat((t + 1) * 64);
+        }
+        const bf16_t* Qt = lds[cur][0];
+        const bf16_t* Dt = lds[cur][1];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) s = mfma32(frag_row128(Qt, 32 * qb, ks, lane), kf[ks], s);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) dp = mfma32(frag_row128(Dt, 32 * qb, ks, lane), vf[ks], dp);
+            f32x16_t ds;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t ls = *reinterpret_cast<const f32x4_t*>(&stats[cur][0][32 * qb + 8 * g + 4 * hi]);
+                const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(&stats[cur][1][32 * qb + 8 * g + 4 * hi]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(s[4 * g + i] * c - ls[i]);
+                    s[4 * g + i] = p;
+                    ds[4 * g + i] = p * (dp[4 * g + i] - dl[i]);
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bf16x8_t pk = pack_frag(s, 8 * cc), dsk = pack_frag(ds, 8 * cc);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    dv[db] = mfma32(frag_tr128(Dt, 32 * qb + 16 * cc, 32 * db, lane), pk, dv[db]);
+                    dk[db] = mfma32(frag_tr128(Qt, 32 * qb + 16 * cc, 32 * db, lane), dsk, dk[db]);
+                }
+            }
+        }
+        if (t + 1 < nt) {
+            tile128_store(lds[cur ^ 1][0], qr);
+            tile128_store(lds[cur ^ 1][1], dr);
+            store_stat(cur ^ 1);
+        }
+        __syncthreads();
+    }
+    const int k = k0 + (lane & 31);
+    if (k < Skv) {
+        store_col128(dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s), dk, scale, hi);
+        store_col128(dV + ((size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)k * sdv.s), dv, 1.f, hi);
+    }
+}
+
+// ===================================================================================================== host
+static inline bool sok128(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= D128 && st[0] % 8 == 0 && st[1] % 8 == 0 && st[2] % 8 == 0; }
+static inline bool rok128(const int64_t* st, int64_t B, int64_t H, int64_t S) { return (B - 1) * st[0] + (H - 1) * st[1] + (S - 1) * st[2] + D128 < ((int64_t)1 << 31); }
+static inline TStride mk128(const int64_t* st) { TStride t; t.b = (uint32_t)st[0]; t.h = (uint32_t)st[1]; t.s = (uint32_t)st[2]; return t; }
+static inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+#define LOG2E_F 1.4426950408889634f
+
+extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
+                                    const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
+                                    hipStream_t stream) {
+    if (!q || !k || !v || !o || !lse2 || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
+    if (!sok128(q_strides) || !sok128(k_strides) || !sok128(v_strides) || !sok128(o_strides) || !a16(q) || !a16(k) || !a16(v) || !a16(o)) return VGPA_ERR_INVALID;
+    if (!rok128(q_strides, B, H, Sq) || !rok128(k_strides, B, H, Skv) || !rok128(v_strides, B, H, Skv) || !rok128(o_strides, B, H, Sq)) return VGPA_ERR_INVALID;
+    const int64_t n_qt = (Sq + 127) / 128, tasks = B * H * n_qt;
+    if (tasks >= ((int64_t)1 << 31)) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
+                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, scale * LOG2E_F);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// delta: caller's fp32 scratch [B * H * Sq]
+extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
+                                    void* dv, float* delta, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                    const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                                    const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, hipStream_t stream) {
+    if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || !delta || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
+    const int64_t* qs[] = {q_strides, o_strides, do_strides, dq_strides};
+    const int64_t* ks[] = {k_strides, v_strides, dk_strides, dv_strides};
+    for (const int64_t* s : qs) if (!sok128(s) || !rok128(s, B, H, Sq)) return VGPA_ERR_INVALID;
+    for (const int64_t* s : ks) if (!sok128(s) || !rok128(s, B, H, Skv)) return VGPA_ERR_INVALID;
+    if (!a16(q) || !a16(k) || !a16(v) || !a16(o) || !a16(d_o) || !a16(dq) || !a16(dk) || !a16(dv)) return VGPA_ERR_INVALID;
+    const int64_t n_qt = (Sq + 127) / 128, n_kt = (Skv + 127) / 128, total = B * H * Sq;
+    if (B * H * n_qt >= ((int64_t)1 << 31) || B * H * n_kt >= ((int64_t)1 << 31) || total * 16 >= ((int64_t)1 << 39)) return VGPA_ERR_INVALID;
+    const float c = scale * LOG2E_F;
+    VGPA_LAUNCH(attn128_delta_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, mk128(do_strides),
+                mk128(o_strides), (int)Sq, (int)H, total, delta);
+    VGPA_LAUNCH(attn128_dq_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
+                lse2, (const float*)delta, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides), mk128(dq_strides), (int)Sq,
+                (int)Skv, (int)H, (int)n_qt, c, scale);
+    VGPA_LAUNCH(attn128_dkv_kernel, dim3((unsigned)(B * H * n_kt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
+                lse2, (const float*)delta, (bf16_t*)dk, (bf16_t*)dv, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides), mk128(dk_strides),
+                mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}

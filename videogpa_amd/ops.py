@@ -714,6 +714,42 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
         _bhs_strides(dq), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
 
 
+class _Attention128Fn(torch.autograd.Function):
+    """softmax(scale q k^T) v for head_dim 128, query and key lengths free (csrc/attention_hd128.hip): Wan2.2's self- and cross-attention"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        B, H, Sq, D = q.shape
+        Skv = k.shape[2]
+        assert D == 128 and k.shape == (B, H, Skv, 128) and v.shape == k.shape and q.dtype == k.dtype == v.dtype == torch.bfloat16
+        q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
+        o = torch.empty(B, H, Sq, D, dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+        _timed("attn128_fwd", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+            "vgpa_attn128_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale), _stream()))
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, H, Sq, D = q.shape
+        Skv = k.shape[2]
+        do = do if do.stride(3) == 1 else do.contiguous()
+        dq, dk, dv = torch.empty_like(o), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device)
+        delta = torch.empty(B * H * Sq, dtype=torch.float32, device=q.device)
+        _timed("attn128_bwd", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+            "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, delta, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
+            _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, ctx.scale, _stream()))
+        return dq, dk, dv, None
+
+
+def attention128(q, k, v, scale=None):
+    """q [B, H, Sq, 128], k / v [B, H, Skv, 128] (bf16, last dim contiguous) -> [B, H, Sq, 128]"""
+    return _Attention128Fn.apply(q, k, v, q.shape[-1] ** -0.5 if scale is None else scale)
+
+
 class _QKNormAttentionFn(torch.autograd.Function):
     """qkv [B,S,3*H*64] (fused QKV GEMM output) -> attention output [B,S,H*64].
     QK-norm (+ optional 3D RoPE on tokens >= text_len) -> flash attention; backward returns dqkv in the same layout."""
