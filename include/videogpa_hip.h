@@ -217,6 +217,28 @@ int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void
                          const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
                          const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, vgpa_stream_t stream);
 
+/* ---- row kernels of the Wan2.2 denoiser block (WanAttentionBlock / WanRMSNorm / rope_apply of the Wan2.2 checkout imported at
+ * train/Wan2.2-TI2V-5B/03_train.py:43-48).  fp32 residual stream, bf16 matmul operands.  Per-token modulation as a table: row
+ * gid[row] of a [groups, mod_stride] fp32 table (shift / scale / gate point at their chunk's column offset); gid NULL = row 0.
+ *   ln_mod_fwd : out(bf16) = ([round_bf16] LN_eps(x)) * ln_w + ln_b, then * (1 + scale[g]) + shift[g]   (affine / modulation optional;
+ *                x_dtype VGPA_DTYPE_F32 | VGPA_DTYPE_BF16)             ln_mod_bwd: dx(fp32) = [dres +] LN-backward(dy (1 + scale) ln_w)
+ *   gate_residual: out(fp32) = [x +] y(bf16) * gate[g]  (gate NULL = 1; out may alias x)       gate_bwd: dy(bf16) = dout(fp32) * gate[g]
+ *   rms_rope   : n = bf16(u rsqrt(mean(u^2) + eps)) over the whole row [heads * head_dim]; y = bf16(n w); interleaved pairs of every head
+ *                rotated by the angle at rope_{cos,sin}[(row % L) * head_dim/2 + pair]  (NULL: no rotation)  */
+int32_t vgpa_wan_ln_mod_fwd(const void* x, int32_t x_dtype, const int32_t* gid, const float* ln_w, const float* ln_b, const float* shift,
+                            const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, int32_t round_xhat, void* out, float* mean,
+                            float* rstd, vgpa_stream_t stream);
+int32_t vgpa_wan_ln_mod_bwd(const void* dy, const void* x, int32_t x_dtype, const float* mean, const float* rstd, const int32_t* gid, const float* ln_w,
+                            const float* scale, int64_t mod_stride, int64_t rows, int64_t D, const float* dres, float* dx, vgpa_stream_t stream);
+int32_t vgpa_wan_gate_residual(const float* x, const void* y, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, float* out,
+                               vgpa_stream_t stream);
+int32_t vgpa_wan_gate_bwd(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* dy,
+                          vgpa_stream_t stream);
+int32_t vgpa_wan_rms_rope_fwd(const void* u, const void* w, const float* rope_cos, const float* rope_sin, int64_t L, int64_t head_dim, int64_t rows,
+                              int64_t D, float eps, void* out, float* rstd, vgpa_stream_t stream);
+int32_t vgpa_wan_rms_rope_bwd(const void* dout, const void* u, const float* rstd, const void* w, const float* rope_cos, const float* rope_sin, int64_t L,
+                              int64_t head_dim, int64_t rows, int64_t D, void* du, vgpa_stream_t stream);
+
 /* ---- VGGT input preprocessing: utils/model_utils.py:16-85 preprocess_images_from_numpy (PIL bicubic resize to width 518 /
  * longer side 518, ToTensor, centre crop or white pad).  frames uint8 [T, H, W, 3] -> out float32 [T, 3, out_h, out_w].
  * mode 0 = "crop", 1 = "pad".  vgpa_preprocess_shape is host arithmetic only (:36-48, :54-71). */

@@ -65,3 +65,80 @@ def test_attention128_strided_views_and_sharp_softmax():
     _close(qg.grad, rq, "dq", 0.03)
     _close(kg.grad, rk, "dk", 0.03)
     _close(vg.grad, rv, "dv", 0.03)
+
+
+# ------------------------------------------------------------------------------------------------ row kernels of the block (csrc/wan.hip)
+def _tab(G, n, C, g):
+    return (torch.randn(G, n, C, device="cuda", generator=g) * 0.5).contiguous()
+
+
+@pytest.mark.parametrize("xdt,affine,mod,rnd", [(torch.float32, False, True, False), (torch.bfloat16, False, True, True), (torch.float32, True, False, False)])
+def test_wan_ln_mod_forward_backward(xdt, affine, mod, rnd):
+    from videogpa_amd.wan_model import ln_mod
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rows, C, G = 300, 3072, 3
+    x = (torch.randn(rows, C, device="cuda", generator=g) * 2 + 0.3).to(xdt)
+    gid = torch.randint(0, G, (rows,), device="cuda", generator=g).int()
+    tab = _tab(G, 6, C, g)
+    w = torch.randn(C, device="cuda", generator=g) if affine else None
+    b = torch.randn(C, device="cuda", generator=g) if affine else None
+    dy = torch.randn(rows, C, device="cuda", generator=g).bfloat16()
+    xg = x.clone().requires_grad_(True)
+    out = ln_mod(xg, gid if mod else None, w, b, tab[:, 3] if mod else None, tab[:, 4] if mod else None, 1e-6, round_xhat=rnd)
+    out.backward(dy)
+    xr = x.double().requires_grad_(True)
+    h = torch.nn.functional.layer_norm(xr, (C,), None, None, 1e-6)
+    if rnd:
+        h = h + (h.detach().bfloat16().double() - h.detach())           # value rounded, gradient straight through (.type_as)
+    if affine:
+        h = h * w.double() + b.double()
+    if mod:
+        h = h * (1 + tab[:, 4].double()[gid.long()]) + tab[:, 3].double()[gid.long()]
+    h.backward(dy.double())
+    assert out.dtype == torch.bfloat16 and (out.double() - h.detach()).abs().max().item() <= 2 ** -8 * h.detach().abs().max().item()
+    assert xg.grad.dtype == xdt
+    tol = 1e-5 if xdt == torch.float32 else 2 ** -8
+    assert (xg.grad.double() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+
+
+def test_wan_gate_residual_forward_backward():
+    from videogpa_amd.wan_model import gate_residual
+    g = torch.Generator(device="cuda").manual_seed(2)
+    rows, C, G = 257, 3072, 2
+    x = torch.randn(rows, C, device="cuda", generator=g)
+    y = torch.randn(rows, C, device="cuda", generator=g).bfloat16()
+    gid = torch.randint(0, G, (rows,), device="cuda", generator=g).int()
+    tab = _tab(G, 6, C, g)
+    dout = torch.randn(rows, C, device="cuda", generator=g)
+    for gate in (tab[:, 2], None):
+        xg, yg = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        out = gate_residual(xg, yg, gid if gate is not None else None, gate)
+        out.backward(dout)
+        gt = gate[gid.long()] if gate is not None else torch.ones_like(x)
+        assert out.dtype == torch.float32 and torch.equal(out, torch.addcmul(x, y.float(), gt)) or (out - (x + y.float() * gt)).abs().max().item() <= 1e-6 * 8
+        assert torch.equal(xg.grad, dout)
+        assert torch.equal(yg.grad, (dout * gt).bfloat16())
+
+
+@pytest.mark.parametrize("rope", [True, False])
+def test_wan_rms_rope_forward_backward(rope):
+    from oracle import wan as ow
+    from videogpa_amd.wan_model import rms_rope, rope_tables
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, grid, n, d = 2, (3, 4, 5), 24, 128
+    L, C = grid[0] * grid[1] * grid[2], n * d
+    u = (torch.randn(B, L, C, device="cuda", generator=g) * 1.7).bfloat16()
+    w = (1 + 0.2 * torch.randn(C, device="cuda", generator=g)).bfloat16()
+    dout = torch.randn(B, L, C, device="cuda", generator=g).bfloat16()
+    cos, sin = rope_tables(grid, d, "cuda") if rope else (None, None)
+    ug = u.clone().requires_grad_(True)
+    out = rms_rope(ug, w, cos, sin, d, 1e-6)
+    out.backward(dout)
+    ur = u.double().requires_grad_(True)
+    r = ow.rms_norm(ur, w.double(), 1e-6)
+    if rope:
+        freqs = torch.cat([ow.rope_params(1024, d - 4 * (d // 6), device="cuda"), ow.rope_params(1024, 2 * (d // 6), device="cuda"), ow.rope_params(1024, 2 * (d // 6), device="cuda")], dim=1)
+        r = ow.rope_apply(r.view(B, L, n, d), grid, freqs).reshape(B, L, C)
+    r.backward(dout.double())
+    assert (out.double() - r.detach()).abs().max().item() <= 1.5 * 2 ** -8 * r.detach().abs().max().item()      # two bf16 roundings + the output's
+    assert (ug.grad.double() - ur.grad).abs().max().item() <= 2.5 * 2 ** -8 * ur.grad.abs().max().item()

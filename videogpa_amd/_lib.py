@@ -59,6 +59,12 @@ SIGNATURES = {
     "vgpa_lora_grad_ws": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P, SZ, P]),
     "vgpa_attn128_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn128_bwd": (I32, [P] * 18 + [I64, I64, I64, I64, F32, P]),
+    "vgpa_wan_ln_mod_fwd": (I32, [P, I32, P, P, P, P, P, I64, I64, I64, F32, I32, P, P, P, P]),
+    "vgpa_wan_ln_mod_bwd": (I32, [P, P, I32, P, P, P, P, P, I64, I64, I64, P, P, P]),
+    "vgpa_wan_gate_residual": (I32, [P, P, P, P, I64, I64, I64, P, P]),
+    "vgpa_wan_gate_bwd": (I32, [P, P, P, I64, I64, I64, P, P]),
+    "vgpa_wan_rms_rope_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, F32, P, P, P]),
+    "vgpa_wan_rms_rope_bwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, P, P]),
     "vgpa_preprocess_shape": (I32, [I32, I32, I32, P, P]),
     "vgpa_preprocess_workspace_bytes": (SZ, [I32, I32, I32, I32]),
     "vgpa_preprocess_frames": (I32, [P, I32, I32, I32, I32, P, P, SZ, P]),

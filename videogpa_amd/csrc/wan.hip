@@ -1,0 +1,317 @@
+// Row kernels of the Wan2.2-TI2V-5B denoiser block (wan/modules/model.py of the Wan2.2 checkout the reference imports at
+// train/Wan2.2-TI2V-5B/03_train.py:43-48; not vendored: restated from its published architecture, see oracle/wan.py):
+//   * the residual stream is fp32 (x + y * e with fp32 e promotes it in the first block), every matmul input is bf16;
+//   * modulation e = modulation + time_projection(t) is PER TOKEN in Wan2.2 ([B, L, 6, C]).  Here it is a small table
+//     [groups, n_chunk, C] (one row per distinct timestep of a sample: 2 for TI2V -- first-frame tokens at t = 0, the rest at t)
+//     plus an int32 group id per token, 8 KB instead of 1.4 GB per sample at 18480 tokens;
+//   * q / k go through WanRMSNorm over the FULL projection width (all heads), times a bf16 weight, then the 3-axis RoPE on
+//     interleaved pairs of each 128-wide head.
+// One wave per row, rows of C <= 4096 elements held in registers; all HBM-bound (algorithmic bytes in DESIGN.md section 4).
+#include "common.h"
+
+#define WAN_NV 8                 // 64 lanes x 8 elements x WAN_NV >= C
+#define WAN_WAVES 4
+
+__device__ __forceinline__ int64_t wan_row() { return (int64_t)blockIdx.x * WAN_WAVES + (threadIdx.x >> 6); }
+
+// y = [round_bf16](LN(x)) * w + b, then * (1 + scale[g]) + shift[g]  ->  bf16            (w, b, scale / shift optional)
+// mod: table row stride `mod_stride` floats, shift at column offset 0 of `shift`, scale of `scale` (pointers into the same table)
+template <int XDT>
+__global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const void* __restrict__ x, const int* __restrict__ gid, const float* __restrict__ w,
+                                                                          const float* __restrict__ b, const float* __restrict__ shift,
+                                                                          const float* __restrict__ scale, int64_t mod_stride, int D, int64_t rows, float eps,
+                                                                          int round_xhat, bf16_t* __restrict__ out, float* __restrict__ mean_out,
+                                                                          float* __restrict__ rstd_out) {
+    const int64_t row = wan_row();
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float v[WAN_NV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            load8<XDT>(x, (size_t)row * D + i0, v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[c][j];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c)
+        if ((c * 64 + lane) * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const size_t g = gid ? (size_t)gid[row] * mod_stride : 0;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float h = (v[c][j] - mean) * rstd;
+                if (round_xhat) h = round_bf16(h);
+                if (w) h = h * w[i0 + j] + b[i0 + j];
+                if (scale) h = h * (1.f + scale[g + i0 + j]) + shift[g + i0 + j];
+                o[j] = h;
+            }
+            store8<VGPA_DTYPE_BF16>(out, (size_t)row * D + i0, o);
+        }
+    }
+}
+
+// dx = [dres +] LN-backward(dy * (1 + scale[g]) * w)           fp32 out (may alias dres)
+template <int XDT>
+__global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x, const float* __restrict__ mean,
+                                                                          const float* __restrict__ rstd, const int* __restrict__ gid, const float* __restrict__ w,
+                                                                          const float* __restrict__ scale, int64_t mod_stride, int D, int64_t rows,
+                                                                          const float* dres, float* dx) {
+    const int64_t row = wan_row();
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float mu = mean[row], rs = rstd[row];
+    const size_t g = gid ? (size_t)gid[row] * mod_stride : 0;
+    float gy[WAN_NV][8], xh[WAN_NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            load8<VGPA_DTYPE_BF16>(dy, (size_t)row * D + i0, gy[c]);
+            load8<XDT>(x, (size_t)row * D + i0, xh[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = gy[c][j];
+                if (scale) t *= 1.f + scale[g + i0 + j];
+                if (w) t *= w[i0 + j];
+                gy[c][j] = t;
+                xh[c][j] = (xh[c][j] - mu) * rs;
+                s1 += t;
+                s2 += t * xh[c][j];
+            }
+        }
+    }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float o[8];
+            if (dres) load8<VGPA_DTYPE_F32>(dres, (size_t)row * D + i0, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (dres ? o[j] : 0.f) + rs * (gy[c][j] - c1 - xh[c][j] * c2);
+            store8<VGPA_DTYPE_F32>(dx, (size_t)row * D + i0, o);
+        }
+    }
+}
+
+// out(fp32) = x + y(bf16) * gate[g]           (x NULL: out = y * gate; gate NULL: 1)          out may alias x
+__global__ __launch_bounds__(256) void wan_gate_residual_kernel(const float* x, const bf16_t* __restrict__ y, const int* __restrict__ gid,
+                                                                  const float* __restrict__ gate, int64_t mod_stride, int D, int64_t rows, float* out) {
+    const int per_row = D / 8;
+    const int64_t total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / per_row;
+        const int i0 = (int)(i % per_row) * 8;
+        float a[8], o[8];
+        load8<VGPA_DTYPE_BF16>(y, (size_t)row * D + i0, a);
+        if (x) load8<VGPA_DTYPE_F32>(x, (size_t)row * D + i0, o);
+        const float* gp = gate ? gate + (gid ? (size_t)gid[row] * mod_stride : 0) + i0 : nullptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (x ? o[j] : 0.f) + a[j] * (gp ? gp[j] : 1.f);
+        store8<VGPA_DTYPE_F32>(out, (size_t)row * D + i0, o);
+    }
+}
+// dy(bf16) = dout(fp32) * gate[g]
+__global__ __launch_bounds__(256) void wan_gate_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ gid, const float* __restrict__ gate,
+                                                             int64_t mod_stride, int D, int64_t rows, bf16_t* __restrict__ dy) {
+    const int per_row = D / 8;
+    const int64_t total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / per_row;
+        const int i0 = (int)(i % per_row) * 8;
+        float o[8];
+        load8<VGPA_DTYPE_F32>(dout, (size_t)row * D + i0, o);
+        const float* gp = gate ? gate + (gid ? (size_t)gid[row] * mod_stride : 0) + i0 : nullptr;
+        if (gp) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= gp[j];
+        }
+        store8<VGPA_DTYPE_BF16>(dy, (size_t)row * D + i0, o);
+    }
+}
+
+// WanRMSNorm over the whole row + bf16 weight + RoPE on interleaved pairs of each head (head_dim = 2 * half, pair p of every head
+// turned by the angle whose cos / sin sit at rope[(row % L) * half + p]); rope NULL: no rotation (cross-attention q / k).
+//   n = bf16(u * rsqrt(mean(u^2) + eps));  y = bf16(n * w);  (a, b) -> (a cos - b sin, a sin + b cos)
+__global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_fwd_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ w, const float* __restrict__ rope_cos,
+                                                                            const float* __restrict__ rope_sin, int L, int half, int D, int64_t rows, float eps,
+                                                                            bf16_t* __restrict__ out, float* __restrict__ rstd_out) {
+    const int64_t row = wan_row();
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float v[WAN_NV][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            load8<VGPA_DTYPE_BF16>(u, (size_t)row * D + i0, v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += v[c][j] * v[c][j];
+        }
+    }
+    const float rs = rsqrtf(wave_sum(sq) / (float)D + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rs;
+    const size_t tr = (size_t)(row % L) * half;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float wv[8], o[8];
+            load8<VGPA_DTYPE_BF16>(w, (size_t)i0, wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = round_bf16(round_bf16(v[c][j] * rs) * wv[j]);
+            if (rope_cos) {
+                const int p0 = (i0 % (2 * half)) / 2;     // first pair of these 8 elements inside its head
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const float cs = rope_cos[tr + p0 + j / 2], sn = rope_sin[tr + p0 + j / 2];
+                    const float a = o[j], bb = o[j + 1];
+                    o[j] = a * cs - bb * sn;
+                    o[j + 1] = a * sn + bb * cs;
+                }
+            }
+            store8<VGPA_DTYPE_BF16>(out, (size_t)row * D + i0, o);
+        }
+    }
+}
+// du = rs * (dn - n sum(dn n) / D),  dn = w * R^T dout,  n = u * rs                       (the weight is frozen: no dw)
+__global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ u, const float* __restrict__ rstd,
+                                                                            const bf16_t* __restrict__ w, const float* __restrict__ rope_cos,
+                                                                            const float* __restrict__ rope_sin, int L, int half, int D, int64_t rows,
+                                                                            bf16_t* __restrict__ du) {
+    const int64_t row = wan_row();
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float rs = rstd[row];
+    const size_t tr = (size_t)(row % L) * half;
+    float dn[WAN_NV][8], n[WAN_NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float wv[8];
+            load8<VGPA_DTYPE_BF16>(dout, (size_t)row * D + i0, dn[c]);
+            load8<VGPA_DTYPE_BF16>(u, (size_t)row * D + i0, n[c]);
+            load8<VGPA_DTYPE_BF16>(w, (size_t)i0, wv);
+            if (rope_cos) {
+                const int p0 = (i0 % (2 * half)) / 2;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const float cs = rope_cos[tr + p0 + j / 2], sn = rope_sin[tr + p0 + j / 2];
+                    const float a = dn[c][j], bb = dn[c][j + 1];
+                    dn[c][j] = a * cs + bb * sn;
+                    dn[c][j + 1] = -a * sn + bb * cs;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dn[c][j] *= wv[j];
+                n[c][j] *= rs;
+                s += dn[c][j] * n[c][j];
+            }
+        }
+    }
+    const float m = wave_sum(s) / (float)D;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rs * (dn[c][j] - n[c][j] * m);
+            store8<VGPA_DTYPE_BF16>(du, (size_t)row * D + i0, o);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------- host
+static inline bool wan_dims_ok(int64_t rows, int64_t D) { return rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * WAN_NV; }
+static inline dim3 wan_grid(int64_t rows) { return dim3((unsigned)((rows + WAN_WAVES - 1) / WAN_WAVES)); }
+static inline dim3 wan_ew_grid(int64_t n8) { const int64_t b = (n8 + 255) / 256; return dim3((unsigned)(b < 65536 ? b : 65536)); }
+
+extern "C" int32_t vgpa_wan_ln_mod_fwd(const void* x, int32_t x_dtype, const int32_t* gid, const float* ln_w, const float* ln_b, const float* shift,
+                                       const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, int32_t round_xhat, void* out, float* mean,
+                                       float* rstd, hipStream_t stream) {
+    if (!x || !out || !wan_dims_ok(rows, D) || (ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale == nullptr) ||
+        (mean == nullptr) != (rstd == nullptr))
+        return VGPA_ERR_INVALID;
+    if (x_dtype == VGPA_DTYPE_F32)
+        VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, x, gid, ln_w, ln_b, shift, scale, mod_stride, (int)D, rows,
+                    eps, round_xhat, (bf16_t*)out, mean, rstd);
+    else if (x_dtype == VGPA_DTYPE_BF16)
+        VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_BF16>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, x, gid, ln_w, ln_b, shift, scale, mod_stride, (int)D, rows,
+                    eps, round_xhat, (bf16_t*)out, mean, rstd);
+    else
+        return VGPA_ERR_INVALID;
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_ln_mod_bwd(const void* dy, const void* x, int32_t x_dtype, const float* mean, const float* rstd, const int32_t* gid, const float* ln_w,
+                                       const float* scale, int64_t mod_stride, int64_t rows, int64_t D, const float* dres, float* dx, hipStream_t stream) {
+    if (!dy || !x || !mean || !rstd || !dx || !wan_dims_ok(rows, D)) return VGPA_ERR_INVALID;
+    if (x_dtype == VGPA_DTYPE_F32)
+        VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)dy, x, mean, rstd, gid, ln_w, scale, mod_stride,
+                    (int)D, rows, dres, dx);
+    else if (x_dtype == VGPA_DTYPE_BF16)
+        VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_BF16>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)dy, x, mean, rstd, gid, ln_w, scale, mod_stride,
+                    (int)D, rows, dres, dx);
+    else
+        return VGPA_ERR_INVALID;
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_gate_residual(const float* x, const void* y, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, float* out,
+                                          hipStream_t stream) {
+    if (!y || !out || rows <= 0 || D <= 0 || D % 8) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(wan_gate_residual_kernel, wan_ew_grid(rows * (D / 8)), dim3(256), 0, stream, x, (const bf16_t*)y, gid, gate, mod_stride, (int)D, rows, out);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_gate_bwd(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* dy,
+                                     hipStream_t stream) {
+    if (!dout || !dy || rows <= 0 || D <= 0 || D % 8) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(wan_gate_bwd_kernel, wan_ew_grid(rows * (D / 8)), dim3(256), 0, stream, dout, gid, gate, mod_stride, (int)D, rows, (bf16_t*)dy);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_rms_rope_fwd(const void* u, const void* w, const float* rope_cos, const float* rope_sin, int64_t L, int64_t head_dim, int64_t rows,
+                                         int64_t D, float eps, void* out, float* rstd, hipStream_t stream) {
+    if (!u || !w || !out || !wan_dims_ok(rows, D) || (rope_cos == nullptr) != (rope_sin == nullptr)) return VGPA_ERR_INVALID;
+    if (rope_cos && (L <= 0 || head_dim <= 0 || head_dim % 8 || D % head_dim)) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(wan_rms_rope_fwd_kernel, wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)u, (const bf16_t*)w, rope_cos, rope_sin, (int)(rope_cos ? L : 1),
+                (int)(rope_cos ? head_dim / 2 : 1), (int)D, rows, eps, (bf16_t*)out, rstd);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_rms_rope_bwd(const void* dout, const void* u, const float* rstd, const void* w, const float* rope_cos, const float* rope_sin, int64_t L,
+                                         int64_t head_dim, int64_t rows, int64_t D, void* du, hipStream_t stream) {
+    if (!dout || !u || !rstd || !w || !du || !wan_dims_ok(rows, D) || (rope_cos == nullptr) != (rope_sin == nullptr)) return VGPA_ERR_INVALID;
+    if (rope_cos && (L <= 0 || head_dim <= 0 || head_dim % 8 || D % head_dim)) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(wan_rms_rope_bwd_kernel, wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)dout, (const bf16_t*)u, rstd, (const bf16_t*)w, rope_cos, rope_sin,
+                (int)(rope_cos ? L : 1), (int)(rope_cos ? head_dim / 2 : 1), (int)D, rows, (bf16_t*)du);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
