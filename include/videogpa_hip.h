@@ -239,6 +239,11 @@ int32_t vgpa_wan_rms_rope_fwd(const void* u, const void* w, const float* rope_co
 int32_t vgpa_wan_rms_rope_bwd(const void* dout, const void* u, const float* rstd, const void* w, const float* rope_cos, const float* rope_sin, int64_t L,
                               int64_t head_dim, int64_t rows, int64_t D, void* du, vgpa_stream_t stream);
 
+/* ---- fp8 operand preparation for the frozen feed-forward GEMMs of the Wan2.2 path (BASELINE.json configs[4]: "fp8 MFMA path"):
+ * per-row dynamic quantisation of bf16 rows to OCP e4m3: scale[m] = amax(row) / 448 (1 for a zero row), q = e4m3(x / scale), RNE, saturating.
+ * x [M, K] bf16 with row stride ldx (elements); q [M, K] bytes, contiguous; scale [M] fp32. */
+int32_t vgpa_quant_fp8_rows(const void* x, int64_t ldx, void* q, float* scale, int64_t M, int64_t K, vgpa_stream_t stream);
+
 /* ---- VGGT input preprocessing: utils/model_utils.py:16-85 preprocess_images_from_numpy (PIL bicubic resize to width 518 /
  * longer side 518, ToTensor, centre crop or white pad).  frames uint8 [T, H, W, 3] -> out float32 [T, 3, out_h, out_w].
  * mode 0 = "crop", 1 = "pad".  vgpa_preprocess_shape is host arithmetic only (:36-48, :54-71). */

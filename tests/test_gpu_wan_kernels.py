@@ -142,3 +142,40 @@ def test_wan_rms_rope_forward_backward(rope):
     r.backward(dout.double())
     assert (out.double() - r.detach()).abs().max().item() <= 1.5 * 2 ** -8 * r.detach().abs().max().item()      # two bf16 roundings + the output's
     assert (ug.grad.double() - ur.grad).abs().max().item() <= 2.5 * 2 ** -8 * ur.grad.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ fp8 operands (csrc/fp8.hip)
+def test_quant_fp8_rows_bit_exact_vs_torch_cast():
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for (M, K) in [(5, 64), (130, 3072), (33, 14336)]:
+        x = (torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 30).bfloat16()
+        x[0] = 0                                                     # all-zero row: scale 1
+        x[1, :8] = torch.tensor([1e-30, -1e-30, 448.0, -448.0, 1e4, -1e4, 0.0, 3.0], device="cuda").bfloat16()
+        q, sc = ops.quant_fp8_rows(x)
+        amax = x.float().abs().amax(dim=1, keepdim=True)
+        ref_sc = torch.where(amax > 0, amax / torch.full_like(amax, 448.0), torch.ones_like(amax))   # tensor / tensor: a true division (tensor / python scalar multiplies by 1/448)
+        ref_q = (x.float() / ref_sc).clamp(-448, 448).to(torch.float8_e4m3fn)
+        assert torch.equal(sc, ref_sc)
+        assert torch.equal(q.view(torch.uint8), ref_q.view(torch.uint8)), (M, K)
+        xs = torch.cat([x, x], dim=1)[:, :K]                          # a column slice: row stride 2K
+        q2, sc2 = ops.quant_fp8_rows(xs)
+        assert torch.equal(q2.view(torch.uint8), q.view(torch.uint8)) and torch.equal(sc2, sc)
+
+
+def test_frozen_linear_fp8_forward_backward_against_fp32():
+    """e4m3 has 3 mantissa bits: each operand carries ~3.6 % rms rounding noise per element, which averages down over K in the product;
+    the GEMM result must sit within 4 % (relative Frobenius error) of fp32 -- the figure tools/fp8_probe.py measures for hipBLASLt alone."""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    M, K, N = 512, 3072, 1024
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16().requires_grad_(True)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g).bfloat16()
+    dy = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    y = ops.frozen_linear_fp8(x, W, b)
+    y.backward(dy)
+    ry = x.detach().float() @ W.float().T + b.float()
+    rdx = dy.float() @ W.float()
+    assert y.dtype == torch.bfloat16 and ((y.float() - ry).norm() / ry.norm()).item() < 0.04
+    assert ((x.grad.float() - rdx).norm() / rdx.norm()).item() < 0.04

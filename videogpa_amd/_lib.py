@@ -65,6 +65,7 @@ SIGNATURES = {
     "vgpa_wan_gate_bwd": (I32, [P, P, P, I64, I64, I64, P, P]),
     "vgpa_wan_rms_rope_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, F32, P, P, P]),
     "vgpa_wan_rms_rope_bwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, P, P]),
+    "vgpa_quant_fp8_rows": (I32, [P, I64, P, P, I64, I64, P]),
     "vgpa_preprocess_shape": (I32, [I32, I32, I32, P, P]),
     "vgpa_preprocess_workspace_bytes": (SZ, [I32, I32, I32, I32]),
     "vgpa_preprocess_frames": (I32, [P, I32, I32, I32, I32, P, P, SZ, P]),

@@ -51,14 +51,23 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const vo
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
-            float o[8];
+            float o[8], t0[8], t1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float h = (v[c][j] - mean) * rstd;
-                if (round_xhat) h = round_bf16(h);
-                if (w) h = h * w[i0 + j] + b[i0 + j];
-                if (scale) h = h * (1.f + scale[g + i0 + j]) + shift[g + i0 + j];
-                o[j] = h;
+                o[j] = (v[c][j] - mean) * rstd;
+                if (round_xhat) o[j] = round_bf16(o[j]);
+            }
+            if (w) {
+                load8<VGPA_DTYPE_F32>(w, (size_t)i0, t0);
+                load8<VGPA_DTYPE_F32>(b, (size_t)i0, t1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = o[j] * t0[j] + t1[j];
+            }
+            if (scale) {
+                load8<VGPA_DTYPE_F32>(scale, g + i0, t0);
+                load8<VGPA_DTYPE_F32>(shift, g + i0, t1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = o[j] * (1.f + t0[j]) + t1[j];
             }
             store8<VGPA_DTYPE_BF16>(out, (size_t)row * D + i0, o);
         }
@@ -84,15 +93,22 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const bf
         if (i0 < D) {
             load8<VGPA_DTYPE_BF16>(dy, (size_t)row * D + i0, gy[c]);
             load8<XDT>(x, (size_t)row * D + i0, xh[c]);
+            float t0[8];
+            if (scale) {
+                load8<VGPA_DTYPE_F32>(scale, g + i0, t0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gy[c][j] *= 1.f + t0[j];
+            }
+            if (w) {
+                load8<VGPA_DTYPE_F32>(w, (size_t)i0, t0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gy[c][j] *= t0[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float t = gy[c][j];
-                if (scale) t *= 1.f + scale[g + i0 + j];
-                if (w) t *= w[i0 + j];
-                gy[c][j] = t;
                 xh[c][j] = (xh[c][j] - mu) * rs;
-                s1 += t;
-                s2 += t * xh[c][j];
+                s1 += gy[c][j];
+                s2 += gy[c][j] * xh[c][j];
             }
         }
     }
@@ -122,8 +138,10 @@ __global__ __launch_bounds__(256) void wan_gate_residual_kernel(const float* x, 
         load8<VGPA_DTYPE_BF16>(y, (size_t)row * D + i0, a);
         if (x) load8<VGPA_DTYPE_F32>(x, (size_t)row * D + i0, o);
         const float* gp = gate ? gate + (gid ? (size_t)gid[row] * mod_stride : 0) + i0 : nullptr;
+        float gt[8];
+        if (gp) load8<VGPA_DTYPE_F32>(gp, 0, gt);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (x ? o[j] : 0.f) + a[j] * (gp ? gp[j] : 1.f);
+        for (int j = 0; j < 8; ++j) o[j] = (x ? o[j] : 0.f) + a[j] * (gp ? gt[j] : 1.f);
         store8<VGPA_DTYPE_F32>(out, (size_t)row * D + i0, o);
     }
 }
@@ -139,8 +157,10 @@ __global__ __launch_bounds__(256) void wan_gate_bwd_kernel(const float* __restri
         load8<VGPA_DTYPE_F32>(dout, (size_t)row * D + i0, o);
         const float* gp = gate ? gate + (gid ? (size_t)gid[row] * mod_stride : 0) + i0 : nullptr;
         if (gp) {
+            float gt[8];
+            load8<VGPA_DTYPE_F32>(gp, 0, gt);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] *= gp[j];
+            for (int j = 0; j < 8; ++j) o[j] *= gt[j];
         }
         store8<VGPA_DTYPE_BF16>(dy, (size_t)row * D + i0, o);
     }

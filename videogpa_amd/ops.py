@@ -544,6 +544,80 @@ class LoraExt:
         return self
 
 
+# ---- fp8 (OCP e4m3) form of a frozen projection: the "fp8 MFMA path" of BASELINE.json configs[4] (Wan2.2-TI2V-5B) ------------------
+def quant_fp8_rows(x2):
+    """bf16 [M, K] (row stride free) -> (e4m3 [M, K], fp32 scale [M, 1]): per-row dynamic scaling, csrc/fp8.hip"""
+    M, K = x2.shape
+    q = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=x2.device)
+    sc = torch.empty(M, 1, dtype=torch.float32, device=x2.device)
+    _timed("quant_fp8_rows", 3.0 * M * K, lambda: _lib.call("vgpa_quant_fp8_rows", x2, x2.stride(0), q, sc, M, K, _stream()), "byte")
+    return q, sc
+
+
+class Fp8Weight:
+    """e4m3 copies of a frozen weight W [N, K], one scale per output row, for y = x W^T, and of W^T for dx = dy W; made once
+    (the base weights never change in LoRA training) and kept with the weight tensor."""
+
+    def __init__(self, W):
+        self.version = W._version
+        self.q, self.s = self._rows(W.detach())                 # [N, K], [1, N]
+        self.qt, self.st = self._rows(W.detach().t().contiguous())   # [K, N], [1, K]
+
+    @staticmethod
+    def _rows(w):
+        fmax = torch.finfo(torch.float8_e4m3fn).max
+        amax = w.float().abs().amax(dim=1, keepdim=True)
+        sc = torch.where(amax > 0, amax / fmax, torch.ones_like(amax))
+        return (w.float() / sc).clamp(-fmax, fmax).to(torch.float8_e4m3fn), sc.t().contiguous()
+
+    @staticmethod
+    def of(W):
+        c = getattr(W, "_vgpa_fp8", None)
+        if c is None or c.version != W._version or c.q.device != W.device:
+            c = Fp8Weight(W)
+            W._vgpa_fp8 = c
+        return c
+
+
+def _fp8_gemm(xq, sx, wq, sw, bias=None):
+    """bf16 [M, N] = (xq * sx) (wq * sw)^T through the vendor fp8 GEMM (hipBLASLt); xq [M, K], wq [N, K] e4m3, sx [M, 1], sw [1, N]"""
+    M, N, K = xq.shape[0], wq.shape[0], xq.shape[1]
+    out = []
+    _timed("hipblaslt_gemm_fp8 (vendor)", 2.0 * M * N * K,
+           lambda: out.append(torch._scaled_mm(xq, wq.t(), scale_a=sx, scale_b=sw, bias=bias, out_dtype=torch.bfloat16)))
+    return out[0]
+
+
+class _Fp8FrozenLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        w8 = Fp8Weight.of(W)
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        xq, sx = quant_fp8_rows(x2)
+        ctx.w8 = w8
+        return _fp8_gemm(xq, sx, w8.q, w8.s, bias).view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        w8 = ctx.w8
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
+        dq, sd = quant_fp8_rows(dy2)
+        return _fp8_gemm(dq, sd, w8.qt, w8.st).view(*dy.shape[:-1], w8.qt.shape[0]), None, None
+
+
+def frozen_linear_fp8(x, W, bias):
+    """frozen_linear with e4m3 operands (per-row dynamic activation scales, per-output-row weight scales), bf16 result"""
+    if W.requires_grad or (bias is not None and bias.requires_grad):
+        raise RuntimeError("videogpa_amd: the fp8 path is for frozen projections only")
+    if x.dtype != torch.bfloat16:
+        raise TypeError("frozen_linear_fp8: bf16 activations")
+    return _Fp8FrozenLinearFn.apply(x, W, bias)
+
+
 class _LinearLoraExtFn(torch.autograd.Function):
     """y = x W^T + b (+ LoRA when `enabled`), W / b frozen; see LoraExt.  x / dy are used in place when they are the heads of
     padded buffers (produced by ops.residual_ln / qknorm_attention with n_pad / o_pad / grad pads), copied into one otherwise."""

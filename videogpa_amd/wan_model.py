@@ -216,6 +216,7 @@ class WanAttentionBlock(nn.Module):
         self.norm2 = WanLayerNorm(dim, eps)
         self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+        self.fp8_ffn = False
 
     def forward(self, x, e0, gid, B, L, rope, context):
         """x [B*L, dim]: bf16 in the first block (the patch embedding's output), fp32 afterwards; e0 [G, 6, dim] fp32; -> fp32"""
@@ -229,7 +230,8 @@ class WanAttentionBlock(nn.Module):
             h = ln_mod(x, None, self.norm3.weight.float(), self.norm3.bias.float(), None, None, self.eps)
         x = gate_residual(x, self.cross_attn(h, context, B, L), None, None)
         h = ln_mod(x, gid, None, None, tab[:, 3], tab[:, 4], self.eps)
-        y = ops.frozen_linear(ops.gelu_tanh(ops.frozen_linear(h, self.ffn[0].weight, self.ffn[0].bias)), self.ffn[2].weight, self.ffn[2].bias)
+        lin = ops.frozen_linear_fp8 if self.fp8_ffn else ops.frozen_linear
+        y = lin(ops.gelu_tanh(lin(h, self.ffn[0].weight, self.ffn[0].bias)), self.ffn[2].weight, self.ffn[2].bias)
         return gate_residual(x, y, gid, tab[:, 5])
 
 
@@ -286,6 +288,13 @@ class WanModel(nn.Module):
     def enable_gradient_checkpointing(self, enabled=True):
         """the reference wraps every block's forward in torch.utils.checkpoint (03_train.py:150-159)"""
         self.gradient_checkpointing = enabled
+
+    def enable_fp8(self, enabled=True):
+        """BASELINE.json configs[4] "fp8 MFMA path": the frozen feed-forward projections (61 % of the linear FLOPs per token) take
+        OCP-e4m3 operands -- per-row dynamic activation scales (csrc/fp8.hip), per-output-row weight scales, fp32 accumulation, bf16
+        out, forward and dX.  The LoRA-carrying q/k/v/o projections stay in bf16."""
+        for blk in self.blocks:
+            blk.fp8_ffn = enabled
 
     def _rope_tables(self, grid, device):
         key = (tuple(grid), str(device))
