@@ -140,3 +140,32 @@ def test_wan_model_fp8_feed_forward_stays_close_to_the_oracle():
         _close(out[b], ref[b], f"out[{b}]", tol=0.08, cos_min=0.99)
     for name, mod in lora.items():
         _close(mod.lora_B["default"].weight.grad, leaves[name][1].grad, name + ".B", tol=0.15, cos_min=0.98)
+
+
+def test_wan_adapter_mount_scale_merge_as_the_generate_script_does(tmp_path):
+    """generate/Wan2.2-TI2V-5B.py:53-71: PeftModel.from_pretrained on the engine's model, scaling *= lora_weight, merge_and_unload.  The merged
+    plain model must reproduce the LoRA-active model at that weight (bf16 weight rounding of the merged delta: 3 % of range, cos >= 0.999)."""
+    from videogpa_amd.lora import PeftModel
+    from videogpa_amd.wan_model import WanModel
+    pm, state, lora = _build(seed=7)
+    pm.save_pretrained(str(tmp_path))
+    x, t, ctx, L, gout = _inputs(seed=11)
+    weight = 0.5
+    for mod in lora.values():
+        mod.scaling["default"] *= weight
+    with torch.no_grad():
+        want = pm(x, t=t, context=ctx, seq_len=L)
+    fresh = WanModel(**CFG).to(device="cuda", dtype=torch.bfloat16)
+    fresh.load_state_dict(state)
+    eng = PeftModel.from_pretrained(fresh, str(tmp_path), adapter_name="default", torch_dtype=torch.bfloat16)
+    for module in eng.modules():                                              # the script's own loop (:64-67)
+        if hasattr(module, "scaling") and isinstance(module.scaling, dict):
+            for adapter in module.scaling:
+                module.scaling[adapter] *= weight
+    merged = eng.merge_and_unload()
+    assert not any(type(m).__name__ == "LoraLinear" for m in merged.modules())
+    merged.eval()
+    with torch.no_grad():
+        got = merged(x, t=t, context=ctx, seq_len=L)
+    for b in range(2):
+        _close(got[b], want[b], f"merged out[{b}]", tol=0.03, cos_min=0.999)
