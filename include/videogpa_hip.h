@@ -209,9 +209,12 @@ int32_t vgpa_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, c
  * (train/Wan2.2-TI2V-5B/03_train.py:150-163; WanModel comes from the un-vendored Wan2.2 checkout: 24 heads x 128, text length 512).
  * q, o, d_o, dq: [B, H, Sq, 128] views; k, v, dk, dv: [B, H, Skv, 128] views; *_strides = element strides {batch, head, token},
  * last dim contiguous.  lse2 [B, H, Sq] fp32 = log2-domain log-sum-exp written by the forward.  delta: fp32 scratch [B*H*Sq]. */
+/* With a workspace (vgpa_attn128_fwd_workspace_bytes) and Skv >= 1024 the forward runs on the one-wave-per-SIMD / LDS-DMA structure
+ * (row-bound softmax shift, flagged strips redone with a running max); workspace NULL: the compiler-scheduled kernel. */
+size_t vgpa_attn128_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq);
 int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                          const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
-                         vgpa_stream_t stream);
+                         void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
                          void* dv, float* delta, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                          const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,

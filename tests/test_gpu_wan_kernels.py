@@ -46,6 +46,55 @@ def test_attention128_forward_backward_vs_fp64(B, H, Sq, Skv):
     _close(vg.grad, rv, "dv")
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 256, 1024), (1, 3, 700, 1500), (2, 2, 1030, 1091), (1, 1, 64, 4096)])
+def test_attention128_w1_forward_long_keys_vs_fp64(B, H, Sq, Skv):
+    """Skv >= 1024: the forward runs on the one-wave-per-SIMD / LDS-DMA kernel (row-bound shift, generated loop); ragged query and key tails"""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(Sq + Skv)
+    q = torch.randn(B, H, Sq, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(B, H, Skv, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(B, H, Skv, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(B, H, Sq, 128, device="cuda", generator=g).bfloat16()
+    scale = 128 ** -0.5
+    qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o = ops.attention128(qg, kg, vg, scale)
+    o.backward(do)
+    ro, rq, rk, rv = _ref(q, k, v, do, scale)
+    _close(o, ro, "o")
+    _close(qg.grad, rq, "dq")
+    _close(kg.grad, rk, "dk")
+    _close(vg.grad, rv, "dv")
+    # the log-sum-exp the backward consumed: recompute the forward's lse2 through a second call and compare P row sums implicitly via dv above;
+    # and the two forward kernels agree with each other
+    import os
+    ops.ATTN128_W1 = False
+    try:
+        o2 = ops.attention128(q, k, v, scale)
+    finally:
+        ops.ATTN128_W1 = True
+    assert (o.float() - o2.float()).abs().max().item() <= 2 ** -7 * ro.abs().max().item()
+
+
+def test_attention128_w1_outlier_rows_take_the_redo_path():
+    """a query row 40x larger than the rest: its bound M exceeds 160 -> the strip is flagged and redone with the running-max kernel; a key
+    40x larger makes EVERY bound loose (sums underflow) -> all strips redone.  Results must stay within the usual tolerance either way."""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(77)
+    B, H, Sq, Skv = 1, 2, 600, 1200
+    for which in ("q", "k"):
+        q = torch.randn(B, H, Sq, 128, device="cuda", generator=g).bfloat16()
+        k = torch.randn(B, H, Skv, 128, device="cuda", generator=g).bfloat16()
+        v = torch.randn(B, H, Skv, 128, device="cuda", generator=g).bfloat16()
+        if which == "q":
+            q[0, 0, 300] *= 40
+        else:
+            k[0, 1, 17] *= 40
+        o = ops.attention128(q, k, v, 128 ** -0.5)
+        ro = torch.softmax((q.double() @ k.double().transpose(-1, -2)) * 128 ** -0.5, dim=-1) @ v.double()
+        assert torch.isfinite(o).all()
+        _close(o, ro, "o " + which)
+
+
 def test_attention128_strided_views_and_sharp_softmax():
     """[B, S, H, 128] storage viewed as [B, H, S, 128] (how the projection leaves q/k/v), and scores large enough that the running max
     moves tile to tile (scale 1.0 on unit-variance rows of 128: |s| up to ~40)."""

@@ -632,6 +632,155 @@ class FwdLoop:
         return em.text() + "\n"
 
 
+# ------------------------------------------------------------------------------------------------------- forward, head_dim 128
+class Fwd128Loop:
+    """FwdLoop for head_dim 128 (csrc/attention_hd128.hip, the Wan2.2 shapes): same pipeline -- half-step(g) issues C(g-1) | A(g+1) | B(g)
+       on 32-key half-tiles, two q-blocks per wave, row-bound shift, fp32 row sums -- with
+         A(g): S[g&1][j] = -M[q] + K_g Q_j^T       16 MFMAs (8 k-steps x 2 q-blocks)
+         C(g): O^T[j][db] += V_g^T P               16 MFMAs (2 key sub-blocks x 4 d-blocks x 2 q-blocks)
+         B(g): 80 VALU, as at head_dim 64: the loop is MFMA-bound here (2.5 VALU per MFMA, was 5).
+       LDS ring slot = [K tile 64 x 128 | V tile] = 32 KiB, 4 slots; rows are 256 B = 16 chunks stored at c ^ f(r),
+       f(r) = ((r & 3) << 2) | ((r >> 2) & 3): the b128 row reads (16 lanes = 16 rows, one logical chunk) and the transpose reads
+       (32 lanes = 4 rows x 4 chunks x 2 halves) are both conflict-free.  ds offsets are 16 bit: lane offsets exist per slot PAIR.
+       register map   a[0:127] O[j][db]   a[128:191] qf[j][ks]   a[192:255] fragment ring (16 x 4)
+                      v[0:63] S[p][j]   v[64:95] PK[p][j][cc]   v[96:127] srcC tuples   v[128:135] l[j][0..3]   v136 v137 -M[q]
+                      v[144:175] lane LDS offsets [slot pair][K rows ks 0..7 | V transposed (db, second read) 0..7]
+                      v[176:183] LDS-DMA source offsets (K x4, V x4)   v184 4 * (lane >> 5)   v185 -inf"""
+
+    LA = 144
+    VOFF = 176
+    HI4 = 184
+    NINF = 185
+    FR = 192
+    LEAD = KNOB.get("lead", 6)
+
+    def S(self, p, j):
+        return p * 32 + j * 16
+
+    def PK(self, p, j, cc):
+        return 64 + p * 16 + j * 8 + cc * 4
+
+    def frag_reg(self, f):
+        return self.FR + 4 * f
+
+    def issue_frag(self, em, f, slotA, kbA, slotC, kbC, tag=None):
+        """f 0..7: transposed V fragments (cc, db) = (f >> 2, f & 3) of the PREVIOUS half; 8..15: K rows ks = f - 8"""
+        tag = f if tag is None else tag
+        r = self.frag_reg(f)
+        if f < 8:
+            cc, db = f >> 2, f & 3
+            base = self.LA + 16 * (slotC >> 1) + 8 + 2 * db
+            off = (slotC & 1) * 32768 + 16384 + kbC * 8192 + cc * 4096
+            em.ds(f"ds_read_b64_tr_b16 {ar(r, 2)}, v{base} offset:{off}", tag)
+            em.ds(f"ds_read_b64_tr_b16 {ar(r + 2, 2)}, v{base + 1} offset:{off}", tag)
+        else:
+            base = self.LA + 16 * (slotA >> 1) + (f - 8)
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{base} offset:{(slotA & 1) * 32768 + kbA * 8192}", tag)
+
+    def mfmas(self, pa, pc):
+        out = []
+        for c in range(8):
+            cc, db = c >> 2, c & 3
+            for j in range(2):
+                d = ar(64 * j + 16 * db, 16)
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(c), 4)}, {vr(self.PK(pc, j, cc), 4)}, {d}", c))
+        for ks in range(8):
+            for j in range(2):
+                d = vr(self.S(pa, j), 16)
+                c = vr(96 + 16 * j, 16) if ks == 0 else d
+                out.append((f"{MFMA} {d}, {ar(self.frag_reg(8 + ks), 4)}, {ar(128 + 32 * j + 4 * ks, 4)}, {c}", 8 + ks))
+        return out
+
+    def valu_ops(self, pb):
+        """as FwdLoop.valu_ops plus the softmax scale: S holds q.k - M / c (q arrives UNscaled here: the backward kernels of
+        attention_hd128.hip read the same q), so one v_mul by c = scale * log2(e) (an SGPR) precedes each exp"""
+        if "novalu" in ABLATE:
+            return []
+
+        def unit(u):
+            j, p = u >> 3, u & 7
+            s0 = self.S(pb, j) + 2 * p
+            w = self.PK(pb, j, p >> 2) + (p & 3)
+            l0, l1 = 128 + 4 * j + ((2 * p) & 3), 128 + 4 * j + ((2 * p + 1) & 3)
+            return ([f"v_mul_f32 v{s0}, %[cs], v{s0}", f"v_mul_f32 v{s0 + 1}, %[cs], v{s0 + 1}", f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                    [f"v_add_f32 v{l0}, v{l0}, v{s0}", f"v_add_f32 v{l1}, v{l1}, v{s0 + 1}"],
+                    f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
+        ops = list(unit(0)[0])
+        for t in range(16):
+            x = unit(t + 1)[0] if t + 1 < 16 else [None] * 4
+            m = unit(t)[1]
+            ops += [o for o in (x[0], m[0], x[1], x[2], m[1], x[3], unit(t)[2]) if o is not None]
+        return ops
+
+    def mask_block(self, em, kb, krem, tmp, label):
+        em.raw(f"s_cmp_ge_i32 {krem}, 64")
+        em.raw(f"s_cbranch_scc1 {label}")
+        for r in range(16):
+            rowc = (r & 3) + 8 * (r >> 2) + 32 * kb
+            em.raw(f"s_sub_i32 {tmp}, {krem}, {rowc}")
+            em.raw(f"v_cmp_lt_i32 vcc, v{self.HI4}, {tmp}")
+            for j in range(2):
+                em.raw(f"v_cndmask_b32 v{96 + 16 * j + r}, v{self.NINF}, v{136 + j}, vcc")
+        em.raw(f"{label}:")
+
+    def half_step(self, em, slotA, kbA, slotC, kbC, pa, nxt, fill_first=()):
+        need = {f: 2 * f for f in range(16)}
+        post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
+        em.retag({("n", f): f for f in range(4)})
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+                 pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT, KREM, TMP = "%0", "%1", "%2", "%3"
+        RK, RV, KSTEP, VSTEP, WBASE, NITER, KREM0 = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]", "%[krem]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        em.raw(f"s_mov_b32 {KREM}, {KREM0}")
+        for i in range(128):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        em.raw(f"v_mov_b32 v{self.NINF}, 0xff800000")
+        for r in range(32, 64):
+            em.raw(f"v_mov_b32 v{r}, v{self.NINF}")
+        for r in list(range(64, 80)) + list(range(128, 136)):
+            em.raw(f"v_mov_b32 v{r}, 0")
+        for j in range(2):
+            for r in range(16):
+                em.raw(f"v_mov_b32 v{96 + 16 * j + r}, v{136 + j}")
+        for f in range(4):
+            self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        em.raw("L_w1f128_loop_%=:")
+        for ph in range(4):
+            em.raw("s_waitcnt vmcnt(8)")
+            if "nosync" not in ABLATE:
+                em.raw("s_barrier")
+            dst = ((ph + 2) & 3) * 32768
+            fill = []
+            for k in range(8):
+                isV = k >= 4
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + (16384 if isV else 0) + (k & 3) * 1024}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {RV if isV else RK}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {VSTEP if isV else KSTEP}, v{self.VOFF + k}"])
+            sp = (ph - 1) & 3
+            self.mask_block(em, 0, KREM, TMP, f"L_w1f128_m{2 * ph}_%=")
+            self.half_step(em, ph, 0, sp, 0, 0, nxt=(sp, 1), fill_first=fill)
+            self.mask_block(em, 1, KREM, TMP, f"L_w1f128_m{2 * ph + 1}_%=")
+            self.half_step(em, ph, 1, sp, 1, 1, nxt=(ph, 0))
+            em.raw(f"s_sub_i32 {KREM}, {KREM}, 64")
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if ph < 3:
+                em.raw("s_cbranch_scc1 L_w1f128_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1f128_loop_%=")
+        em.raw("L_w1f128_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 # --------------------------------------------------------------------------------------------------------------------- GEMM loop
 class GemmLoop:
     """C^T tile = W A^T for a 256 (M) x 128 (N) output tile, operands both K-contiguous (x [M, K], W [N, K]: y = x W^T), BK = 64 per
@@ -722,6 +871,8 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_dq_clobbers.inc": lambda: clobbers([(0, 159)], [(128, 151)]),
            "w1_dkv_loop.inc": lambda: DkvLoop().generate(),
            "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)]),
+           "w1_fwd128_loop.inc": lambda: Fwd128Loop().generate(),
+           "w1_fwd128_clobbers.inc": lambda: clobbers([(0, 127), (185, 185)], [(192, 255)]),
            "w1_gemm_loop.inc": lambda: GemmLoop().generate(),
            "w1_gemm_clobbers.inc": lambda: clobbers([], [(128, 175)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),

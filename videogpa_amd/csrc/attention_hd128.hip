@@ -71,9 +71,11 @@ __device__ __forceinline__ void store_col128(bf16_t* row_ptr, const f32x16_t (&a
 // ===================================================================================================== forward
 __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                bf16_t* __restrict__ O, float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
-                                                               int Sq, int Skv, int H, int n_qt, float c) {
+                                                               int Sq, int Skv, int H, int n_qt, float c, const int* __restrict__ only_flagged) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][T128];
     const int bh = blockIdx.x / n_qt, qt = blockIdx.x % n_qt;
+    // redo pass of the w1 forward: flags are per 256-row strip (= two of this kernel's 128-row tasks)
+    if (only_flagged && !only_flagged[bh * ((n_qt + 1) / 2) + (qt >> 1)]) return;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, hi = lane >> 5, wave = threadIdx.x >> 6;
     const int q0 = qt * 128 + wave * 32;
@@ -159,6 +161,176 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(const bf16_t* __res
         store_col128(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), o, 1.f / l, hi);
         if (hi == 0) LSE2[(size_t)bh * Sq + q] = m + __builtin_amdgcn_logf(l);   // v_log_f32 is log2
     }
+}
+
+// ----------------------------------------------------------------------------------------------------- forward, w1 structure
+// The forward on the one-wave-per-SIMD structure of attention_w1.hip at head_dim 128: 4 waves x 2 q-blocks
+// = 256 query rows per workgroup, K/V tiles [64 x 128] by LDS-DMA into a 4-slot ring of 32 KiB slots, main loop from
+// tools/gen_w1_asm.py::Fwd128Loop (w1_fwd128_loop.inc: pipeline, LDS image and register map in its docstring).  Softmax shift = the
+// row bound M[q] = c |q| max|k| (attn128_kmax_kernel), strips that underflow / overflow / are not finite are flagged and redone by
+// attn128_fwd_kernel.
+#include "attn_w1.h"
+
+typedef __attribute__((ext_vector_type(16))) uint32_t u32x16_t;
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
+#define W1H_TILE_BYTES 16384
+#define W1H_SLOT_BYTES 32768
+#define W1H_RING_BYTES (4 * W1H_SLOT_BYTES)
+#define W1H_L_MIN 7.888609052210118e-31f   // 2^-100
+#define W1H_M_MAX 160.0f
+
+__device__ __forceinline__ uint32_t w1h_swz(uint32_t r) { return ((r & 3u) << 2) | ((r >> 2) & 3u); }
+
+__global__ __launch_bounds__(256) void attn128_kmax_kernel(const bf16_t* __restrict__ K, TStride sk, int S, int H, unsigned* __restrict__ kmax2) {
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)S * 16; i += (int64_t)gridDim.x * 256) {   // 16 lanes per row
+        const int row = (int)(i >> 4), c16 = (int)(i & 15);
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(Kb + ((size_t)row * sk.s + c16 * 8)), f);
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += f[j] * f[j];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        a += __shfl_xor(a, 8, 64);
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax(kmax2 + bh, __float_as_uint(mx));
+}
+
+__device__ __forceinline__ u32x16_t pack4h(const bf16x8_t& a, const bf16x8_t& b, const bf16x8_t& c, const bf16x8_t& d) {
+    const u32x4_t w[4] = {__builtin_bit_cast(u32x4_t, a), __builtin_bit_cast(u32x4_t, b), __builtin_bit_cast(u32x4_t, c), __builtin_bit_cast(u32x4_t, d)};
+    u32x16_t r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = w[i >> 2][i & 3];
+    return r;
+}
+
+__global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                                  bf16_t* __restrict__ O, float* __restrict__ LSE2, const unsigned* __restrict__ KMAX2,
+                                                                  int* __restrict__ flags, TStride sq, TStride sk, TStride sv, TStride so, int Sq, int Skv,
+                                                                  int H, int n_qt, float c) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[W1H_RING_BYTES];   // slot = [K tile | V tile]
+    const int vid = blockIdx.x;
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int q0 = (qt * 4 + wave) * 64;
+
+    bf16x8_t qf[2][8];
+    float nmc[2];    // -M[q] / c: the srcC of the score chains (the loop multiplies by c)
+    const float kmax = sqrtf(__uint_as_float(KMAX2[bh]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) load_row_frags128(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0 + 32 * j, Sq, lane, qf[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            asm volatile("" ::"v"(qf[j][ks]));
+            float f[8];
+            unpack8(__builtin_bit_cast(u32x4_t, qf[j][ks]), f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += f[i] * f[i];
+        }
+        a += other_half(a);
+        nmc[j] = -(sqrtf(a) * kmax * 1.0009765625f);
+    }
+    const int nt = (Skv + 63) / 64;
+    {   // the pipeline's first transposed reads hit the V tile of ring slot 3: make it finite
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(lds + 3 * W1H_SLOT_BYTES + W1H_TILE_BYTES + i * 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
+    const W1Rsrc krs = w1_rsrc(Kb, ((uint32_t)(Skv - 1) * sk.s + (uint32_t)D128) * 2u);
+    const W1Rsrc vrs = w1_rsrc(Vb, ((uint32_t)(Skv - 1) * sv.s + (uint32_t)D128) * 2u);
+    // this wave moves pieces 4 wave .. 4 wave + 3 of a tile: piece p = rows 4p .. 4p+3; lane -> (row 4p + lane / 16, LDS chunk lane % 16)
+    u32x8_t voff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t row = 4u * (uint32_t)(wave * 4 + i) + (uint32_t)(lane >> 4);
+        const uint32_t cl = (uint32_t)(lane & 15) ^ w1h_swz(row);
+        voff[i] = (row * sk.s + cl * 8u) * 2u;
+        voff[4 + i] = (row * sv.s + cl * 8u) * 2u;
+    }
+    const uint32_t kstep = __builtin_amdgcn_readfirstlane(64u * sk.s * 2u), vstep = __builtin_amdgcn_readfirstlane(64u * sv.s * 2u);
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds + (uint32_t)wave * 4096u);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {   // tiles 0, 1 -> ring slots 0, 1
+        const uint32_t dst = wbase + (uint32_t)t * W1H_SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w1_dma(dst + 1024u * i, krs, voff[i], 0u);
+            w1_dma(dst + W1H_TILE_BYTES + 1024u * i, vrs, voff[4 + i], 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { voff[i] += kstep; voff[4 + i] += vstep; }
+    }
+    // lane-constant LDS read offsets, one set per slot pair (ds offsets are 16 bit)
+    u32x16_t la[2];
+    {
+        const uint32_t m = lane & 31;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) la[st][ks] = st * 65536u + m * 256u + ((((uint32_t)(2 * ks) + (uint32_t)hi) ^ w1h_swz(m)) << 4);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r3 = 0; r3 < 2; ++r3) {
+                    const uint32_t rr = 4u * hi + ((uint32_t)(lane & 15) >> 2) + 8u * r3;
+                    const uint32_t cc = 4u * db + 2u * ((uint32_t)(lane >> 4) & 1u) + (((uint32_t)lane & 3u) >> 1);
+                    la[st][8 + 2 * db + r3] = st * 65536u + rr * 256u + ((cc ^ w1h_swz(rr)) << 4) + ((uint32_t)lane & 1u) * 8u;
+                }
+        }
+    }
+    const u32x16_t q00 = pack4h(qf[0][0], qf[0][1], qf[0][2], qf[0][3]), q01 = pack4h(qf[0][4], qf[0][5], qf[0][6], qf[0][7]);
+    const u32x16_t q10 = pack4h(qf[1][0], qf[1][1], qf[1][2], qf[1][3]), q11 = pack4h(qf[1][4], qf[1][5], qf[1][6], qf[1][7]);
+    const uint32_t niter = (uint32_t)(nt + 1);     // one extra tile step drains the pipeline
+    const uint32_t krem = (uint32_t)Skv;
+    const uint32_t hi4 = 4u * (uint32_t)hi;
+    const uint32_t cs = __builtin_amdgcn_readfirstlane(__float_as_uint(c));
+    f32x16_t o[2][4];
+    u32x8_t lv;
+    uint32_t t0, t1, t2, t3;
+    asm volatile(
+#include "w1_fwd128_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "={a[0:15]}"(o[0][0]), "={a[16:31]}"(o[0][1]), "={a[32:47]}"(o[0][2]), "={a[48:63]}"(o[0][3]),
+          "={a[64:79]}"(o[1][0]), "={a[80:95]}"(o[1][1]), "={a[96:111]}"(o[1][2]), "={a[112:127]}"(o[1][3]), "={v[128:135]}"(lv), "+{v[176:183]}"(voff)
+        : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [krem] "s"(krem), [cs] "s"(cs),
+          "{a[128:143]}"(q00), "{a[144:159]}"(q01), "{a[160:175]}"(q10), "{a[176:191]}"(q11), "{v136}"(nmc[0]), "{v137}"(nmc[1]), "{v[144:159]}"(la[0]),
+          "{v[160:175]}"(la[1]), "{v184}"(hi4)
+        : "memory", "scc", "vcc",
+#include "w1_fwd128_clobbers.inc"
+    );
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) asm volatile("" : "+v"(o[j][db]));
+
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float a = (__uint_as_float(lv[4 * j]) + __uint_as_float(lv[4 * j + 1])) + (__uint_as_float(lv[4 * j + 2]) + __uint_as_float(lv[4 * j + 3]));
+        const float l = a + other_half(a);
+        const float M = -nmc[j] * c;
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < Sq) {
+            bad = bad || !(l >= W1H_L_MIN && l < INFINITY) || !(M <= W1H_M_MAX);
+            store_col128(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), o[j], 1.f / l, hi);
+            if (hi == 0) LSE2[(size_t)bh * Sq + q] = M + __builtin_amdgcn_logf(l);
+        }
+    }
+    if (__any(bad) && lane == 0) flags[vid] = 1;
 }
 
 // ===================================================================================================== backward
@@ -355,16 +527,40 @@ static inline TStride mk128(const int64_t* st) { TStride t; t.b = (uint32_t)st[0
 static inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 #define LOG2E_F 1.4426950408889634f
 
+// workspace of the w1 forward: per (batch, head) max |k|^2 and one redo flag per 256-row strip
+extern "C" size_t vgpa_attn128_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq) {
+    if (B <= 0 || H <= 0 || Sq <= 0) return 0;
+    return (size_t)(B * H) * 4 + (size_t)(B * H * ((Sq + 255) / 256)) * 4;
+}
+
+// workspace NULL (or too few keys for the pipeline to pay): the compiler-scheduled kernel
+#define ATTN128_W1_MIN_KEYS 1024
 extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                                     const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
-                                    hipStream_t stream) {
+                                    void* workspace, size_t ws_bytes, hipStream_t stream) {
     if (!q || !k || !v || !o || !lse2 || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
     if (!sok128(q_strides) || !sok128(k_strides) || !sok128(v_strides) || !sok128(o_strides) || !a16(q) || !a16(k) || !a16(v) || !a16(o)) return VGPA_ERR_INVALID;
     if (!rok128(q_strides, B, H, Sq) || !rok128(k_strides, B, H, Skv) || !rok128(v_strides, B, H, Skv) || !rok128(o_strides, B, H, Sq)) return VGPA_ERR_INVALID;
     const int64_t n_qt = (Sq + 127) / 128, tasks = B * H * n_qt;
     if (tasks >= ((int64_t)1 << 31)) return VGPA_ERR_INVALID;
+    const float c = scale * LOG2E_F;
+    if (workspace && Skv >= ATTN128_W1_MIN_KEYS) {
+        if (ws_bytes < vgpa_attn128_fwd_workspace_bytes(B, H, Sq) || ((uintptr_t)workspace & 3)) return VGPA_ERR_WORKSPACE;
+        const int64_t n_q256 = (Sq + 255) / 256, tasks256 = B * H * n_q256;
+        unsigned* kmax2 = (unsigned*)workspace;
+        int* flags = (int*)workspace + B * H;
+        if (hipMemsetAsync(workspace, 0, vgpa_attn128_fwd_workspace_bytes(B, H, Sq), stream) != hipSuccess) return VGPA_ERR_LAUNCH;
+        VGPA_LAUNCH(attn128_kmax_kernel, dim3(16, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)k, mk128(k_strides), (int)Skv, (int)H, kmax2);
+        VGPA_LAUNCH(attn128_fwd_w1_kernel, dim3((unsigned)tasks256), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
+                    (const unsigned*)kmax2, flags, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_q256, c);
+        // flagged strips again, with the running-max kernel (exits at once for unflagged ones)
+        VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
+                    mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags);
+        VGPA_CHECK_LAUNCH();
+        return VGPA_OK;
+    }
     VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
-                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, scale * LOG2E_F);
+                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)nullptr);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

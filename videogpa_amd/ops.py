@@ -788,6 +788,9 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
         _bhs_strides(dq), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
 
 
+ATTN128_W1 = _os.environ.get("VGPA_ATTN128_W1", "1") == "1"    # 0: the compiler-scheduled hd128 forward everywhere
+
+
 class _Attention128Fn(torch.autograd.Function):
     """softmax(scale q k^T) v for head_dim 128, query and key lengths free (csrc/attention_hd128.hip): Wan2.2's self- and cross-attention"""
 
@@ -799,8 +802,11 @@ class _Attention128Fn(torch.autograd.Function):
         q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
         o = torch.empty(B, H, Sq, D, dtype=torch.bfloat16, device=q.device)
         lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
-        _timed("attn128_fwd", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-            "vgpa_attn128_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale), _stream()))
+        ws_bytes = _lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, Sq) if ATTN128_W1 else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
+        _timed("attn128_fwd" if Skv >= 1024 else "attn128_fwd (short keys)", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+            "vgpa_attn128_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale),
+            ws, ws_bytes, _stream()))
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale = float(scale)
         return o
@@ -813,7 +819,7 @@ class _Attention128Fn(torch.autograd.Function):
         do = do if do.stride(3) == 1 else do.contiguous()
         dq, dk, dv = torch.empty_like(o), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device)
         delta = torch.empty(B * H * Sq, dtype=torch.float32, device=q.device)
-        _timed("attn128_bwd", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+        _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
             "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, delta, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
             _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, ctx.scale, _stream()))
         return dq, dk, dv, None
