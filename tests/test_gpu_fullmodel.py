@@ -145,6 +145,8 @@ def test_cfg5_wan22_ti2v_5b_full_size_pair_step():
     after one optimizer step the policy has moved and the loss is still finite.  44 GB."""
     from videogpa_amd.wan import WanDPOTrainer
     from videogpa_amd.wan_model import WanModel
+    import gc
+    gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
     torch.manual_seed(0)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.bfloat16)
