@@ -208,17 +208,21 @@ int32_t vgpa_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, c
 /* ---- head_dim-128 attention with separate query / key lengths: the self- and cross-attention of the Wan2.2-TI2V-5B denoiser
  * (train/Wan2.2-TI2V-5B/03_train.py:150-163; WanModel comes from the un-vendored Wan2.2 checkout: 24 heads x 128, text length 512).
  * q, o, d_o, dq: [B, H, Sq, 128] views; k, v, dk, dv: [B, H, Skv, 128] views; *_strides = element strides {batch, head, token},
- * last dim contiguous.  lse2 [B, H, Sq] fp32 = log2-domain log-sum-exp written by the forward.  delta: fp32 scratch [B*H*Sq]. */
+ * last dim contiguous.  lse2 [B, H, Sq] fp32 = log2-domain log-sum-exp written by the forward. */
 /* With a workspace (vgpa_attn128_fwd_workspace_bytes) and Skv >= 1024 the forward runs on the one-wave-per-SIMD / LDS-DMA structure
  * (row-bound softmax shift, flagged strips redone with a running max); workspace NULL: the compiler-scheduled kernel. */
 size_t vgpa_attn128_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq);
 int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                          const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
                          void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* workspace (vgpa_attn128_bwd_workspace_bytes): delta + the statistics planes.  dkv_mode -1 = automatic (w1 dK/dV kernel from 1024 queries on),
+ * 0 = compiler-scheduled kernel, 1 = w1 kernel */
+size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq);
 int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
-                         void* dv, float* delta, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                         void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                          const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
-                         const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, vgpa_stream_t stream);
+                         const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, int32_t dkv_mode, void* workspace,
+                         size_t ws_bytes, vgpa_stream_t stream);
 
 /* ---- row kernels of the Wan2.2 denoiser block (WanAttentionBlock / WanRMSNorm / rope_apply of the Wan2.2 checkout imported at
  * train/Wan2.2-TI2V-5B/03_train.py:43-48).  fp32 residual stream, bf16 matmul operands.  Per-token modulation as a table: row

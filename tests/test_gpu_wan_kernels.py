@@ -46,7 +46,7 @@ def test_attention128_forward_backward_vs_fp64(B, H, Sq, Skv):
     _close(vg.grad, rv, "dv")
 
 
-@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 256, 1024), (1, 3, 700, 1500), (2, 2, 1030, 1091), (1, 1, 64, 4096)])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 256, 1024), (1, 3, 700, 1500), (2, 2, 1030, 1091), (1, 1, 64, 4096), (1, 2, 1500, 1024), (1, 1, 2048, 130)])
 def test_attention128_w1_forward_long_keys_vs_fp64(B, H, Sq, Skv):
     """Skv >= 1024: the forward runs on the one-wave-per-SIMD / LDS-DMA kernel (row-bound shift, generated loop); ragged query and key tails"""
     from videogpa_amd import ops

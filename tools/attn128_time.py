@@ -1,0 +1,40 @@
+"""Timing of the head_dim-128 attention entry points at the Wan2.2 self-attention shape (B*H = 24, S = 18480), per kernel family:
+forward (w1 / compiler-scheduled), backward with the dK/dV kernel in either form.   gpurun -- 'PYTHONPATH=. python tools/attn128_time.py'"""
+import torch
+from videogpa_amd import _lib, ops
+
+B, H, S, D = 1, 24, 18480, 128
+g = torch.Generator(device="cuda").manual_seed(0)
+q, k, v, do = (torch.randn(B, H, S, D, device="cuda", generator=g).bfloat16() for _ in range(4))
+st = lambda t: ops._bhs_strides(t)
+stream = torch.cuda.current_stream().cuda_stream
+o = torch.empty_like(q); lse = torch.empty(B, H, S, dtype=torch.float32, device="cuda")
+dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+wsf = torch.empty(_lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, S), dtype=torch.uint8, device="cuda")
+wsb = torch.empty(_lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, S), dtype=torch.uint8, device="cuda")
+scale = D ** -0.5
+
+
+def fwd(w1):
+    _lib.call("vgpa_attn128_fwd", q, k, v, o, lse, st(q), st(k), st(v), st(o), B, H, S, S, scale, wsf if w1 else None, wsf.numel() if w1 else 0, stream)
+
+
+def bwd(mode):
+    _lib.call("vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv), B, H, S, S, scale, mode, wsb, wsb.numel(), stream)
+
+
+def timeit(fn, n=5):
+    fn(); fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+ff = 4.0 * B * H * S * S * D
+for name, fn, fl in [("fwd w1", lambda: fwd(True), ff), ("fwd simple", lambda: fwd(False), ff), ("bwd (dq simple + dkv w1)", lambda: bwd(1), 2.5 * ff),
+                     ("bwd (dq simple + dkv simple)", lambda: bwd(0), 2.5 * ff)]:
+    t = timeit(fn)
+    print(f"{name:32s} {t:8.3f} ms   {fl / t / 1e9:7.0f} TFLOP/s algorithmic")

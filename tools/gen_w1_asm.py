@@ -781,6 +781,157 @@ class Fwd128Loop:
         return em.text() + "\n"
 
 
+# ---------------------------------------------------------------------------------------------------------- dK, dV, head_dim 128
+class Dkv128Loop:
+    """DkvLoop for head_dim 128 (csrc/attention_hd128.hip): ONE 32-key block per wave -- dK^T, dV^T (4 d-blocks each) and the K, V
+       fragments (8 k-steps each) already take 192 AGPRs -- streaming 64-row Q|dO tiles; per 32-row half-tile g:
+         A(g): S[g&1] = -lse2[q] / c + Q_g K^T,  DP[g&1] = -delta[q] + dO_g V^T        16 MFMAs (8 k-steps each); q unscaled, so
+         B(g): P = exp2(c S) -> PK (bf16), dS = P * DP -> DSK (bf16)                    64 VALU (16 of them the v_mul by c)
+         C(g): dV^T[db] += dO_g^T P,  dK^T[db] += Q_g^T dS                              16 MFMAs on transpose-read fragments
+       Every streamed fragment feeds one MFMA here (two at head_dim 64): the loop needs one 1 KiB LDS read per MFMA and is bound by
+       LDS bandwidth, not by the matrix pipe.
+       LDS: ring slot s at 32768 s = [Q tile 64 x 128 | dO tile], rows swizzled as in Fwd128Loop; statistics of slot s at
+       131072 + 1024 s (layout as DkvLoop).
+       register map   a[0:63] dk[db]  a[64:127] dv[db]  a[128:159] kf[ks]  a[160:191] vf[ks]  a[192:255] fragment ring (16 x 4)
+                      v[0:63] S / DP [p] (s dp)   v[64:95] PK / DSK [p][cc]   v[96:111] srcC -lse2/c   v[112:127] srcC -delta
+                      v[128:159] lane LDS offsets [slot pair][rows ks 0..7 | transposed (db, second read) 0..7]
+                      v[160:167] LDS-DMA source offsets (Q x4, dO x4)   v168 statistics source offset   v169 statistics read base"""
+
+    LA = 128
+    VOFF = 160
+    SB = 169
+    FR = 192
+    LEAD = KNOB.get("lead", 6)
+
+    def S(self, p):
+        return p * 32
+
+    def DP(self, p):
+        return p * 32 + 16
+
+    def PK(self, p, cc):
+        return 64 + p * 16 + cc * 4
+
+    def DSK(self, p, cc):
+        return 64 + p * 16 + 8 + cc * 4
+
+    def frag_reg(self, f):
+        return self.FR + 4 * (f % 16)
+
+    def issue_frag(self, em, f, slotA, qbA, slotC, qbC, tag=None):
+        """f 0..15: transposed fragments of the PREVIOUS half (even: dO tile, odd: Q tile; (cc, db) = (f >> 3, (f >> 1) & 3));
+        16..23: Q rows ks; 24..31: dO rows ks; "cs" / "cd": the srcC tuples"""
+        tag = f if tag is None else tag
+        if f == "cs" or f == "cd":
+            base = 96 if f == "cs" else 112
+            for g in range(4):
+                off = slotA * 1024 + 512 * qbA + 256 * (g >> 1) + 32 * (g & 1) + (64 if f == "cd" else 0)
+                em.ds(f"ds_read_b128 {vr(base + 4 * g, 4)}, v{self.SB} offset:{off}", tag)
+            return
+        r = self.frag_reg(f)
+        if f < 16:
+            c = f >> 1
+            cc, db = c >> 2, c & 3
+            base = self.LA + 16 * (slotC >> 1) + 8 + 2 * db
+            off = (slotC & 1) * 32768 + (16384 if (f & 1) == 0 else 0) + qbC * 8192 + cc * 4096
+            em.ds(f"ds_read_b64_tr_b16 {ar(r, 2)}, v{base} offset:{off}", tag)
+            em.ds(f"ds_read_b64_tr_b16 {ar(r + 2, 2)}, v{base + 1} offset:{off}", tag)
+        else:
+            isdo = f >= 24
+            ks = (f - 16) & 7
+            base = self.LA + 16 * (slotA >> 1) + ks
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{base} offset:{(slotA & 1) * 32768 + (16384 if isdo else 0) + qbA * 8192}", tag)
+
+    def mfmas(self, pa, pc):
+        out = []
+        for f in range(16):
+            c = f >> 1
+            cc, db = c >> 2, c & 3
+            if (f & 1) == 0:
+                d, b = ar(64 + 16 * db, 16), vr(self.PK(pc, cc), 4)
+            else:
+                d, b = ar(16 * db, 16), vr(self.DSK(pc, cc), 4)
+            out.append((f"{MFMA} {d}, {ar(self.frag_reg(f), 4)}, {b}, {d}", f))
+        for ks in range(8):
+            d = vr(self.S(pa), 16)
+            c = vr(96, 16) if ks == 0 else d
+            out.append((f"{MFMA} {d}, {ar(self.frag_reg(16 + ks), 4)}, {ar(128 + 4 * ks, 4)}, {c}", 16 + ks))
+        for ks in range(8):
+            d = vr(self.DP(pa), 16)
+            c = vr(112, 16) if ks == 0 else d
+            out.append((f"{MFMA} {d}, {ar(self.frag_reg(24 + ks), 4)}, {ar(160 + 4 * ks, 4)}, {c}", 24 + ks))
+        return out
+
+    def valu_ops(self, pb):
+        if "novalu" in ABLATE:
+            return []
+
+        def unit(p):
+            s0, d0 = self.S(pb) + 2 * p, self.DP(pb) + 2 * p
+            wp, wd = self.PK(pb, p >> 2) + (p & 3), self.DSK(pb, p >> 2) + (p & 3)
+            return ([f"v_mul_f32 v{s0}, %[cs], v{s0}", f"v_mul_f32 v{s0 + 1}, %[cs], v{s0 + 1}", f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                    [f"v_mul_f32 v{d0}, v{d0}, v{s0}", f"v_mul_f32 v{d0 + 1}, v{d0 + 1}, v{s0 + 1}"],
+                    [f"v_cvt_pk_bf16_f32 v{wp}, v{s0}, v{s0 + 1}", f"v_cvt_pk_bf16_f32 v{wd}, v{d0}, v{d0 + 1}"])
+        ops = list(unit(0)[0])
+        for t in range(9):
+            x = unit(t + 1)[0] if t + 1 < 8 else [None] * 4
+            m = unit(t)[1] if t < 8 else [None, None]
+            c = unit(t - 1)[2] if 1 <= t else [None, None]
+            ops += [o for o in (x[0], m[0], x[1], c[0], x[2], m[1], x[3], c[1]) if o is not None]
+        return ops
+
+    def half_step(self, em, slotA, qbA, slotC, qbC, pa, nxt, fill_first=()):
+        need = {f: f for f in range(32)}
+        need["cs"] = 16
+        need["cd"] = 24
+        post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
+        em.retag({("n", f): f for f in range(4)})
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, qbA, slotC, qbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+                 pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT = "%0", "%1"
+        RQ, RDO, RST, QSTEP, DSTEP, WBASE, SBASE, NITER = "%[rq]", "%[rdo]", "%[rst]", "%[qstep]", "%[dstep]", "%[wbase]", "%[sbase]", "%[niter]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        for i in range(128):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        for r in list(range(32, 64)) + list(range(64, 80)):      # S / DP[1], PK / DSK[0]
+            em.raw(f"v_mov_b32 v{r}, 0")
+        for f in range(4):
+            self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        em.raw("L_w1dkv128_loop_%=:")
+        for ph in range(4):
+            em.raw("s_waitcnt vmcnt(9)")
+            if "nosync" not in ABLATE:
+                em.raw("s_barrier")
+            dst = ((ph + 2) & 3) * 32768
+            fill = []
+            for k in range(8):
+                isdo = k >= 4
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + (16384 if isdo else 0) + (k & 3) * 1024}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {RDO if isdo else RQ}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {DSTEP if isdo else QSTEP}, v{self.VOFF + k}"])
+            fill.append([f"s_add_u32 m0, {SBASE}, {((ph + 2) & 3) * 1024}"])
+            fill.append([f"buffer_load_dword v{self.VOFF + 8}, {RST}, 0 offen lds", f"v_add_u32 v{self.VOFF + 8}, 256, v{self.VOFF + 8}"])
+            sp = (ph - 1) & 3
+            self.half_step(em, ph, 0, sp, 0, 0, nxt=(sp, 1), fill_first=fill)
+            self.half_step(em, ph, 1, sp, 1, 1, nxt=(ph, 0))
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if ph < 3:
+                em.raw("s_cbranch_scc1 L_w1dkv128_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1dkv128_loop_%=")
+        em.raw("L_w1dkv128_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 # --------------------------------------------------------------------------------------------------------------------- GEMM loop
 class GemmLoop:
     """C^T tile = W A^T for a 256 (M) x 128 (N) output tile, operands both K-contiguous (x [M, K], W [N, K]: y = x W^T), BK = 64 per
@@ -873,6 +1024,8 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)]),
            "w1_fwd128_loop.inc": lambda: Fwd128Loop().generate(),
            "w1_fwd128_clobbers.inc": lambda: clobbers([(0, 127), (185, 185)], [(192, 255)]),
+           "w1_dkv128_loop.inc": lambda: Dkv128Loop().generate(),
+           "w1_dkv128_clobbers.inc": lambda: clobbers([(0, 127)], [(192, 255)]),
            "w1_gemm_loop.inc": lambda: GemmLoop().generate(),
            "w1_gemm_clobbers.inc": lambda: clobbers([], [(128, 175)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),

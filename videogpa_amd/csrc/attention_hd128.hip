@@ -15,6 +15,12 @@
 #define P128 136
 #define T128 (64 * P128)   // elements of one [64 x 128] LDS tile
 
+// consecutive workgroup ids go round-robin over the 8 XCDs: give every XCD a contiguous range of tasks (its L2 then sees one (b, h) at a time)
+__device__ __forceinline__ int xcd_remap128(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 __device__ __forceinline__ rsrc_t rsrc128(const bf16_t* base /* uniform */, uint32_t row_stride, int S) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, ((uint32_t)(S - 1) * row_stride + (uint32_t)D128) * 2u, 0x00020000);
 }
@@ -334,16 +340,20 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __
 }
 
 // ===================================================================================================== backward
-// delta[b,h,q] = sum_d dO O : 16 lanes per row, 16 B each
+// delta[b,h,q] = sum_d dO O : 16 lanes per row, 16 B each; with `stats` also the planes [B, H, 2, S] = {-lse2 / c, -delta} the w1 dK/dV kernel
+// takes as the srcC of its score chains
 __global__ __launch_bounds__(256) void attn128_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, TStride sdo, TStride so, int S, int H,
-                                                              int64_t total, float* __restrict__ delta) {
+                                                              int64_t total, float* __restrict__ delta, const float* __restrict__ LSE2, float inv_c,
+                                                              float* __restrict__ stats) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = gid >> 4;
     const int c16 = (int)(gid & 15);
     float acc = 0.f;
+    int64_t bh = 0;
+    int q = 0;
     if (row < total) {
-        const int q = (int)(row % S);
-        const int64_t bh = row / S;
+        q = (int)(row % S);
+        bh = row / S;
         const int h = (int)(bh % H), b = (int)(bh / H);
         float a[8], o[8];
         unpack8(*reinterpret_cast<const u32x4_t*>(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h + (size_t)q * sdo.s + c16 * 8)), a);
@@ -355,7 +365,13 @@ __global__ __launch_bounds__(256) void attn128_delta_kernel(const bf16_t* __rest
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
     acc += __shfl_xor(acc, 8, 64);
-    if (row < total && c16 == 0) delta[row] = acc;
+    if (row < total && c16 == 0) {
+        delta[row] = acc;
+        if (stats) {
+            stats[bh * 2 * S + q] = -LSE2[row] * inv_c;
+            stats[bh * 2 * S + S + q] = -acc;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256, 1) void attn128_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
@@ -520,6 +536,109 @@ __global__ __launch_bounds__(256, 1) void attn128_dkv_kernel(const bf16_t* __res
     }
 }
 
+// ----------------------------------------------------------------------------------------------------- dK, dV, w1 structure
+// One 32-key block per wave (dK^T, dV^T and the K, V fragments in AGPRs), Q | dO tiles and the statistics planes by LDS-DMA, main loop from
+// tools/gen_w1_asm.py::Dkv128Loop.  LDS-bandwidth-bound by construction (one fragment read per MFMA), see the generator's docstring.
+#define W1H_STAT_BYTES 1024
+__global__ __launch_bounds__(256, 1) void attn128_dkv_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ STATS, bf16_t* __restrict__ dK,
+                                                                  bf16_t* __restrict__ dV, TStride sq, TStride sk, TStride sv, TStride sdo, TStride sdk,
+                                                                  TStride sdv, int Sq, int Skv, int H, int n_kt, float c, float scale) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[W1H_RING_BYTES + 4 * W1H_STAT_BYTES];   // slot = [Q tile | dO tile]; statistics behind the ring
+    const int vid = xcd_remap128(blockIdx.x, gridDim.x);
+    const int bh = vid / n_kt, kt = vid % n_kt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int k0 = (kt * 4 + wave) * 32;
+
+    bf16x8_t kf[8], vf[8];
+    load_row_frags128(K + ((size_t)b * sk.b + (size_t)h * sk.h), sk.s, k0, Skv, lane, kf);
+    load_row_frags128(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, k0, Skv, lane, vf);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { asm volatile("" ::"v"(kf[ks])); asm volatile("" ::"v"(vf[ks])); }
+    const int nt = (Sq + 63) / 64;
+    {   // the pipeline's first transposed reads hit ring slot 3 (both tiles): make it finite
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4_t*>(lds + 3 * W1H_SLOT_BYTES + i * 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const W1Rsrc qrs = w1_rsrc(Q + ((size_t)b * sq.b + (size_t)h * sq.h), ((uint32_t)(Sq - 1) * sq.s + (uint32_t)D128) * 2u);
+    const W1Rsrc dors = w1_rsrc(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), ((uint32_t)(Sq - 1) * sdo.s + (uint32_t)D128) * 2u);
+    const W1Rsrc strs = w1_rsrc(STATS + (int64_t)bh * 2 * Sq, (uint32_t)(2 * Sq) * 4u);
+    u32x8_t voff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t row = 4u * (uint32_t)(wave * 4 + i) + (uint32_t)(lane >> 4);
+        const uint32_t cl = (uint32_t)(lane & 15) ^ w1h_swz(row);
+        voff[i] = (row * sq.s + cl * 8u) * 2u;
+        voff[4 + i] = (row * sdo.s + cl * 8u) * 2u;
+    }
+    const uint32_t qstep = __builtin_amdgcn_readfirstlane(64u * sq.s * 2u), dstep = __builtin_amdgcn_readfirstlane(64u * sdo.s * 2u);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 4096u);
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)W1H_RING_BYTES + (uint32_t)wave * 256u);
+    // statistics piece of this wave: lanes 0..15 fetch plane 0 (-lse2 / c) of rows 16 wave + lane, lanes 16..31 plane 1 (-delta); the upper
+    // half-wave repeats the lower one (its 128 bytes of the LDS piece are never read)
+    uint32_t svo = ((uint32_t)((lane >> 4) & 1) * (uint32_t)Sq + (uint32_t)(16 * wave + (lane & 15))) * 4u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {   // tiles 0, 1 -> ring slots 0, 1
+        const uint32_t dst = wbase + (uint32_t)t * W1H_SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w1_dma(dst + 1024u * i, qrs, voff[i], 0u);
+            w1_dma(dst + W1H_TILE_BYTES + 1024u * i, dors, voff[4 + i], 0u);
+        }
+        w1_dma4(sbase + (uint32_t)t * W1H_STAT_BYTES, strs, svo, 0u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { voff[i] += qstep; voff[4 + i] += dstep; }
+        svo += 256u;
+    }
+    u32x16_t la[2];
+    {
+        const uint32_t m = lane & 31;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) la[st][ks] = st * 65536u + m * 256u + ((((uint32_t)(2 * ks) + (uint32_t)hi) ^ w1h_swz(m)) << 4);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r3 = 0; r3 < 2; ++r3) {
+                    const uint32_t rr = 4u * hi + ((uint32_t)(lane & 15) >> 2) + 8u * r3;
+                    const uint32_t cc = 4u * db + 2u * ((uint32_t)(lane >> 4) & 1u) + (((uint32_t)lane & 3u) >> 1);
+                    la[st][8 + 2 * db + r3] = st * 65536u + rr * 256u + ((cc ^ w1h_swz(rr)) << 4) + ((uint32_t)lane & 1u) * 8u;
+                }
+        }
+    }
+    const uint32_t sread = lds0 + (uint32_t)W1H_RING_BYTES + 16u * (uint32_t)hi;
+    const u32x16_t kf0 = pack4h(kf[0], kf[1], kf[2], kf[3]), kf1 = pack4h(kf[4], kf[5], kf[6], kf[7]);
+    const u32x16_t vf0 = pack4h(vf[0], vf[1], vf[2], vf[3]), vf1 = pack4h(vf[4], vf[5], vf[6], vf[7]);
+    const uint32_t niter = (uint32_t)(nt + 1);   // one extra tile step drains the pipeline
+    const uint32_t cs = __builtin_amdgcn_readfirstlane(__float_as_uint(c));
+    f32x16_t dk[4], dv[4];
+    uint32_t t0, t1;
+    asm volatile(
+#include "w1_dkv128_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "={a[0:15]}"(dk[0]), "={a[16:31]}"(dk[1]), "={a[32:47]}"(dk[2]), "={a[48:63]}"(dk[3]), "={a[64:79]}"(dv[0]),
+          "={a[80:95]}"(dv[1]), "={a[96:111]}"(dv[2]), "={a[112:127]}"(dv[3]), "+{v[160:167]}"(voff), "+{v168}"(svo)
+        : [rq] "s"(qrs.w), [rdo] "s"(dors.w), [rst] "s"(strs.w), [qstep] "s"(qstep), [dstep] "s"(dstep), [wbase] "s"(wbase), [sbase] "s"(sbase),
+          [niter] "s"(niter), [cs] "s"(cs), "{a[128:143]}"(kf0), "{a[144:159]}"(kf1), "{a[160:175]}"(vf0), "{a[176:191]}"(vf1), "{v[128:143]}"(la[0]),
+          "{v[144:159]}"(la[1]), "{v169}"(sread)
+        : "memory", "scc",
+#include "w1_dkv128_clobbers.inc"
+    );
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { asm volatile("" : "+v"(dk[db])); asm volatile("" : "+v"(dv[db])); }
+    const int k = k0 + (lane & 31);
+    if (k < Skv) {
+        store_col128(dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s), dk, scale, hi);
+        store_col128(dV + ((size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)k * sdv.s), dv, 1.f, hi);
+    }
+}
+
 // ===================================================================================================== host
 static inline bool sok128(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= D128 && st[0] % 8 == 0 && st[1] % 8 == 0 && st[2] % 8 == 0; }
 static inline bool rok128(const int64_t* st, int64_t B, int64_t H, int64_t S) { return (B - 1) * st[0] + (H - 1) * st[1] + (S - 1) * st[2] + D128 < ((int64_t)1 << 31); }
@@ -565,28 +684,45 @@ extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v,
     return VGPA_OK;
 }
 
-// delta: caller's fp32 scratch [B * H * Sq]
+// workspace: delta [B*H*Sq] + the statistics planes [B, H, 2, Sq] (fp32)
+extern "C" size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq) {
+    if (B <= 0 || H <= 0 || Sq <= 0) return 0;
+    return (size_t)(3 * B * H * Sq) * 4;
+}
+
+// dkv_mode: 0 = the compiler-scheduled dK/dV kernel, 1 = the w1 kernel (needs Sq >= 256 to pay), -1 = automatic
 extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
-                                    void* dv, float* delta, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                    void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                     const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
-                                    const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, hipStream_t stream) {
-    if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || !delta || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
+                                    const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, int32_t dkv_mode, void* workspace,
+                                    size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
     const int64_t* qs[] = {q_strides, o_strides, do_strides, dq_strides};
     const int64_t* ks[] = {k_strides, v_strides, dk_strides, dv_strides};
     for (const int64_t* s : qs) if (!sok128(s) || !rok128(s, B, H, Sq)) return VGPA_ERR_INVALID;
     for (const int64_t* s : ks) if (!sok128(s) || !rok128(s, B, H, Skv)) return VGPA_ERR_INVALID;
     if (!a16(q) || !a16(k) || !a16(v) || !a16(o) || !a16(d_o) || !a16(dq) || !a16(dk) || !a16(dv)) return VGPA_ERR_INVALID;
+    if (!workspace || ((uintptr_t)workspace & 15) || ws_bytes < vgpa_attn128_bwd_workspace_bytes(B, H, Sq)) return VGPA_ERR_WORKSPACE;
     const int64_t n_qt = (Sq + 127) / 128, n_kt = (Skv + 127) / 128, total = B * H * Sq;
-    if (B * H * n_qt >= ((int64_t)1 << 31) || B * H * n_kt >= ((int64_t)1 << 31) || total * 16 >= ((int64_t)1 << 39)) return VGPA_ERR_INVALID;
+    if (B * H * n_qt >= ((int64_t)1 << 31) || B * H * n_kt >= ((int64_t)1 << 31) || total * 16 >= ((int64_t)1 << 39) || 2 * Sq * 4 >= ((int64_t)1 << 31))
+        return VGPA_ERR_INVALID;
     const float c = scale * LOG2E_F;
+    float* delta = (float*)workspace;
+    float* stats = delta + total;
+    const bool w1 = dkv_mode == 1 || (dkv_mode < 0 && Sq >= 1024);
     VGPA_LAUNCH(attn128_delta_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, mk128(do_strides),
-                mk128(o_strides), (int)Sq, (int)H, total, delta);
+                mk128(o_strides), (int)Sq, (int)H, total, delta, lse2, 1.f / c, w1 ? stats : (float*)nullptr);
     VGPA_LAUNCH(attn128_dq_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
                 lse2, (const float*)delta, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides), mk128(dq_strides), (int)Sq,
                 (int)Skv, (int)H, (int)n_qt, c, scale);
-    VGPA_LAUNCH(attn128_dkv_kernel, dim3((unsigned)(B * H * n_kt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
-                lse2, (const float*)delta, (bf16_t*)dk, (bf16_t*)dv, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides), mk128(dk_strides),
-                mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, scale);
+    if (w1)
+        VGPA_LAUNCH(attn128_dkv_w1_kernel, dim3((unsigned)(B * H * n_kt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dk, (bf16_t*)dv, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
+                    mk128(dk_strides), mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, scale);
+    else
+        VGPA_LAUNCH(attn128_dkv_kernel, dim3((unsigned)(B * H * n_kt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (const bf16_t*)d_o, lse2, (const float*)delta, (bf16_t*)dk, (bf16_t*)dv, mk128(q_strides), mk128(k_strides), mk128(v_strides),
+                    mk128(do_strides), mk128(dk_strides), mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, scale);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

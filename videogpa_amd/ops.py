@@ -818,10 +818,11 @@ class _Attention128Fn(torch.autograd.Function):
         Skv = k.shape[2]
         do = do if do.stride(3) == 1 else do.contiguous()
         dq, dk, dv = torch.empty_like(o), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device)
-        delta = torch.empty(B * H * Sq, dtype=torch.float32, device=q.device)
+        ws_bytes = _lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, Sq)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
         _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-            "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, delta, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
-            _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, ctx.scale, _stream()))
+            "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
+            _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, ctx.scale, -1 if ATTN128_W1 else 0, ws, ws_bytes, _stream()))
         return dq, dk, dv, None
 
 
