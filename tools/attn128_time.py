@@ -34,7 +34,7 @@ def timeit(fn, n=5):
 
 
 ff = 4.0 * B * H * S * S * D
-for name, fn, fl in [("fwd w1", lambda: fwd(True), ff), ("fwd simple", lambda: fwd(False), ff), ("bwd (dq simple + dkv w1)", lambda: bwd(1), 2.5 * ff),
-                     ("bwd (dq simple + dkv simple)", lambda: bwd(0), 2.5 * ff)]:
+for name, fn, fl in [("fwd w1", lambda: fwd(True), ff), ("fwd simple", lambda: fwd(False), ff), ("bwd (w1 dq + w1 dkv)", lambda: bwd(1), 2.5 * ff),
+                     ("bwd (compiler-scheduled)", lambda: bwd(0), 2.5 * ff)]:
     t = timeit(fn)
     print(f"{name:32s} {t:8.3f} ms   {fl / t / 1e9:7.0f} TFLOP/s algorithmic")

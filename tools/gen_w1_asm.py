@@ -932,6 +932,132 @@ class Dkv128Loop:
         return em.text() + "\n"
 
 
+# --------------------------------------------------------------------------------------------------------------- dQ, head_dim 128
+class Dq128Loop:
+    """DqLoop for head_dim 128: ONE 32-row q-block per wave (dQ^T 64 + Q, dO fragments 64 AGPRs; two blocks would leave no room for the
+       fragment ring), streaming 64-key K|V tiles (LDS image as Fwd128Loop); per 32-key half-tile g:
+         A(g): S[g&1] = -lse2[q] / c + K_g Q^T,  DP[g&1] = -delta[q] + V_g dO^T         16 MFMAs; the constants are loop-invariant srcC tuples
+         B(g): D[g&1] = bf16(exp2(c S) * DP)                                             56 VALU
+         C(g): dQ^T[db] += K_g^T D                                                       8 MFMAs on transpose-read K fragments
+       24 fragment reads per 24 MFMAs.  Keys past the end need no mask (their K rows are zero).
+       register map   a[0:63] dq[db]   a[64:95] qf[ks]   a[96:127] dof[ks]   a[128:223] fragment ring (24 x 4)
+                      v[0:63] S / DP [p]   v[64:79] D[p][cc]   v[80:95] srcC -lse2/c   v[96:111] srcC -delta
+                      v[112:143] lane LDS offsets [slot pair][16]   v[144:151] LDS-DMA source offsets (K x4, V x4)"""
+
+    LA = 112
+    VOFF = 144
+    FR = 128
+    LEAD = KNOB.get("lead", 6)
+
+    def S(self, p):
+        return p * 32
+
+    def DP(self, p):
+        return p * 32 + 16
+
+    def D(self, p, cc):
+        return 64 + p * 8 + cc * 4
+
+    def frag_reg(self, f):
+        return self.FR + 4 * f
+
+    def issue_frag(self, em, f, slotA, kbA, slotC, kbC, tag=None):
+        """f 0..7: transposed K fragments (cc, db) = (f >> 2, f & 3) of the PREVIOUS half; 8..15: K rows ks; 16..23: V rows ks"""
+        tag = f if tag is None else tag
+        r = self.frag_reg(f)
+        if f < 8:
+            cc, db = f >> 2, f & 3
+            base = self.LA + 16 * (slotC >> 1) + 8 + 2 * db
+            off = (slotC & 1) * 32768 + kbC * 8192 + cc * 4096
+            em.ds(f"ds_read_b64_tr_b16 {ar(r, 2)}, v{base} offset:{off}", tag)
+            em.ds(f"ds_read_b64_tr_b16 {ar(r + 2, 2)}, v{base + 1} offset:{off}", tag)
+        else:
+            isv = f >= 16
+            base = self.LA + 16 * (slotA >> 1) + ((f - 8) & 7)
+            em.ds(f"ds_read_b128 {ar(r, 4)}, v{base} offset:{(slotA & 1) * 32768 + (16384 if isv else 0) + kbA * 8192}", tag)
+
+    def mfmas(self, pa, pc):
+        out = []
+        for c in range(8):
+            cc, db = c >> 2, c & 3
+            d = ar(16 * db, 16)
+            out.append((f"{MFMA} {d}, {ar(self.frag_reg(c), 4)}, {vr(self.D(pc, cc), 4)}, {d}", c))
+        for ks in range(8):
+            d = vr(self.S(pa), 16)
+            c = vr(80, 16) if ks == 0 else d
+            out.append((f"{MFMA} {d}, {ar(self.frag_reg(8 + ks), 4)}, {ar(64 + 4 * ks, 4)}, {c}", 8 + ks))
+        for ks in range(8):
+            d = vr(self.DP(pa), 16)
+            c = vr(96, 16) if ks == 0 else d
+            out.append((f"{MFMA} {d}, {ar(self.frag_reg(16 + ks), 4)}, {ar(96 + 4 * ks, 4)}, {c}", 16 + ks))
+        return out
+
+    def valu_ops(self, pb):
+        if "novalu" in ABLATE:
+            return []
+
+        def unit(p):
+            s0, d0 = self.S(pb) + 2 * p, self.DP(pb) + 2 * p
+            w = self.D(pb, p >> 2) + (p & 3)
+            return ([f"v_mul_f32 v{s0}, %[cs], v{s0}", f"v_mul_f32 v{s0 + 1}, %[cs], v{s0 + 1}", f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                    [f"v_mul_f32 v{s0}, v{d0}, v{s0}", f"v_mul_f32 v{s0 + 1}, v{d0 + 1}, v{s0 + 1}"],
+                    f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
+        ops = list(unit(0)[0])
+        for t in range(9):
+            x = unit(t + 1)[0] if t + 1 < 8 else [None] * 4
+            m = unit(t)[1] if t < 8 else [None, None]
+            c = unit(t - 1)[2] if 1 <= t else None
+            ops += [o for o in (x[0], m[0], x[1], x[2], m[1], x[3], c) if o is not None]
+        return ops
+
+    def half_step(self, em, slotA, kbA, slotC, kbC, pa, nxt, fill_first=()):
+        need = {f: f for f in range(24)}
+        post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
+        em.retag({("n", f): f for f in range(4)})
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+                 pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT = "%0", "%1"
+        RK, RV, KSTEP, VSTEP, WBASE, NITER = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        for i in range(64):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        for r in list(range(32, 64)) + list(range(64, 72)):      # S / DP[1], D[0]
+            em.raw(f"v_mov_b32 v{r}, 0")
+        for f in range(4):
+            self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        em.raw("L_w1dq128_loop_%=:")
+        for ph in range(4):
+            em.raw("s_waitcnt vmcnt(8)")
+            if "nosync" not in ABLATE:
+                em.raw("s_barrier")
+            dst = ((ph + 2) & 3) * 32768
+            fill = []
+            for k in range(8):
+                isv = k >= 4
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + (16384 if isv else 0) + (k & 3) * 1024}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {RV if isv else RK}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {VSTEP if isv else KSTEP}, v{self.VOFF + k}"])
+            sp = (ph - 1) & 3
+            self.half_step(em, ph, 0, sp, 0, 0, nxt=(sp, 1), fill_first=fill)
+            self.half_step(em, ph, 1, sp, 1, 1, nxt=(ph, 0))
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if ph < 3:
+                em.raw("s_cbranch_scc1 L_w1dq128_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1dq128_loop_%=")
+        em.raw("L_w1dq128_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 # --------------------------------------------------------------------------------------------------------------------- GEMM loop
 class GemmLoop:
     """C^T tile = W A^T for a 256 (M) x 128 (N) output tile, operands both K-contiguous (x [M, K], W [N, K]: y = x W^T), BK = 64 per
@@ -1026,6 +1152,8 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_fwd128_clobbers.inc": lambda: clobbers([(0, 127), (185, 185)], [(192, 255)]),
            "w1_dkv128_loop.inc": lambda: Dkv128Loop().generate(),
            "w1_dkv128_clobbers.inc": lambda: clobbers([(0, 127)], [(192, 255)]),
+           "w1_dq128_loop.inc": lambda: Dq128Loop().generate(),
+           "w1_dq128_clobbers.inc": lambda: clobbers([(0, 79)], [(128, 223)]),
            "w1_gemm_loop.inc": lambda: GemmLoop().generate(),
            "w1_gemm_clobbers.inc": lambda: clobbers([], [(128, 175)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),

@@ -639,6 +639,100 @@ __global__ __launch_bounds__(256, 1) void attn128_dkv_w1_kernel(const bf16_t* __
     }
 }
 
+// ----------------------------------------------------------------------------------------------------- dQ, w1 structure
+// One 32-row q-block per wave (dQ^T, Q and dO fragments in AGPRs), K | V tiles by LDS-DMA, main loop from tools/gen_w1_asm.py::Dq128Loop.
+__global__ __launch_bounds__(256, 1) void attn128_dq_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ STATS, bf16_t* __restrict__ dQ,
+                                                                 TStride sq, TStride sk, TStride sv, TStride sdo, TStride sdq, int Sq, int Skv, int H, int n_qt,
+                                                                 float c, float scale) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[W1H_RING_BYTES];   // slot = [K tile | V tile]
+    const int vid = xcd_remap128(blockIdx.x, gridDim.x);
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int q0 = (qt * 4 + wave) * 32;
+
+    bf16x8_t qf[8], dof[8];
+    load_row_frags128(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0, Sq, lane, qf);
+    load_row_frags128(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0, Sq, lane, dof);
+    int qc = q0 + (lane & 31);
+    qc = qc < Sq ? qc : Sq - 1;
+    const float nl = STATS[(size_t)bh * 2 * Sq + qc], nd = STATS[(size_t)bh * 2 * Sq + Sq + qc];    // -lse2 / c, -delta
+    f32x16_t cs_t, cd_t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cs_t[i] = nl; cd_t[i] = nd; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { asm volatile("" ::"v"(qf[ks])); asm volatile("" ::"v"(dof[ks])); }
+    const int nt = (Skv + 63) / 64;
+    {   // the pipeline's first transposed reads hit the K tile of ring slot 3: make it finite
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(lds + 3 * W1H_SLOT_BYTES + i * 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const W1Rsrc krs = w1_rsrc(K + ((size_t)b * sk.b + (size_t)h * sk.h), ((uint32_t)(Skv - 1) * sk.s + (uint32_t)D128) * 2u);
+    const W1Rsrc vrs = w1_rsrc(V + ((size_t)b * sv.b + (size_t)h * sv.h), ((uint32_t)(Skv - 1) * sv.s + (uint32_t)D128) * 2u);
+    u32x8_t voff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t row = 4u * (uint32_t)(wave * 4 + i) + (uint32_t)(lane >> 4);
+        const uint32_t cl = (uint32_t)(lane & 15) ^ w1h_swz(row);
+        voff[i] = (row * sk.s + cl * 8u) * 2u;
+        voff[4 + i] = (row * sv.s + cl * 8u) * 2u;
+    }
+    const uint32_t kstep = __builtin_amdgcn_readfirstlane(64u * sk.s * 2u), vstep = __builtin_amdgcn_readfirstlane(64u * sv.s * 2u);
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds + (uint32_t)wave * 4096u);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t dst = wbase + (uint32_t)t * W1H_SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w1_dma(dst + 1024u * i, krs, voff[i], 0u);
+            w1_dma(dst + W1H_TILE_BYTES + 1024u * i, vrs, voff[4 + i], 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { voff[i] += kstep; voff[4 + i] += vstep; }
+    }
+    u32x16_t la[2];
+    {
+        const uint32_t m = lane & 31;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) la[st][ks] = st * 65536u + m * 256u + ((((uint32_t)(2 * ks) + (uint32_t)hi) ^ w1h_swz(m)) << 4);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r3 = 0; r3 < 2; ++r3) {
+                    const uint32_t rr = 4u * hi + ((uint32_t)(lane & 15) >> 2) + 8u * r3;
+                    const uint32_t cc = 4u * db + 2u * ((uint32_t)(lane >> 4) & 1u) + (((uint32_t)lane & 3u) >> 1);
+                    la[st][8 + 2 * db + r3] = st * 65536u + rr * 256u + ((cc ^ w1h_swz(rr)) << 4) + ((uint32_t)lane & 1u) * 8u;
+                }
+        }
+    }
+    const u32x16_t qf0 = pack4h(qf[0], qf[1], qf[2], qf[3]), qf1 = pack4h(qf[4], qf[5], qf[6], qf[7]);
+    const u32x16_t do0 = pack4h(dof[0], dof[1], dof[2], dof[3]), do1 = pack4h(dof[4], dof[5], dof[6], dof[7]);
+    const uint32_t niter = (uint32_t)(nt + 1);
+    const uint32_t cs = __builtin_amdgcn_readfirstlane(__float_as_uint(c));
+    f32x16_t dq[4];
+    uint32_t t0, t1;
+    asm volatile(
+#include "w1_dq128_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "={a[0:15]}"(dq[0]), "={a[16:31]}"(dq[1]), "={a[32:47]}"(dq[2]), "={a[48:63]}"(dq[3]), "+{v[144:151]}"(voff)
+        : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [cs] "s"(cs),
+          "{a[64:79]}"(qf0), "{a[80:95]}"(qf1), "{a[96:111]}"(do0), "{a[112:127]}"(do1), "{v[80:95]}"(cs_t), "{v[96:111]}"(cd_t), "{v[112:127]}"(la[0]),
+          "{v[128:143]}"(la[1])
+        : "memory", "scc",
+#include "w1_dq128_clobbers.inc"
+    );
+#pragma unroll
+    for (int db = 0; db < 4; ++db) asm volatile("" : "+v"(dq[db]));
+    const int q = q0 + (lane & 31);
+    if (q < Sq) store_col128(dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s), dq, scale, hi);
+}
+
 // ===================================================================================================== host
 static inline bool sok128(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= D128 && st[0] % 8 == 0 && st[1] % 8 == 0 && st[2] % 8 == 0; }
 static inline bool rok128(const int64_t* st, int64_t B, int64_t H, int64_t S) { return (B - 1) * st[0] + (H - 1) * st[1] + (S - 1) * st[2] + D128 < ((int64_t)1 << 31); }
@@ -690,7 +784,7 @@ extern "C" size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t
     return (size_t)(3 * B * H * Sq) * 4;
 }
 
-// dkv_mode: 0 = the compiler-scheduled dK/dV kernel, 1 = the w1 kernel (needs Sq >= 256 to pay), -1 = automatic
+// dkv_mode: 0 = the compiler-scheduled dQ and dK/dV kernels, 1 = the w1 kernels, -1 = automatic (w1 dK/dV from 1024 queries on, w1 dQ from 1024 keys on)
 extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
                                     void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                     const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
@@ -710,11 +804,17 @@ extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v,
     float* delta = (float*)workspace;
     float* stats = delta + total;
     const bool w1 = dkv_mode == 1 || (dkv_mode < 0 && Sq >= 1024);
+    const bool w1q = dkv_mode == 1 || (dkv_mode < 0 && Skv >= 1024);     // the dQ kernel sweeps the keys
     VGPA_LAUNCH(attn128_delta_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, mk128(do_strides),
-                mk128(o_strides), (int)Sq, (int)H, total, delta, lse2, 1.f / c, w1 ? stats : (float*)nullptr);
-    VGPA_LAUNCH(attn128_dq_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
-                lse2, (const float*)delta, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides), mk128(dq_strides), (int)Sq,
-                (int)Skv, (int)H, (int)n_qt, c, scale);
+                mk128(o_strides), (int)Sq, (int)H, total, delta, lse2, 1.f / c, (w1 || w1q) ? stats : (float*)nullptr);
+    if (w1q)
+        VGPA_LAUNCH(attn128_dq_w1_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
+                    mk128(dq_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, scale);
+    else
+        VGPA_LAUNCH(attn128_dq_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
+                    lse2, (const float*)delta, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides), mk128(dq_strides), (int)Sq,
+                    (int)Skv, (int)H, (int)n_qt, c, scale);
     if (w1)
         VGPA_LAUNCH(attn128_dkv_w1_kernel, dim3((unsigned)(B * H * n_kt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                     (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dk, (bf16_t*)dv, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
