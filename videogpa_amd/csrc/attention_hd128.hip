@@ -1,9 +1,13 @@
 // Attention for head_dim 128 with separate query / key lengths: the two attention shapes of the Wan2.2-TI2V-5B denoiser
 // (train/Wan2.2-TI2V-5B/03_train.py:150-163 builds it; self-attention 24 heads x 128 over the video tokens, cross-attention of the
 // video tokens over the 512 text tokens), forward and backward.  Same mathematics and operand conventions as attention.hip
-// (softmax in the exp2 domain, fp32 statistics, lse2 = m + log2(l) kept for the backward, delta = rowsum(dO o O)), first version of
-// the blocking: 4 waves x 32 stationary rows per workgroup, the streamed operand as [64 x 128] tiles through registers into a
-// double-buffered padded LDS image (pitch 136: the 16-byte row-fragment reads are conflict-free), compiler-scheduled.
+// (softmax in the exp2 domain, fp32 statistics, lse2 = m + log2(l) kept for the backward, delta = rowsum(dO o O)).  Two kernel
+// families behind the same entry points:
+//   * the w1 kernels (one wave per SIMD, LDS-DMA ring, generated main loops -- DESIGN.md sections 4.0 / 4.5) for long sweeps:
+//     attn128_fwd_w1_kernel, attn128_dkv_w1_kernel, attn128_dq_w1_kernel;
+//   * compiler-scheduled kernels for short sweeps (cross-attention over 512 text tokens), the forward's flagged strips and as the
+//     reference implementation: 4 waves x 32 stationary rows per workgroup, the streamed operand as [64 x 128] tiles through registers
+//     into a double-buffered padded LDS image (pitch 136: the 16-byte row-fragment reads are conflict-free).
 //   forward :  S^T = K Q^T (q on the lanes) -> online softmax per lane -> O^T += V^T P^T
 //   dQ      :  dQ^T += K^T dS^T,  dS^T = P^T o (dP^T - delta),  dP^T = V dO^T
 //   dK, dV  :  key on the lanes:  S = Q K^T,  dV^T += dO^T P,  dK^T += Q^T dS          (statistics per row from an LDS tile)
