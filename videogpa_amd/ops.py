@@ -800,7 +800,8 @@ class _Attention128Fn(torch.autograd.Function):
         Skv = k.shape[2]
         assert D == 128 and k.shape == (B, H, Skv, 128) and v.shape == k.shape and q.dtype == k.dtype == v.dtype == torch.bfloat16
         q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
-        o = torch.empty(B, H, Sq, D, dtype=torch.bfloat16, device=q.device)
+        # token-major storage [B, S, H, 128] behind the [B, H, S, 128] view: the caller's flatten to [B * S, H * 128] is then free
+        o = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
         lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
         ws_bytes = _lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, Sq) if ATTN128_W1 else 0
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
@@ -817,7 +818,9 @@ class _Attention128Fn(torch.autograd.Function):
         B, H, Sq, D = q.shape
         Skv = k.shape[2]
         do = do if do.stride(3) == 1 else do.contiguous()
-        dq, dk, dv = torch.empty_like(o), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device), torch.empty(B, H, Skv, D, dtype=torch.bfloat16, device=q.device)
+        dq = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)      # token-major, like the projections' outputs
+        dk = torch.empty(B, Skv, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
+        dv = torch.empty(B, Skv, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
         ws_bytes = _lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, Sq)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
         _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
