@@ -57,8 +57,8 @@ summ = ops.TIMER.summary()
 ops.TIMER = None
 tot = sum(v["total_ms"] for v in summ.values())
 res = {"workload": f"Wan2.2-TI2V-5B pair step, {a.layers} layers, 48x{a.frames}x44x80 latent, batch 1, LoRA r64, ckpt" + (", fp8 feed-forward" if a.fp8 else ""), "s_per_step": dt, "pair_steps_per_s": 1 / dt,
-       "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "timed_kernels_ms": tot, "kernels": {}}
-print(f"{res['workload']}: {dt:.3f} s/step, loss {float(loss):.4f}, peak {res['peak_mem_GB']:.1f} GB; timed kernels {tot:.0f} ms")
+       "loss": float(loss.detach()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "timed_kernels_ms": tot, "kernels": {}}
+print(f"{res['workload']}: {dt:.3f} s/step, loss {float(loss.detach()):.4f}, peak {res['peak_mem_GB']:.1f} GB; timed kernels {tot:.0f} ms")
 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
     rate = v["work_per_launch"] / (v["avg_ms"] * 1e-3)
     r = f"{rate / 1e12:.0f} TFLOP/s" if v["unit"] == "flop" else f"{rate / 1e9:.0f} GB/s"

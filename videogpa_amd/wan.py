@@ -27,6 +27,7 @@ DEFAULT_CONFIG: Dict[str, Any] = {           # train/Wan2.2-TI2V-5B/03_train.py:
     "gradient_clip_val": 1.0, "weight_decay": 0.01, "num_train_timesteps": 1000, "shift": 5.0,
     "lora_rank": 64, "lora_alpha": 128.0, "lora_dropout": 0.0, "lora_target_modules": ["q", "k", "v", "o"],
     "patch_size": (1, 2, 2), "seed": 0,
+    "pair_batch": True,      # MI355X-first: win and lose as one batch through the denoiser (False = two calls, like the reference)
 }
 
 
@@ -99,8 +100,18 @@ class WanDPOTrainer(nn.Module):
         kw = dict(t=t_batch, context=ctx, seq_len=seq_len)
         xw_in = [xt_pair[b, 0] for b in range(B)]
         xl_in = [xt_pair[b, 1] for b in range(B)]
-        v_wr, v_lr = torch.stack(self._ref(xw_in, **kw)), torch.stack(self._ref(xl_in, **kw))                             # reference first (:227-229)
-        v_w, v_l = torch.stack(self.transformer(xw_in, **kw)), torch.stack(self.transformer(xl_in, **kw))
+        if self.config.get("pair_batch", True):
+            # win and lose through the model as ONE batch of 2B samples (the reference calls it twice, :227-233): rows are independent, results
+            # unchanged, and every launch gets twice the rows -- at 18 480 tokens one sample leaves the last scheduling round of the attention
+            # grids 16 % empty (1752 workgroups on 256 CUs), two samples 2 %
+            kw2 = dict(t=torch.cat([t_batch, t_batch]), context=ctx + ctx, seq_len=seq_len)
+            r = self._ref(xw_in + xl_in, **kw2)                                                                             # reference first (:227-229)
+            v_wr, v_lr = torch.stack(r[:B]), torch.stack(r[B:])
+            p = self.transformer(xw_in + xl_in, **kw2)
+            v_w, v_l = torch.stack(p[:B]), torch.stack(p[B:])
+        else:
+            v_wr, v_lr = torch.stack(self._ref(xw_in, **kw)), torch.stack(self._ref(xl_in, **kw))                         # reference first (:227-229)
+            v_w, v_l = torch.stack(self.transformer(xw_in, **kw)), torch.stack(self.transformer(xl_in, **kw))
         v_pol = torch.stack([v_w, v_l], dim=1).to(x_win.dtype).contiguous()
         v_ref = torch.stack([v_wr, v_lr], dim=1).to(x_win.dtype).contiguous()
         lf = self.loss_fn
