@@ -37,7 +37,7 @@ CONFIGS = {
                  label="BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720"),
     "cfg3": dict(model="COGVIDEOX_5B_I2V", frames=13, height=60, width=90, checkpoint=False, cond=True,
                  label="BASELINE configs[2]: CogVideoX-5B-I2V (32 input channels, learned positional table), 49f x 480x720 + image-cond latent"),
-    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=True, checkpoint_stride=2, cond=False,
+    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=True, checkpoint_stride=4, cond=False,
                  label="BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t=2), 81f x 768x1360 (21 latent frames, even-cropped to 20)"),
 }
 
