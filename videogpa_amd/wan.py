@@ -1,16 +1,14 @@
 """Wan2.2-TI2V flow-matching DPO step (train/Wan2.2-TI2V-5B/03_train.py:103-125,130-242) on the MI355X kernels.
 
-BLOCKED PART, stated plainly: the denoiser itself, `wan.modules.model.WanModel`, comes from an un-vendored sibling
-checkout (`sys.path.insert(0, '../../Wan2.2')`, 03_train.py:43-46) that is not in the reference tree, so there is no source
-to build a drop-in from or to check one against.  This module therefore takes the transformer as an argument -- any
-`nn.Module` with WanModel's call convention
+The denoiser, `wan.modules.model.WanModel`, comes in the reference from an un-vendored sibling checkout
+(`sys.path.insert(0, '../../Wan2.2')`, 03_train.py:43-46); here it is `videogpa_amd.wan_model.WanModel` (same constructor, module names and call
+convention, restated from the published architecture -- parity unpinned, see oracle/wan.py).  This trainer takes the transformer as an argument --
+that class, or any `nn.Module` with WanModel's call convention
         model(list of [C,F,H,W] latents, t=[B, seq_len], context=list of [L, D_text], seq_len=int) -> list of [C,F,H,W]
--- and provides everything of the step that IS in the reference: shifted-sigma noising and the velocity target
-(fused HIP pass over the paired layout, csrc/noise.hip), the clean first latent frame, the per-token timestep tensor
-with zeros on first-frame tokens, reference forwards before policy forwards, PEFT-LoRA on the q/k/v/o linears (their
-A.B contractions run the MFMA kernels of csrc/lora.hip through LoraLinear), the Diffusion-DPO loss kernel and the flat
-AdamW / all-reduce engine shared with the CogVideoX trainers.  BASELINE.json configs[4] (fp8 MFMA attention at head_dim
-128, cross-attention) waits on that source.
+-- and provides the step the reference defines: shifted-sigma noising and the velocity target (fused HIP pass over the paired layout,
+csrc/noise.hip), the clean first latent frame, the per-token timestep tensor with zeros on first-frame tokens, reference forwards before policy
+forwards, PEFT-LoRA on the q/k/v/o linears (their A.B contractions run the MFMA kernels of csrc/lora.hip through LoraLinear), the Diffusion-DPO loss
+kernel and the flat AdamW / all-reduce engine shared with the CogVideoX trainers.
 """
 from typing import Any, Dict, Optional
 
