@@ -48,3 +48,24 @@ def test_ops_fail_loudly_without_gpu():
                                     use_rotary_positional_embeddings=True).to(torch.bfloat16)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 1, 16, 4, 4, dtype=torch.bfloat16), torch.zeros(1, 2, 48, dtype=torch.bfloat16), torch.tensor([1]))
+
+
+def test_preprocess_shape_host_arithmetic_matches_the_reference_sizing():
+    """vgpa_preprocess_shape is host code (no GPU): utils/model_utils.py:36-48,54-71 -- Python's round-half-to-even included -- over a sweep of
+    frame sizes, against the oracle's restatement of those lines."""
+    import ctypes
+    from oracle import preprocess as pp
+    from videogpa_amd import _lib
+    lib = _lib.load()
+    for H in list(range(20, 1200, 37)) + [175, 189, 518, 720, 1080]:
+        for W in list(range(24, 2000, 53)) + [518, 1280, 1920]:
+            for mode, mi in (("crop", 0), ("pad", 1)):
+                nw, nh = pp.output_size(H, W, mode)
+                h, w = ctypes.c_int32(), ctypes.c_int32()
+                rc = lib.vgpa_preprocess_shape(H, W, mi, ctypes.byref(h), ctypes.byref(w))
+                if nw <= 0 or nh <= 0:
+                    assert rc != 0
+                    continue
+                assert rc == 0
+                want = (518, 518) if mode == "pad" else (min(nh, 518), nw)
+                assert (h.value, w.value) == want, (H, W, mode, (h.value, w.value), want)
