@@ -11,7 +11,9 @@
 //                                                       over M across workgroups, fp32 atomics into the small result)
 // Every product is taken transposed (D[n][m]) where that makes each lane's accumulator run along the contiguous
 // output dimension, so results leave as 8-byte row-contiguous pieces.
-#include "mfma_tiles.h"
+#include "attn_w1.h"
+
+#include <cstdlib>
 
 // ---- staging helpers with bounds (zero fill) -------------------------------------------------------------------
 // rows [row0, row0+64) x cols [col0, col0+64) of a row-major bf16 matrix; rows >= nrows or cols >= ncols read as 0
@@ -107,6 +109,103 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
                             for (int i = 0; i < 4; ++i)
                                 if (n + i < R) T[m * ldt + n + i] = f32_to_bf16(acc[a][4 * g + i]);
                         }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// down, LDS-DMA form: the same product with the [64 x 64] X chunks and the [RP x 64] A chunks streamed by `buffer_load ... lds` into a
+// ring of NS stages (chunk-swizzled image of attn_w1.h, conflict-free 16-byte fragment reads), NS - 1 chunks in flight per workgroup.
+// The register-staged kernel above has ONE chunk in flight while it computes eight MFMAs: with about one workgroup per CU (M = 18 480
+// rows -> 289 workgroups) every K step waits a full HBM round trip (56 us for 113 MB = 2.0 TB/s); with the ring the stream is
+// bandwidth-bound.  Chunks past K are requested too (they land in slots nobody reads): the hand-counted s_waitcnt stays uniform.
+// =====================================================================================================
+template <int N>
+__device__ __forceinline__ void lora_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+template <int NCB, int NS>
+__global__ __launch_bounds__(256) void lora_down_dma_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ A, bf16_t* __restrict__ T,
+                                                              int64_t ldt, int64_t M, int K, int R) {
+    constexpr int RP = 32 * NCB;
+    constexpr int NACC = (NCB + 1) / 2;
+    constexpr int STAGE = 8192 + RP * 128;           // X chunk | A chunk
+    constexpr int PW = 2 + NCB;                      // LDS-DMA pieces per wave and stage
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * STAGE];
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int rb = wave & 1, cg = wave >> 1;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t rows = (M - row0) < 64 ? (M - row0) : 64;
+
+    const W1Rsrc xrs = w1_rsrc(X + row0 * ldx, (uint32_t)(((rows - 1) * ldx + K) * 2));
+    const W1Rsrc ars = w1_rsrc(A, (uint32_t)((int64_t)R * K * 2));
+    // piece p of a chunk = rows 8p .. 8p+7; lane -> (row 8p + lane / 8, LDS chunk position lane % 8)
+    uint32_t xo[2], ao[NCB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t row = 8u * (uint32_t)(wave * 2 + i) + (uint32_t)(lane >> 3);
+        xo[i] = (uint32_t)((row * (uint64_t)ldx + (((uint32_t)(lane & 7) ^ w1_swz(row)) * 8u)) * 2u);
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+        const uint32_t row = 8u * (uint32_t)(wave * NCB + i) + (uint32_t)(lane >> 3);
+        ao[i] = (row * (uint32_t)K + (((uint32_t)(lane & 7) ^ w1_swz(row)) * 8u)) * 2u;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 2048u);
+    const uint32_t adst = __builtin_amdgcn_readfirstlane(lds0 + 8192u + (uint32_t)wave * (uint32_t)NCB * 1024u);
+    auto issue = [&](int slot) {
+        const uint32_t so = (uint32_t)slot * (uint32_t)STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { w1_dma(xdst + so + 1024u * i, xrs, xo[i], 0u); xo[i] += 128u; }
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) { w1_dma(adst + so + 1024u * i, ars, ao[i], 0u); ao[i] += 128u; }
+    };
+    f32x16_t acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    const W1Lane la = w1_lane_offsets(lane);
+    const int nk = K / 64;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t);
+    for (int t = 0; t < nk; ++t) {
+        lora_wait_vm<PW * (NS - 2)>();          // chunk t has landed (this wave's pieces); chunks t+1 .. t+NS-2 may still fly
+        __syncthreads();                        // ... for every wave, and everybody is done reading chunk t-1
+        issue((t + NS - 1) % NS);               // refill chunk t-1's slot
+        const uint32_t xb = (uint32_t)(t % NS) * (uint32_t)STAGE, ab = xb + 8192u;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8_t xf = w1_frag_row(lds, xb, la, rb, ks);
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                const int cb = cg + 2 * a;
+                if (cb < NCB) acc[a] = mfma32(w1_frag_row(lds, ab, la, cb, ks), xf, acc[a]);
+            }
+        }
+    }
+    lora_wait_vm<0>();                          // nothing may still be writing this workgroup's LDS when it retires
+    const int64_t m = row0 + rb * 32 + (lane & 31);
+    if (m < M) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const int cb = cg + 2 * a;
+            if (cb < NCB) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = cb * 32 + 8 * g + 4 * hi;
+                    if (n + 3 < R) {
+                        u32x2_t w;
+                        w[0] = pack_bf16x2(acc[a][4 * g], acc[a][4 * g + 1]);
+                        w[1] = pack_bf16x2(acc[a][4 * g + 2], acc[a][4 * g + 3]);
+                        *reinterpret_cast<u32x2_t*>(T + m * ldt + n) = w;
+                    } else {
+                        for (int i = 0; i < 4; ++i)
+                            if (n + i < R) T[m * ldt + n + i] = f32_to_bf16(acc[a][4 * g + i]);
                     }
                 }
             }
@@ -253,6 +352,21 @@ int32_t vgpa_lora_down(const void* X, int64_t ldx, const void* A, void* T, int64
     if (M > ((int64_t)1 << 31) * 32) return VGPA_ERR_INVALID;
     const int ncb = (int)((R + 31) / 32);
     const dim3 grid((unsigned)((M + 63) / 64));
+    // LDS-DMA form (descriptor offsets are 32 bit: one workgroup's 64 rows of X and the whole of A must be addressable, incl. the
+    // chunks requested past K); VGPA_LORA_DOWN_DMA=0 selects the register-staged kernel
+    static const bool dma_off = getenv("VGPA_LORA_DOWN_DMA") && getenv("VGPA_LORA_DOWN_DMA")[0] == '0';
+    // measured (tools/ew_bench.py, tools/wan_step.py): R = 64 at M = 36 960: 54 vs 59 us, equal at M = 35 552; R = 192: 136 vs 127 us (one workgroup per
+    // CU at 128 KiB of LDS) -- so the ring serves the narrow adapters only
+    if (!dma_off && ncb <= 2 && (uint64_t)64 * (uint64_t)ldx * 2 + (uint64_t)K * 2 + 1024 < (1ull << 32) && ((uint64_t)R + 8) * (uint64_t)K * 2 + 1024 < (1ull << 32)) {
+#define LDD(N, S) VGPA_LAUNCH((lora_down_dma_kernel<N, S>), grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)A, (bf16_t*)T, ldt, M, (int)K, (int)R)
+        switch (ncb) {
+            case 1: LDD(1, 4); break; case 2: LDD(2, 4); break;
+            default: return VGPA_ERR_INVALID;
+        }
+#undef LDD
+        VGPA_CHECK_LAUNCH();
+        return VGPA_OK;
+    }
     const size_t shmem = (size_t)2 * (64 + 32 * ncb) * PITCH * sizeof(bf16_t);
 #define LD(N)                                                                                                                      \
     if (hipFuncSetAttribute((const void*)lora_down_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) \
