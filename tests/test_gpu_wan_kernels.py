@@ -75,6 +75,28 @@ def test_attention128_w1_forward_long_keys_vs_fp64(B, H, Sq, Skv):
     assert (o.float() - o2.float()).abs().max().item() <= 2 ** -7 * ro.abs().max().item()
 
 
+def test_attention128_w1_kernels_on_token_major_views():
+    """the layout the Wan model uses: [B, S, H, 128] storage (projection outputs) viewed as [B, H, S, 128], long enough for all three w1 kernels"""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(123)
+    B, H, Sq, Skv = 2, 3, 1100, 1200
+    q = torch.randn(B, Sq, H, 128, device="cuda", generator=g).bfloat16().permute(0, 2, 1, 3)
+    kv = torch.randn(B, Skv, 2, H, 128, device="cuda", generator=g).bfloat16()
+    k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+    do = torch.randn(B, Sq, H, 128, device="cuda", generator=g).bfloat16().permute(0, 2, 1, 3)
+    qg, kg, vg = (t.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for t in (q, k, v))
+    assert not qg.is_contiguous() and qg.stride(3) == 1
+    o = ops.attention128(qg, kg, vg, 128 ** -0.5)
+    assert o.permute(0, 2, 1, 3).is_contiguous()                       # token-major storage behind the view
+    o.backward(do)
+    assert qg.grad.shape == q.shape
+    ro, rq, rk, rv = _ref(q, k, v, do, 128 ** -0.5)
+    _close(o, ro, "o")
+    _close(qg.grad, rq, "dq")
+    _close(kg.grad, rk, "dk")
+    _close(vg.grad, rv, "dv")
+
+
 def test_attention128_w1_outlier_rows_take_the_redo_path():
     """a query row 40x larger than the rest: its bound M exceeds 160 -> the strip is flagged and redone with the running-max kernel; a key
     40x larger makes EVERY bound loose (sums underflow) -> all strips redone.  Results must stay within the usual tolerance either way."""
