@@ -227,29 +227,40 @@ int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void
 /* ---- row kernels of the Wan2.2 denoiser block (WanAttentionBlock / WanRMSNorm / rope_apply of the Wan2.2 checkout imported at
  * train/Wan2.2-TI2V-5B/03_train.py:43-48).  fp32 residual stream, bf16 matmul operands.  Per-token modulation as a table: row
  * gid[row] of a [groups, mod_stride] fp32 table (shift / scale / gate point at their chunk's column offset); gid NULL = row 0.
- *   ln_mod_fwd : out(bf16) = ([round_bf16] LN_eps(x)) * ln_w + ln_b, then * (1 + scale[g]) + shift[g]   (affine / modulation optional;
- *                x_dtype VGPA_DTYPE_F32 | VGPA_DTYPE_BF16)             ln_mod_bwd: dx(fp32) = [dres +] LN-backward(dy (1 + scale) ln_w)
- *   gate_residual: out(fp32) = [x +] y(bf16) * gate[g]  (gate NULL = 1; out may alias x)       gate_bwd: dy(bf16) = dout(fp32) * gate[g]
+ *   ln_mod_fwd : out(bf16, row stride out_ld >= D: the LoRA tail of the consuming projection may follow each row) = ([round_bf16] LN_eps(x)) * ln_w
+ *                + ln_b, then * (1 + scale[g]) + shift[g]   (affine / modulation optional; x_dtype VGPA_DTYPE_F32 | VGPA_DTYPE_BF16); with q8 / q8_scale the
+ *                same rows are ALSO (or, out NULL, only) written as the e4m3 operand of the fp8 feed-forward GEMM: q8 [rows, D] bytes, q8_scale [rows]
+ *                fp32, bit-identical to vgpa_quant_fp8_rows of the bf16 output
+ *   ln_mod_bwd : dx(fp32) = [dres +] LN-backward(dy (1 + scale) ln_w)
+ *   gate_residual: out(fp32) = [x +] y(bf16) * gate[g]  (gate NULL = 1; out may alias x)
+ *   gate_bwd   : dy(bf16, row stride ld_dy) = dout(fp32) * gate[g];   gate_bwd_q8: the same rows as e4m3 + per-row scale (fp8 dX GEMM operand)
  *   rms_rope   : n = bf16(u rsqrt(mean(u^2) + eps)) over the whole row [heads * head_dim]; y = bf16(n w); interleaved pairs of every head
- *                rotated by the angle at rope_{cos,sin}[(row % L) * head_dim/2 + pair]  (NULL: no rotation)  */
+ *                rotated by the angle at rope_{cos,sin}[(row % L) * head_dim/2 + pair]  (NULL: no rotation); u / out / dout / du are row-strided
+ *                (ld_* in elements) so that q and k are read from and their gradients written into the fused [rows, 3 D (+ LoRA tail)] buffers */
 int32_t vgpa_wan_ln_mod_fwd(const void* x, int32_t x_dtype, const int32_t* gid, const float* ln_w, const float* ln_b, const float* shift,
-                            const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, int32_t round_xhat, void* out, float* mean,
-                            float* rstd, vgpa_stream_t stream);
+                            const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, int32_t round_xhat, void* out, int64_t out_ld,
+                            void* q8, float* q8_scale, float* mean, float* rstd, vgpa_stream_t stream);
 int32_t vgpa_wan_ln_mod_bwd(const void* dy, const void* x, int32_t x_dtype, const float* mean, const float* rstd, const int32_t* gid, const float* ln_w,
                             const float* scale, int64_t mod_stride, int64_t rows, int64_t D, const float* dres, float* dx, vgpa_stream_t stream);
 int32_t vgpa_wan_gate_residual(const float* x, const void* y, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, float* out,
                                vgpa_stream_t stream);
-int32_t vgpa_wan_gate_bwd(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* dy,
+int32_t vgpa_wan_gate_bwd(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* dy, int64_t ld_dy,
                           vgpa_stream_t stream);
-int32_t vgpa_wan_rms_rope_fwd(const void* u, const void* w, const float* rope_cos, const float* rope_sin, int64_t L, int64_t head_dim, int64_t rows,
-                              int64_t D, float eps, void* out, float* rstd, vgpa_stream_t stream);
-int32_t vgpa_wan_rms_rope_bwd(const void* dout, const void* u, const float* rstd, const void* w, const float* rope_cos, const float* rope_sin, int64_t L,
-                              int64_t head_dim, int64_t rows, int64_t D, void* du, vgpa_stream_t stream);
+int32_t vgpa_wan_gate_bwd_q8(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* q8,
+                             float* q8_scale, vgpa_stream_t stream);
+int32_t vgpa_wan_rms_rope_fwd(const void* u, int64_t ld_u, const void* w, const float* rope_cos, const float* rope_sin, int64_t L, int64_t head_dim,
+                              int64_t rows, int64_t D, float eps, void* out, int64_t ld_out, float* rstd, vgpa_stream_t stream);
+int32_t vgpa_wan_rms_rope_bwd(const void* dout, int64_t ld_dout, const void* u, int64_t ld_u, const float* rstd, const void* w, const float* rope_cos,
+                              const float* rope_sin, int64_t L, int64_t head_dim, int64_t rows, int64_t D, void* du, int64_t ld_du, vgpa_stream_t stream);
 
 /* ---- fp8 operand preparation for the frozen feed-forward GEMMs of the Wan2.2 path (BASELINE.json configs[4]: "fp8 MFMA path"):
  * per-row dynamic quantisation of bf16 rows to OCP e4m3: scale[m] = amax(row) / 448 (1 for a zero row), q = e4m3(x / scale), RNE, saturating.
  * x [M, K] bf16 with row stride ldx (elements); q [M, K] bytes, contiguous; scale [M] fp32. */
 int32_t vgpa_quant_fp8_rows(const void* x, int64_t ldx, void* q, float* scale, int64_t M, int64_t K, vgpa_stream_t stream);
+/* the feed-forward's activation written as that operand by its producer: q8 = e4m3(bf16(gelu_tanh(u)) / scale) resp. of bf16(dy * gelu_tanh'(u));
+ * u / dy [rows, K] bf16 contiguous, K <= 16384; bit-identical to vgpa_gelu_tanh_{fwd,bwd} followed by vgpa_quant_fp8_rows */
+int32_t vgpa_gelu_tanh_fwd_q8(const void* u, int64_t rows, int64_t K, void* q8, float* q8_scale, vgpa_stream_t stream);
+int32_t vgpa_gelu_tanh_bwd_q8(const void* u, const void* dy, int64_t rows, int64_t K, void* q8, float* q8_scale, vgpa_stream_t stream);
 
 /* ---- VGGT input preprocessing: utils/model_utils.py:16-85 preprocess_images_from_numpy (PIL bicubic resize to width 518 /
  * longer side 518, ToTensor, centre crop or white pad).  frames uint8 [T, H, W, 3] -> out float32 [T, 3, out_h, out_w].

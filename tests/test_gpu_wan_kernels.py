@@ -250,3 +250,101 @@ def test_frozen_linear_fp8_forward_backward_against_fp32():
     rdx = dy.float() @ W.float()
     assert y.dtype == torch.bfloat16 and ((y.float() - ry).norm() / ry.norm()).item() < 0.04
     assert ((x.grad.float() - rdx).norm() / rdx.norm()).item() < 0.04
+
+
+def _same_q8(q, sc, ref_q, ref_sc, what):
+    """fused producers against the unfused chain: identical scales; identical bytes (the float expressions are the same source, but the compiler
+    may contract them differently inside a different kernel, so a 1-ulp-of-bf16 difference before quantisation is tolerated on <= 0.1 % of the bytes)"""
+    assert torch.equal(sc, ref_sc) or (sc - ref_sc).abs().max().item() <= 2 ** -7 * ref_sc.abs().max().item(), what
+    a, b = q.view(torch.uint8), ref_q.view(torch.uint8)
+    frac = (a != b).float().mean().item()
+    assert frac <= 1e-3, (what, frac)
+    assert (q.float() * sc - ref_q.float() * ref_sc).abs().max().item() <= 0.13 * (ref_q.float() * ref_sc).abs().max().item(), what
+
+
+def test_fp8_operands_written_by_their_producers_match_the_unfused_chain():
+    """vgpa_wan_ln_mod_fwd(q8), vgpa_gelu_tanh_{fwd,bwd}_q8, vgpa_wan_gate_bwd_q8  ==  bf16 producer + vgpa_quant_fp8_rows"""
+    from videogpa_amd import _lib, ops
+    from videogpa_amd.wan_model import ln_mod
+    g = torch.Generator(device="cuda").manual_seed(21)
+    st = torch.cuda.current_stream().cuda_stream
+    rows, C, F, G = 203, 3072, 14336, 3
+    x = torch.randn(rows, C, device="cuda", generator=g) * 2 + 0.3
+    gid = torch.randint(0, G, (rows,), device="cuda", generator=g).int()
+    tab = _tab(G, 6, C, g)
+    # LN + modulation
+    h = ln_mod(x, gid, None, None, tab[:, 3], tab[:, 4], 1e-6)
+    rq, rs = ops.quant_fp8_rows(h)
+    q = torch.empty(rows, C, dtype=torch.float8_e4m3fn, device="cuda"); sc = torch.empty(rows, 1, device="cuda")
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    h2 = torch.empty(rows, C + 64, dtype=torch.bfloat16, device="cuda")
+    _lib.call("vgpa_wan_ln_mod_fwd", x, 0, gid, None, None, tab[:, 3], tab[:, 4], tab.stride(0), rows, C, 1e-6, 0, h2, C + 64, q, sc, mean, rstd, st)
+    assert torch.equal(h2[:, :C], h)                                     # strided bf16 output next to the e4m3 one
+    _same_q8(q, sc, rq, rs, "ln_mod")
+    # GELU forward / backward
+    u = (torch.randn(rows, F, device="cuda", generator=g) * 1.5).bfloat16()
+    dy = torch.randn(rows, F, device="cuda", generator=g).bfloat16()
+    ug = u.clone().requires_grad_(True)
+    a = ops.gelu_tanh(ug)
+    a.backward(dy)
+    _same_q8(*ops.gelu_tanh_fwd_q8(u), *ops.quant_fp8_rows(a.detach()), "gelu fwd")
+    _same_q8(*ops.gelu_tanh_bwd_q8(u, dy), *ops.quant_fp8_rows(ug.grad), "gelu bwd")
+    # gate backward
+    dout = torch.randn(rows, C, device="cuda", generator=g)
+    ref = (dout * tab[:, 5][gid.long()]).bfloat16()
+    _lib.call("vgpa_wan_gate_bwd_q8", dout, gid, tab[:, 5], tab.stride(0), rows, C, q, sc, st)
+    _same_q8(q, sc, *ops.quant_fp8_rows(ref), "gate bwd")
+    z = torch.zeros(4, C, device="cuda")
+    _lib.call("vgpa_wan_gate_bwd_q8", z, None, None, 0, 4, C, q[:4], sc[:4], st)
+    assert torch.equal(sc[:4], torch.ones(4, 1, device="cuda")) and not q[:4].view(torch.uint8).any()      # all-zero rows: scale 1
+
+
+def test_wan_ffn_fp8_branch_equals_the_composed_ops():
+    """_FfnFp8Fn (one autograd node, operands quantised by their producers, residual gradient added inside the LN backward) against the same
+    branch composed from ln_mod / frozen_linear_fp8 / gelu_tanh / gate_residual: output and input gradient to fp32 rounding of the one add that moved."""
+    from videogpa_amd import ops
+    from videogpa_amd.wan_model import ffn_fp8, gate_residual, ln_mod
+    g = torch.Generator(device="cuda").manual_seed(22)
+    rows, C, F, G = 260, 1024, 2048, 2
+    x = torch.randn(rows, C, device="cuda", generator=g)
+    gid = torch.randint(0, G, (rows,), device="cuda", generator=g).int()
+    tab = _tab(G, 6, C, g)
+    W1 = (torch.randn(F, C, device="cuda", generator=g) / C ** 0.5).bfloat16(); b1 = (0.1 * torch.randn(F, device="cuda", generator=g)).bfloat16()
+    W2 = (torch.randn(C, F, device="cuda", generator=g) / F ** 0.5).bfloat16(); b2 = (0.1 * torch.randn(C, device="cuda", generator=g)).bfloat16()
+    dout = torch.randn(rows, C, device="cuda", generator=g)
+    xa = x.clone().requires_grad_(True)
+    ya = ffn_fp8(xa, gid, tab[:, 3], tab[:, 4], tab[:, 5], 1e-6, W1, b1, W2, b2)
+    ya.backward(dout)
+    xb = x.clone().requires_grad_(True)
+    h = ln_mod(xb, gid, None, None, tab[:, 3], tab[:, 4], 1e-6)
+    y = ops.frozen_linear_fp8(ops.gelu_tanh(ops.frozen_linear_fp8(h, W1, b1)), W2, b2)
+    yb = gate_residual(xb, y, gid, tab[:, 5])
+    yb.backward(dout)
+    assert (ya - yb).abs().max().item() <= 2e-2 * yb.abs().max().item() and ((ya - yb).norm() / yb.norm()).item() <= 1e-3
+    assert ((xa.grad - xb.grad).norm() / xb.grad.norm()).item() <= 1e-3
+
+
+def test_wan_self_attention_core_on_the_fused_qkv_buffer():
+    """_SelfAttnFn (q / k normalised from strided slices of the fused projection output, v read in place, gradients written into one padded
+    [B, L, 3 D + pad] buffer) against rms_rope + attention128 on separate contiguous tensors: identical kernels, identical results"""
+    from videogpa_amd import ops
+    from videogpa_amd.wan_model import _SelfAttnFn, rms_rope, rope_tables
+    g = torch.Generator(device="cuda").manual_seed(23)
+    B, grid, H, d = 2, (3, 6, 8), 2, 128
+    L, D = grid[0] * grid[1] * grid[2], H * d
+    qkv = (torch.randn(B, L, 3 * D, device="cuda", generator=g) * 1.3).bfloat16()
+    wq = (1 + 0.2 * torch.randn(D, device="cuda", generator=g)).bfloat16(); wk = (1 + 0.2 * torch.randn(D, device="cuda", generator=g)).bfloat16()
+    do = torch.randn(B, L, D, device="cuda", generator=g).bfloat16()
+    cos, sin = rope_tables(grid, d, "cuda")
+    a = qkv.clone().requires_grad_(True)
+    oa = _SelfAttnFn.apply(a, wq, wk, cos, sin, H, 1e-6, 16, 48)
+    assert ops._padded_base(oa.reshape(B * L, D), D + 16) is not None
+    oa.backward(do)
+    assert ops._padded_base(a.grad.reshape(B * L, 3 * D), 3 * D + 48) is not None or a.grad.shape == (B, L, 3 * D)
+    b = qkv.clone().requires_grad_(True)
+    q, k, v = b[:, :, :D].contiguous(), b[:, :, D:2 * D].contiguous(), b[:, :, 2 * D:].contiguous()
+    hd = lambda t: t.view(B, L, H, d).permute(0, 2, 1, 3)
+    ob = ops.attention128(hd(rms_rope(q, wq, cos, sin, d, 1e-6)), hd(rms_rope(k, wk, cos, sin, d, 1e-6)), hd(v)).permute(0, 2, 1, 3).reshape(B, L, D)
+    ob.backward(do)
+    assert torch.equal(oa, ob)
+    assert torch.equal(a.grad, b.grad)

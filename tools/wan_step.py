@@ -17,6 +17,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--frames", type=int, default=21)
 ap.add_argument("--out", default="")
 ap.add_argument("--fp8", action="store_true")
+ap.add_argument("--ckpt-stride", type=int, default=1, help="recompute every k-th block; 0 = keep all activations (no recompute)")
 a = ap.parse_args()
 torch.manual_seed(0)
 dev = "cuda"
@@ -26,7 +27,7 @@ with torch.device(dev):
     torch.set_default_dtype(torch.float32)
 with torch.no_grad():
     torch.nn.init.normal_(m.head.head.weight, std=0.02)
-m.enable_gradient_checkpointing(True)
+m.enable_gradient_checkpointing(a.ckpt_stride > 0, max(1, a.ckpt_stride))
 m.enable_fp8(a.fp8)
 tr = WanDPOTrainer({}, m)
 opt = tr.configure_optimizers()
@@ -56,7 +57,7 @@ torch.cuda.synchronize()
 summ = ops.TIMER.summary()
 ops.TIMER = None
 tot = sum(v["total_ms"] for v in summ.values())
-res = {"workload": f"Wan2.2-TI2V-5B pair step, {a.layers} layers, 48x{a.frames}x44x80 latent, batch 1, LoRA r64, ckpt" + (", fp8 feed-forward" if a.fp8 else ""), "s_per_step": dt, "pair_steps_per_s": 1 / dt,
+res = {"workload": f"Wan2.2-TI2V-5B pair step, {a.layers} layers, 48x{a.frames}x44x80 latent, batch 1, LoRA r64, " + ("no recompute" if a.ckpt_stride == 0 else f"recompute every {a.ckpt_stride}. block") + (", fp8 feed-forward" if a.fp8 else ""), "s_per_step": dt, "pair_steps_per_s": 1 / dt,
        "loss": float(loss.detach()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "timed_kernels_ms": tot, "kernels": {}}
 print(f"{res['workload']}: {dt:.3f} s/step, loss {float(loss.detach()):.4f}, peak {res['peak_mem_GB']:.1f} GB; timed kernels {tot:.0f} ms")
 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):

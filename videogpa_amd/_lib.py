@@ -61,13 +61,16 @@ SIGNATURES = {
     "vgpa_attn128_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
     "vgpa_attn128_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn128_bwd": (I32, [P] * 17 + [I64, I64, I64, I64, F32, I32, P, SZ, P]),
-    "vgpa_wan_ln_mod_fwd": (I32, [P, I32, P, P, P, P, P, I64, I64, I64, F32, I32, P, P, P, P]),
+    "vgpa_wan_ln_mod_fwd": (I32, [P, I32, P, P, P, P, P, I64, I64, I64, F32, I32, P, I64, P, P, P, P, P]),
     "vgpa_wan_ln_mod_bwd": (I32, [P, P, I32, P, P, P, P, P, I64, I64, I64, P, P, P]),
     "vgpa_wan_gate_residual": (I32, [P, P, P, P, I64, I64, I64, P, P]),
-    "vgpa_wan_gate_bwd": (I32, [P, P, P, I64, I64, I64, P, P]),
-    "vgpa_wan_rms_rope_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, F32, P, P, P]),
-    "vgpa_wan_rms_rope_bwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, P, P]),
+    "vgpa_wan_gate_bwd": (I32, [P, P, P, I64, I64, I64, P, I64, P]),
+    "vgpa_wan_gate_bwd_q8": (I32, [P, P, P, I64, I64, I64, P, P, P]),
+    "vgpa_wan_rms_rope_fwd": (I32, [P, I64, P, P, P, I64, I64, I64, I64, F32, P, I64, P, P]),
+    "vgpa_wan_rms_rope_bwd": (I32, [P, I64, P, I64, P, P, P, P, I64, I64, I64, I64, P, I64, P]),
     "vgpa_quant_fp8_rows": (I32, [P, I64, P, P, I64, I64, P]),
+    "vgpa_gelu_tanh_fwd_q8": (I32, [P, I64, I64, P, P, P]),
+    "vgpa_gelu_tanh_bwd_q8": (I32, [P, P, I64, I64, P, P, P]),
     "vgpa_preprocess_shape": (I32, [I32, I32, I32, P, P]),
     "vgpa_preprocess_workspace_bytes": (SZ, [I32, I32, I32, I32]),
     "vgpa_preprocess_frames": (I32, [P, I32, I32, I32, I32, P, P, SZ, P]),

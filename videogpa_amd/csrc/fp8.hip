@@ -44,6 +44,93 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
     }
 }
 
+// ---- producers that write the e4m3 operand themselves (no bf16 round trip through HBM): GELU forward / backward of the feed-forward.
+// One 256-thread workgroup per row, the row (<= 16384 wide) in registers as bf16-rounded values; results are bit-identical to the unfused
+// chain  gelu_tanh_{fwd,bwd} -> quant_fp8_rows  (tests/test_gpu_wan_kernels.py).
+#define Q8_NV 8
+#define GELU_K1 (-2.302208198f)      // as csrc/norm.hip
+#define GELU_K2 (-0.1029432396f)
+__device__ __forceinline__ float q8_gelu_sig(float x, float x2) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (GELU_K1 + GELU_K2 * x2))); }
+
+__device__ __forceinline__ float q8_block_max(float v, float* smem) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(smem[0], smem[1]), fmaxf(smem[2], smem[3]));
+}
+
+__device__ __forceinline__ void q8_store_row(const float (*v)[8], int K, float sc, uint8_t* __restrict__ qr) {
+#pragma unroll
+    for (int c = 0; c < Q8_NV; ++c) {
+        const int i0 = (c * 256 + (int)threadIdx.x) * 8;
+        if (i0 < K) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(v[c][j] / sc, -FP8_E4M3_MAX), FP8_E4M3_MAX);
+            u32x2_t w;
+            int p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], p, true);
+            w[0] = (uint32_t)p;
+            p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], p, true);
+            w[1] = (uint32_t)p;
+            *reinterpret_cast<u32x2_t*>(qr + i0) = w;
+        }
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_q8_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dy, int K, uint8_t* __restrict__ q,
+                                                        float* __restrict__ scale) {
+    __shared__ float smem[4];
+    const int64_t row = blockIdx.x;
+    const bf16_t* ur = u + (size_t)row * K;
+    float v[Q8_NV][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < Q8_NV; ++c) {
+        const int i0 = (c * 256 + (int)threadIdx.x) * 8;
+        if (i0 < K) {
+            float a[8], g[8];
+            load8<VGPA_DTYPE_BF16>(ur, (size_t)i0, a);
+            if (BWD) load8<VGPA_DTYPE_BF16>(dy + (size_t)row * K, (size_t)i0, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = a[j], x2 = x * x, sg = q8_gelu_sig(x, x2);
+                float r;
+                if (BWD) {
+                    const float dz2 = 1.5957691216057308f + 0.2140644488f * x2;
+                    r = g[j] * (sg + x * (sg - sg * sg) * dz2);
+                } else {
+                    r = x * sg;
+                }
+                v[c][j] = round_bf16(r);
+                amax = fmaxf(amax, fabsf(v[c][j]));
+            }
+        }
+    }
+    amax = q8_block_max(amax, smem);
+    const float sc = amax > 0.f ? amax / FP8_E4M3_MAX : 1.f;
+    if (threadIdx.x == 0) scale[row] = sc;
+    q8_store_row(v, K, sc, q + (size_t)row * K);
+}
+
+extern "C" int32_t vgpa_gelu_tanh_fwd_q8(const void* u, int64_t rows, int64_t K, void* q8, float* q8_scale, hipStream_t stream) {
+    if (!u || !q8 || !q8_scale || rows <= 0 || K <= 0 || K % 8 || K > 256 * 8 * Q8_NV) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(gelu_q8_kernel<false>, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)u, (const bf16_t*)nullptr, (int)K, (uint8_t*)q8, q8_scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_gelu_tanh_bwd_q8(const void* u, const void* dy, int64_t rows, int64_t K, void* q8, float* q8_scale, hipStream_t stream) {
+    if (!u || !dy || !q8 || !q8_scale || rows <= 0 || K <= 0 || K % 8 || K > 256 * 8 * Q8_NV) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(gelu_q8_kernel<true>, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)u, (const bf16_t*)dy, (int)K, (uint8_t*)q8, q8_scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
 extern "C" int32_t vgpa_quant_fp8_rows(const void* x, int64_t ldx, void* q, float* scale, int64_t M, int64_t K, hipStream_t stream) {
     if (!x || !q || !scale || M <= 0 || K <= 0 || K % 8 || ldx < K || ldx % 8 || K > (1 << 24)) return VGPA_ERR_INVALID;
     VGPA_LAUNCH(quant_fp8_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (uint8_t*)q, scale, M, (int)K);

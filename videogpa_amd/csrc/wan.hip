@@ -14,14 +14,48 @@
 
 __device__ __forceinline__ int64_t wan_row() { return (int64_t)blockIdx.x * WAN_WAVES + (threadIdx.x >> 6); }
 
-// y = [round_bf16](LN(x)) * w + b, then * (1 + scale[g]) + shift[g]  ->  bf16            (w, b, scale / shift optional)
+// one row held by a wave as v[c][j] (already rounded to bf16) -> e4m3 + the row's scale, the arithmetic of quant_fp8_rows_kernel (csrc/fp8.hip)
+__device__ __forceinline__ void wan_quant_row(const float (*v)[8], int D, int lane, uint8_t* __restrict__ qr, float* __restrict__ scale) {
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c)
+        if ((c * 64 + lane) * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[c][j]));
+        }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.f;
+    if (lane == 0) *scale = sc;
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(v[c][j] / sc, -448.0f), 448.0f);
+            u32x2_t w;
+            int p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], p, true);
+            w[0] = (uint32_t)p;
+            p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], p, true);
+            w[1] = (uint32_t)p;
+            *reinterpret_cast<u32x2_t*>(qr + i0) = w;
+        }
+    }
+}
+
+// y = [round_bf16](LN(x)) * w + b, then * (1 + scale[g]) + shift[g]  ->  bf16 (row stride out_ld) and / or e4m3 + per-row scale   (w, b, scale / shift optional)
 // mod: table row stride `mod_stride` floats, shift at column offset 0 of `shift`, scale of `scale` (pointers into the same table)
 template <int XDT>
 __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const void* __restrict__ x, const int* __restrict__ gid, const float* __restrict__ w,
                                                                           const float* __restrict__ b, const float* __restrict__ shift,
                                                                           const float* __restrict__ scale, int64_t mod_stride, int D, int64_t rows, float eps,
-                                                                          int round_xhat, bf16_t* __restrict__ out, float* __restrict__ mean_out,
-                                                                          float* __restrict__ rstd_out) {
+                                                                          int round_xhat, bf16_t* __restrict__ out, int64_t out_ld,
+                                                                          uint8_t* __restrict__ q8, float* __restrict__ q8_scale,
+                                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int64_t row = wan_row();
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -69,9 +103,14 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const vo
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = o[j] * (1.f + t0[j]) + t1[j];
             }
-            store8<VGPA_DTYPE_BF16>(out, (size_t)row * D + i0, o);
+            if (out) store8<VGPA_DTYPE_BF16>(out, (size_t)row * out_ld + i0, o);
+            if (q8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = round_bf16(o[j]);       // the e4m3 operand is made from the bf16 value, as quant_fp8_rows does
+            }
         }
     }
+    if (q8) wan_quant_row(v, D, lane, q8 + (size_t)row * D, q8_scale + row);
 }
 
 // dx = [dres +] LN-backward(dy * (1 + scale[g]) * w)           fp32 out (may alias dres)
@@ -147,7 +186,7 @@ __global__ __launch_bounds__(256) void wan_gate_residual_kernel(const float* x, 
 }
 // dy(bf16) = dout(fp32) * gate[g]
 __global__ __launch_bounds__(256) void wan_gate_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ gid, const float* __restrict__ gate,
-                                                             int64_t mod_stride, int D, int64_t rows, bf16_t* __restrict__ dy) {
+                                                             int64_t mod_stride, int D, int64_t rows, bf16_t* __restrict__ dy, int64_t ld_dy) {
     const int per_row = D / 8;
     const int64_t total = rows * per_row;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -162,8 +201,30 @@ __global__ __launch_bounds__(256) void wan_gate_bwd_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] *= gt[j];
         }
-        store8<VGPA_DTYPE_BF16>(dy, (size_t)row * D + i0, o);
+        store8<VGPA_DTYPE_BF16>(dy, (size_t)row * ld_dy + i0, o);
     }
+}
+// the same product written as the e4m3 operand of the feed-forward's fp8 dX GEMM: q8 = e4m3(bf16(dout * gate[g]) / scale), one wave per row
+__global__ __launch_bounds__(64 * WAN_WAVES) void wan_gate_bwd_q8_kernel(const float* __restrict__ dout, const int* __restrict__ gid, const float* __restrict__ gate,
+                                                                           int64_t mod_stride, int D, int64_t rows, uint8_t* __restrict__ q8,
+                                                                           float* __restrict__ q8_scale) {
+    const int64_t row = wan_row();
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* gp = gate ? gate + (gid ? (size_t)gid[row] * mod_stride : 0) : nullptr;
+    float v[WAN_NV][8];
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        if (i0 < D) {
+            load8<VGPA_DTYPE_F32>(dout, (size_t)row * D + i0, v[c]);
+            float gt[8];
+            if (gp) load8<VGPA_DTYPE_F32>(gp, (size_t)i0, gt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = round_bf16(gp ? v[c][j] * gt[j] : v[c][j]);
+        }
+    }
+    wan_quant_row(v, D, lane, q8 + (size_t)row * D, q8_scale + row);
 }
 
 // WanRMSNorm over the whole row + bf16 weight + RoPE on interleaved pairs of each head (head_dim = 2 * half, pair p of every head
@@ -171,7 +232,7 @@ __global__ __launch_bounds__(256) void wan_gate_bwd_kernel(const float* __restri
 //   n = bf16(u * rsqrt(mean(u^2) + eps));  y = bf16(n * w);  (a, b) -> (a cos - b sin, a sin + b cos)
 __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_fwd_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ w, const float* __restrict__ rope_cos,
                                                                             const float* __restrict__ rope_sin, int L, int half, int D, int64_t rows, float eps,
-                                                                            bf16_t* __restrict__ out, float* __restrict__ rstd_out) {
+                                                                            int64_t ld_u, bf16_t* __restrict__ out, int64_t ld_out, float* __restrict__ rstd_out) {
     const int64_t row = wan_row();
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -181,7 +242,7 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_fwd_kernel(const 
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
-            load8<VGPA_DTYPE_BF16>(u, (size_t)row * D + i0, v[c]);
+            load8<VGPA_DTYPE_BF16>(u, (size_t)row * ld_u + i0, v[c]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sq += v[c][j] * v[c][j];
         }
@@ -207,7 +268,7 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_fwd_kernel(const 
                     o[j + 1] = a * sn + bb * cs;
                 }
             }
-            store8<VGPA_DTYPE_BF16>(out, (size_t)row * D + i0, o);
+            store8<VGPA_DTYPE_BF16>(out, (size_t)row * ld_out + i0, o);
         }
     }
 }
@@ -215,7 +276,7 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_fwd_kernel(const 
 __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ u, const float* __restrict__ rstd,
                                                                             const bf16_t* __restrict__ w, const float* __restrict__ rope_cos,
                                                                             const float* __restrict__ rope_sin, int L, int half, int D, int64_t rows,
-                                                                            bf16_t* __restrict__ du) {
+                                                                            int64_t ld_dout, int64_t ld_u, bf16_t* __restrict__ du, int64_t ld_du) {
     const int64_t row = wan_row();
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -228,8 +289,8 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_bwd_kernel(const 
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
             float wv[8];
-            load8<VGPA_DTYPE_BF16>(dout, (size_t)row * D + i0, dn[c]);
-            load8<VGPA_DTYPE_BF16>(u, (size_t)row * D + i0, n[c]);
+            load8<VGPA_DTYPE_BF16>(dout, (size_t)row * ld_dout + i0, dn[c]);
+            load8<VGPA_DTYPE_BF16>(u, (size_t)row * ld_u + i0, n[c]);
             load8<VGPA_DTYPE_BF16>(w, (size_t)i0, wv);
             if (rope_cos) {
                 const int p0 = (i0 % (2 * half)) / 2;
@@ -257,7 +318,7 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_bwd_kernel(const 
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = rs * (dn[c][j] - n[c][j] * m);
-            store8<VGPA_DTYPE_BF16>(du, (size_t)row * D + i0, o);
+            store8<VGPA_DTYPE_BF16>(du, (size_t)row * ld_du + i0, o);
         }
     }
 }
@@ -268,17 +329,17 @@ static inline dim3 wan_grid(int64_t rows) { return dim3((unsigned)((rows + WAN_W
 static inline dim3 wan_ew_grid(int64_t n8) { const int64_t b = (n8 + 255) / 256; return dim3((unsigned)(b < 65536 ? b : 65536)); }
 
 extern "C" int32_t vgpa_wan_ln_mod_fwd(const void* x, int32_t x_dtype, const int32_t* gid, const float* ln_w, const float* ln_b, const float* shift,
-                                       const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, int32_t round_xhat, void* out, float* mean,
-                                       float* rstd, hipStream_t stream) {
-    if (!x || !out || !wan_dims_ok(rows, D) || (ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale == nullptr) ||
-        (mean == nullptr) != (rstd == nullptr))
+                                       const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, int32_t round_xhat, void* out, int64_t out_ld,
+                                       void* q8, float* q8_scale, float* mean, float* rstd, hipStream_t stream) {
+    if (!x || (!out && !q8) || !wan_dims_ok(rows, D) || (ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale == nullptr) ||
+        (mean == nullptr) != (rstd == nullptr) || (q8 == nullptr) != (q8_scale == nullptr) || (out && (out_ld < D || out_ld % 8)))
         return VGPA_ERR_INVALID;
     if (x_dtype == VGPA_DTYPE_F32)
         VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, x, gid, ln_w, ln_b, shift, scale, mod_stride, (int)D, rows,
-                    eps, round_xhat, (bf16_t*)out, mean, rstd);
+                    eps, round_xhat, (bf16_t*)out, out_ld, (uint8_t*)q8, q8_scale, mean, rstd);
     else if (x_dtype == VGPA_DTYPE_BF16)
         VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_BF16>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, x, gid, ln_w, ln_b, shift, scale, mod_stride, (int)D, rows,
-                    eps, round_xhat, (bf16_t*)out, mean, rstd);
+                    eps, round_xhat, (bf16_t*)out, out_ld, (uint8_t*)q8, q8_scale, mean, rstd);
     else
         return VGPA_ERR_INVALID;
     VGPA_CHECK_LAUNCH();
@@ -309,29 +370,39 @@ extern "C" int32_t vgpa_wan_gate_residual(const float* x, const void* y, const i
 }
 
 extern "C" int32_t vgpa_wan_gate_bwd(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* dy,
-                                     hipStream_t stream) {
-    if (!dout || !dy || rows <= 0 || D <= 0 || D % 8) return VGPA_ERR_INVALID;
-    VGPA_LAUNCH(wan_gate_bwd_kernel, wan_ew_grid(rows * (D / 8)), dim3(256), 0, stream, dout, gid, gate, mod_stride, (int)D, rows, (bf16_t*)dy);
+                                     int64_t ld_dy, hipStream_t stream) {
+    if (!dout || !dy || rows <= 0 || D <= 0 || D % 8 || ld_dy < D || ld_dy % 8) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(wan_gate_bwd_kernel, wan_ew_grid(rows * (D / 8)), dim3(256), 0, stream, dout, gid, gate, mod_stride, (int)D, rows, (bf16_t*)dy, ld_dy);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
 
-extern "C" int32_t vgpa_wan_rms_rope_fwd(const void* u, const void* w, const float* rope_cos, const float* rope_sin, int64_t L, int64_t head_dim, int64_t rows,
-                                         int64_t D, float eps, void* out, float* rstd, hipStream_t stream) {
+extern "C" int32_t vgpa_wan_gate_bwd_q8(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* q8,
+                                        float* q8_scale, hipStream_t stream) {
+    if (!dout || !q8 || !q8_scale || !wan_dims_ok(rows, D)) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH(wan_gate_bwd_q8_kernel, wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, dout, gid, gate, mod_stride, (int)D, rows, (uint8_t*)q8, q8_scale);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_rms_rope_fwd(const void* u, int64_t ld_u, const void* w, const float* rope_cos, const float* rope_sin, int64_t L, int64_t head_dim,
+                                         int64_t rows, int64_t D, float eps, void* out, int64_t ld_out, float* rstd, hipStream_t stream) {
     if (!u || !w || !out || !wan_dims_ok(rows, D) || (rope_cos == nullptr) != (rope_sin == nullptr)) return VGPA_ERR_INVALID;
+    if (ld_u < D || ld_u % 8 || ld_out < D || ld_out % 8) return VGPA_ERR_INVALID;
     if (rope_cos && (L <= 0 || head_dim <= 0 || head_dim % 8 || D % head_dim)) return VGPA_ERR_INVALID;
     VGPA_LAUNCH(wan_rms_rope_fwd_kernel, wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)u, (const bf16_t*)w, rope_cos, rope_sin, (int)(rope_cos ? L : 1),
-                (int)(rope_cos ? head_dim / 2 : 1), (int)D, rows, eps, (bf16_t*)out, rstd);
+                (int)(rope_cos ? head_dim / 2 : 1), (int)D, rows, eps, ld_u, (bf16_t*)out, ld_out, rstd);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
 
-extern "C" int32_t vgpa_wan_rms_rope_bwd(const void* dout, const void* u, const float* rstd, const void* w, const float* rope_cos, const float* rope_sin, int64_t L,
-                                         int64_t head_dim, int64_t rows, int64_t D, void* du, hipStream_t stream) {
+extern "C" int32_t vgpa_wan_rms_rope_bwd(const void* dout, int64_t ld_dout, const void* u, int64_t ld_u, const float* rstd, const void* w, const float* rope_cos,
+                                         const float* rope_sin, int64_t L, int64_t head_dim, int64_t rows, int64_t D, void* du, int64_t ld_du, hipStream_t stream) {
     if (!dout || !u || !rstd || !w || !du || !wan_dims_ok(rows, D) || (rope_cos == nullptr) != (rope_sin == nullptr)) return VGPA_ERR_INVALID;
+    if (ld_dout < D || ld_dout % 8 || ld_u < D || ld_u % 8 || ld_du < D || ld_du % 8) return VGPA_ERR_INVALID;
     if (rope_cos && (L <= 0 || head_dim <= 0 || head_dim % 8 || D % head_dim)) return VGPA_ERR_INVALID;
     VGPA_LAUNCH(wan_rms_rope_bwd_kernel, wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)dout, (const bf16_t*)u, rstd, (const bf16_t*)w, rope_cos, rope_sin,
-                (int)(rope_cos ? L : 1), (int)(rope_cos ? head_dim / 2 : 1), (int)D, rows, (bf16_t*)du);
+                (int)(rope_cos ? L : 1), (int)(rope_cos ? head_dim / 2 : 1), (int)D, rows, ld_dout, ld_u, (bf16_t*)du, ld_du);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

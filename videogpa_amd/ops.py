@@ -554,6 +554,24 @@ def quant_fp8_rows(x2):
     return q, sc
 
 
+def gelu_tanh_fwd_q8(u2):
+    """bf16 [M, K] -> (e4m3(gelu_tanh(u)) [M, K], scale [M, 1]): the activation written as the fp8 GEMM operand by its producer"""
+    M, K = u2.shape
+    q = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=u2.device)
+    sc = torch.empty(M, 1, dtype=torch.float32, device=u2.device)
+    _timed("gelu_tanh_fwd_q8", 3.0 * M * K, lambda: _lib.call("vgpa_gelu_tanh_fwd_q8", u2, M, K, q, sc, _stream()), "byte")
+    return q, sc
+
+
+def gelu_tanh_bwd_q8(u2, dy2):
+    """(u, dy) bf16 [M, K] -> (e4m3(dy * gelu_tanh'(u)) [M, K], scale [M, 1])"""
+    M, K = u2.shape
+    q = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=u2.device)
+    sc = torch.empty(M, 1, dtype=torch.float32, device=u2.device)
+    _timed("gelu_tanh_bwd_q8", 5.0 * M * K, lambda: _lib.call("vgpa_gelu_tanh_bwd_q8", u2, dy2, M, K, q, sc, _stream()), "byte")
+    return q, sc
+
+
 class Fp8Weight:
     """e4m3 copies of a frozen weight W [N, K], one scale per output row, for y = x W^T, and of W^T for dx = dy W; made once
     (the base weights never change in LoRA training) and kept with the weight tensor."""
@@ -791,23 +809,42 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
 ATTN128_W1 = _os.environ.get("VGPA_ATTN128_W1", "1") == "1"    # 0: the compiler-scheduled hd128 forward everywhere
 
 
+def attention128_fwd_raw(q, k, v, scale, o_pad=0):
+    """q [B,H,Sq,128], k / v [B,H,Skv,128] bf16 views (any batch / head / token strides, last dim contiguous) -> (o, lse2 [B,H,Sq] fp32).
+    o is a [B,H,Sq,128] view of token-major storage [B, Sq, H*128 (+ o_pad)]: the caller's flatten to [B*Sq, H*128] is free, and with
+    o_pad it is the head of a `_padded_empty` buffer (the output projection's LoRA tail, see LoraExt)."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    assert D == 128 and k.shape == (B, H, Skv, 128) and v.shape == k.shape and q.dtype == k.dtype == v.dtype == torch.bfloat16
+    o2 = _padded_empty((B, Sq), H * D, o_pad, torch.bfloat16, q.device) if o_pad else torch.empty(B, Sq, H * D, dtype=torch.bfloat16, device=q.device)
+    o = o2.unflatten(-1, (H, D)).permute(0, 2, 1, 3)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    ws_bytes = _lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, Sq) if ATTN128_W1 else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
+    _timed("attn128_fwd" if Skv >= 1024 else "attn128_fwd (short keys)", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+        "vgpa_attn128_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale),
+        ws, ws_bytes, _stream()))
+    return o, lse
+
+
+def attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale):
+    """all [B,H,S,128] bf16 views; writes dq, dk, dv in place (they may be strided slices of a fused gradient buffer)"""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    ws_bytes = _lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, Sq)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+        "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
+        _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, float(scale), -1 if ATTN128_W1 else 0, ws, ws_bytes, _stream()))
+
+
 class _Attention128Fn(torch.autograd.Function):
     """softmax(scale q k^T) v for head_dim 128, query and key lengths free (csrc/attention_hd128.hip): Wan2.2's self- and cross-attention"""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
-        B, H, Sq, D = q.shape
-        Skv = k.shape[2]
-        assert D == 128 and k.shape == (B, H, Skv, 128) and v.shape == k.shape and q.dtype == k.dtype == v.dtype == torch.bfloat16
+    def forward(ctx, q, k, v, scale, o_pad):
         q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
-        # token-major storage [B, S, H, 128] behind the [B, H, S, 128] view: the caller's flatten to [B * S, H * 128] is then free
-        o = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
-        lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
-        ws_bytes = _lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, Sq) if ATTN128_W1 else 0
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
-        _timed("attn128_fwd" if Skv >= 1024 else "attn128_fwd (short keys)", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-            "vgpa_attn128_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale),
-            ws, ws_bytes, _stream()))
+        o, lse = attention128_fwd_raw(q, k, v, scale, o_pad)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale = float(scale)
         return o
@@ -821,17 +858,13 @@ class _Attention128Fn(torch.autograd.Function):
         dq = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)      # token-major, like the projections' outputs
         dk = torch.empty(B, Skv, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
         dv = torch.empty(B, Skv, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
-        ws_bytes = _lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, Sq)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-        _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-            "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
-            _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, ctx.scale, -1 if ATTN128_W1 else 0, ws, ws_bytes, _stream()))
-        return dq, dk, dv, None
+        attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale)
+        return dq, dk, dv, None, None
 
 
-def attention128(q, k, v, scale=None):
+def attention128(q, k, v, scale=None, o_pad=0):
     """q [B, H, Sq, 128], k / v [B, H, Skv, 128] (bf16, last dim contiguous) -> [B, H, Sq, 128]"""
-    return _Attention128Fn.apply(q, k, v, q.shape[-1] ** -0.5 if scale is None else scale)
+    return _Attention128Fn.apply(q, k, v, q.shape[-1] ** -0.5 if scale is None else scale, int(o_pad))
 
 
 class _QKNormAttentionFn(torch.autograd.Function):

@@ -26,6 +26,10 @@ DEFAULT_CONFIG: Dict[str, Any] = {           # train/Wan2.2-TI2V-5B/03_train.py:
     "lora_rank": 64, "lora_alpha": 128.0, "lora_dropout": 0.0, "lora_target_modules": ["q", "k", "v", "o"],
     "patch_size": (1, 2, 2), "seed": 0,
     "pair_batch": True,      # MI355X-first: win and lose as one batch through the denoiser (False = two calls, like the reference)
+    # the reference recomputes every block in the backward (03_train.py:150-159, sized for 80 GB parts); 288 GB hold the activations of
+    # the full-size pair step (measured 206 GB), which saves one forward in five: None leaves the model as the caller configured it,
+    # True / False (+ stride k = recompute every k-th block) is applied to a model that has enable_gradient_checkpointing
+    "enable_gradient_checkpointing": None, "gradient_checkpointing_stride": 1,
 }
 
 
@@ -59,6 +63,11 @@ class WanDPOTrainer(nn.Module):
         self.num_train_timesteps, self.shift, self.patch_size = cfg["num_train_timesteps"], cfg["shift"], tuple(cfg["patch_size"])
         self.global_step = 0
         self._rng = None
+        if cfg["enable_gradient_checkpointing"] is not None:
+            base = self.transformer.get_base_model()
+            if not hasattr(base, "enable_gradient_checkpointing"):
+                raise TypeError("enable_gradient_checkpointing is set but the transformer has no enable_gradient_checkpointing()")
+            base.enable_gradient_checkpointing(bool(cfg["enable_gradient_checkpointing"]), stride=int(cfg["gradient_checkpointing_stride"]))
 
     def rng(self, device):
         if self._rng is None or self._rng.device != device:

@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, ops
+from .transformer import _adapter, _f32, _parts
 
 _F32, _BF16 = 0, 1
 
@@ -40,18 +41,21 @@ def _ptr_dtype(x):
 
 
 class _LnModFn(torch.autograd.Function):
-    """bf16( LN_eps(x) [rounded to bf16] * ln_w + ln_b, then * (1 + scale[gid]) + shift[gid] );   x [rows, D] fp32 or bf16"""
+    """bf16( LN_eps(x) [rounded to bf16] * ln_w + ln_b, then * (1 + scale[gid]) + shift[gid] );   x [rows, D] fp32 or bf16.
+    pad > 0: the result is the head of a [rows, D + pad] buffer (ops._padded_empty) whose tail the consuming projection fills with its LoRA
+    down-projection, so the K-extended GEMM (ops.LoraExt) reads its operand in place."""
 
     @staticmethod
-    def forward(ctx, x, gid, ln_w, ln_b, shift, scale, eps, round_xhat):
+    def forward(ctx, x, gid, ln_w, ln_b, shift, scale, eps, round_xhat, pad):
         rows, D = x.shape
         x = x.contiguous()
-        out = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
+        out = ops._padded_empty((rows,), D, pad, torch.bfloat16, x.device) if pad else torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         ms = 0 if shift is None else shift.stride(0)
         ops._timed("wan_ln_mod_fwd", (x.element_size() + 2.0) * rows * D, lambda: _lib.call(
-            "vgpa_wan_ln_mod_fwd", x, _ptr_dtype(x), gid, ln_w, ln_b, shift, scale, ms, rows, D, float(eps), int(round_xhat), out, mean, rstd, _stream()), "byte")
+            "vgpa_wan_ln_mod_fwd", x, _ptr_dtype(x), gid, ln_w, ln_b, shift, scale, ms, rows, D, float(eps), int(round_xhat), out, D + pad, None, None,
+            mean, rstd, _stream()), "byte")
         ctx.save_for_backward(x, mean, rstd, gid, ln_w, scale)
         ctx.ms = ms
         return out
@@ -63,68 +67,192 @@ class _LnModFn(torch.autograd.Function):
         dx = torch.empty(rows, D, dtype=torch.float32, device=x.device)
         ops._timed("wan_ln_mod_bwd", (x.element_size() + 6.0) * rows * D, lambda: _lib.call(
             "vgpa_wan_ln_mod_bwd", dy.contiguous(), x, _ptr_dtype(x), mean, rstd, gid, ln_w, scale, ctx.ms, rows, D, None, dx, _stream()), "byte")
-        return dx.to(x.dtype), None, None, None, None, None, None, None
+        return dx.to(x.dtype), None, None, None, None, None, None, None, None
 
 
 class _GateResidualFn(torch.autograd.Function):
-    """fp32: x + y(bf16) * gate[gid]      (gate None: 1)"""
+    """fp32: x + y(bf16) * gate[gid]      (gate None: 1).  dy_pad: the gradient of y is returned as the head of a buffer that much wider (the
+    LoRA tail of the output projection's backward GEMM)."""
 
     @staticmethod
-    def forward(ctx, x, y, gid, gate):
+    def forward(ctx, x, y, gid, gate, dy_pad):
         rows, D = y.shape
         out = torch.empty(rows, D, dtype=torch.float32, device=y.device)
         ms = 0 if gate is None else gate.stride(0)
         ops._timed("wan_gate_residual", 10.0 * rows * D, lambda: _lib.call(
             "vgpa_wan_gate_residual", x.contiguous(), y.contiguous(), gid, gate, ms, rows, D, out, _stream()), "byte")
         ctx.save_for_backward(gid, gate)
-        ctx.ms = ms
+        ctx.ms, ctx.dy_pad = ms, dy_pad
         return out
 
     @staticmethod
     def backward(ctx, dout):
         gid, gate = ctx.saved_tensors
         rows, D = dout.shape
-        dy = torch.empty(rows, D, dtype=torch.bfloat16, device=dout.device)
+        pad = ctx.dy_pad
+        dy = ops._padded_empty((rows,), D, pad, torch.bfloat16, dout.device) if pad else torch.empty(rows, D, dtype=torch.bfloat16, device=dout.device)
         dout = dout.contiguous()
-        ops._timed("wan_gate_bwd", 6.0 * rows * D, lambda: _lib.call("vgpa_wan_gate_bwd", dout, gid, gate, ctx.ms, rows, D, dy, _stream()), "byte")
-        return dout, dy, None, None
+        ops._timed("wan_gate_bwd", 6.0 * rows * D, lambda: _lib.call("vgpa_wan_gate_bwd", dout, gid, gate, ctx.ms, rows, D, dy, D + pad, _stream()), "byte")
+        return dout, dy, None, None, None
+
+
+def _rows2(t, D):
+    """[.., D] tensor with a contiguous last dim and uniformly strided rows -> ([rows, D] view, row stride); copies only if it has to"""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    try:
+        t2 = t.view(-1, D)
+    except RuntimeError:
+        t2 = t.contiguous().view(-1, D)
+    return t2, t2.stride(0)
+
+
+def _rms_rope_fwd_raw(u2, ld_u, w, cos, sin, L, head_dim, eps, out2, ld_out, rstd):
+    rows, D = u2.shape
+    ops._timed("wan_rms_rope_fwd", 4.0 * rows * D, lambda: _lib.call(
+        "vgpa_wan_rms_rope_fwd", u2, ld_u, w, cos, sin, L, head_dim, rows, D, float(eps), out2, ld_out, rstd, _stream()), "byte")
+
+
+def _rms_rope_bwd_raw(dout2, ld_dout, u2, ld_u, rstd, w, cos, sin, L, head_dim, du2, ld_du):
+    rows, D = u2.shape
+    ops._timed("wan_rms_rope_bwd", 6.0 * rows * D, lambda: _lib.call(
+        "vgpa_wan_rms_rope_bwd", dout2, ld_dout, u2, ld_u, rstd, w, cos, sin, L, head_dim, rows, D, du2, ld_du, _stream()), "byte")
 
 
 class _RmsRopeFn(torch.autograd.Function):
-    """WanRMSNorm over the full row, bf16 weight, RoPE per head:  u [B, L, D] bf16 -> [B, L, D] bf16"""
+    """WanRMSNorm over the full row, bf16 weight, RoPE per head:  u [B, L, D] bf16 (rows may be strided) -> [B, L, D] bf16.  grad_pad: du is the
+    head of a buffer that much wider (LoRA tail of the producing projection's backward GEMM)."""
 
     @staticmethod
-    def forward(ctx, u, w, cos, sin, head_dim, eps):
+    def forward(ctx, u, w, cos, sin, head_dim, eps, grad_pad):
         B, L, D = u.shape
-        u = u.contiguous()
-        out = torch.empty_like(u)
+        u2, ld_u = _rows2(u, D)
+        out = torch.empty(B, L, D, dtype=torch.bfloat16, device=u.device)
         rstd = torch.empty(B * L, dtype=torch.float32, device=u.device)
-        ops._timed("wan_rms_rope_fwd", 4.0 * B * L * D, lambda: _lib.call(
-            "vgpa_wan_rms_rope_fwd", u, w, cos, sin, L, head_dim, B * L, D, float(eps), out, rstd, _stream()), "byte")
-        ctx.save_for_backward(u, rstd, w, cos, sin)
-        ctx.head_dim = head_dim
+        _rms_rope_fwd_raw(u2, ld_u, w, cos, sin, L, head_dim, eps, out, D, rstd)
+        ctx.save_for_backward(u2, rstd, w, cos, sin)
+        ctx.meta = (B, L, D, head_dim, grad_pad)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        u, rstd, w, cos, sin = ctx.saved_tensors
-        B, L, D = u.shape
-        du = torch.empty_like(u)
-        ops._timed("wan_rms_rope_bwd", 6.0 * B * L * D, lambda: _lib.call(
-            "vgpa_wan_rms_rope_bwd", dout.contiguous(), u, rstd, w, cos, sin, L, ctx.head_dim, B * L, D, du, _stream()), "byte")
-        return du, None, None, None, None, None
+        u2, rstd, w, cos, sin = ctx.saved_tensors
+        B, L, D, head_dim, pad = ctx.meta
+        du = ops._padded_empty((B, L), D, pad, torch.bfloat16, u2.device) if pad else torch.empty(B, L, D, dtype=torch.bfloat16, device=u2.device)
+        d2, ld_d = _rows2(dout, D)
+        _rms_rope_bwd_raw(d2, ld_d, u2, u2.stride(0), rstd, w, cos, sin, L, head_dim, du, D + pad)
+        return du, None, None, None, None, None, None
 
 
-def ln_mod(x, gid=None, ln_w=None, ln_b=None, shift=None, scale=None, eps=1e-6, round_xhat=False):
-    return _LnModFn.apply(x, gid, ln_w, ln_b, shift, scale, eps, round_xhat)
+class _SelfAttnFn(torch.autograd.Function):
+    """qkv [B, L, 3 D] (the fused q/k/v projection's output) -> attention output [B, L, D]: WanRMSNorm + RoPE on the q and k slices, v read from the
+    buffer by stride, head_dim-128 attention; the backward writes the three gradients straight into one [B, L, 3 D (+ grad_pad)] buffer (dv by the
+    attention kernel, dq / dk by the norm backward), so the fused projection's backward GEMM needs no concatenation.  o_pad / grad_pad: LoRA tails of
+    the output projection's forward resp. the q/k/v projection's backward operand (ops.LoraExt)."""
+
+    @staticmethod
+    def forward(ctx, qkv, wq, wk, cos, sin, H, eps, o_pad, grad_pad):
+        B, L, W = qkv.shape
+        D = W // 3
+        hd = D // H
+        q2, ld = _rows2(qkv, W)
+        qn = torch.empty(B, L, D, dtype=torch.bfloat16, device=qkv.device)
+        kn = torch.empty_like(qn)
+        rq = torch.empty(B * L, dtype=torch.float32, device=qkv.device)
+        rk = torch.empty_like(rq)
+        _rms_rope_fwd_raw(q2[:, :D], ld, wq, cos, sin, L, hd, eps, qn, D, rq)
+        _rms_rope_fwd_raw(q2[:, D:2 * D], ld, wk, cos, sin, L, hd, eps, kn, D, rk)
+        heads = lambda t: t.unflatten(-1, (H, hd)).permute(0, 2, 1, 3)
+        v = heads(q2.view(B, L, W)[:, :, 2 * D:])
+        o, lse = ops.attention128_fwd_raw(heads(qn), heads(kn), v, hd ** -0.5, o_pad)
+        ctx.save_for_backward(q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin)
+        ctx.meta = (B, L, D, H, hd, grad_pad)
+        return o.permute(0, 2, 1, 3).flatten(2)          # [B, L, D]: a view of the token-major storage
+
+    @staticmethod
+    def backward(ctx, do):
+        q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin = ctx.saved_tensors
+        B, L, D, H, hd, pad = ctx.meta
+        W = 3 * D
+        heads = lambda t: t.unflatten(-1, (H, hd)).permute(0, 2, 1, 3)
+        do = do if do.stride(-1) == 1 else do.contiguous()
+        dqkv = ops._padded_empty((B, L), W, pad, torch.bfloat16, q2.device) if pad else torch.empty(B, L, W, dtype=torch.bfloat16, device=q2.device)
+        dqn = torch.empty(B, L, D, dtype=torch.bfloat16, device=q2.device)
+        dkn = torch.empty_like(dqn)
+        v = heads(q2.view(B, L, W)[:, :, 2 * D:])
+        ops.attention128_bwd_raw(heads(qn), heads(kn), v, o, heads(do), lse, heads(dqn), heads(dkn), heads(dqkv[:, :, 2 * D:]), hd ** -0.5)
+        d2 = dqkv.view(B * L, W)
+        _rms_rope_bwd_raw(dqn, D, q2[:, :D], q2.stride(0), rq, wq, cos, sin, L, hd, d2[:, :D], d2.stride(0))
+        _rms_rope_bwd_raw(dkn, D, q2[:, D:2 * D], q2.stride(0), rk, wk, cos, sin, L, hd, d2[:, D:2 * D], d2.stride(0))
+        return dqkv, None, None, None, None, None, None, None, None
 
 
-def gate_residual(x, y, gid=None, gate=None):
-    return _GateResidualFn.apply(x, y, gid, gate)
+class _FfnFp8Fn(torch.autograd.Function):
+    """One feed-forward branch of a block with e4m3 GEMM operands, x' = x + gate[g] * W2 gelu(W1 ln_mod(x) + b1) + b2, as ONE autograd node: every
+    fp8 operand is written by its producer (LN + modulation, GELU, the gate's backward, GELU's backward -- csrc/wan.hip, csrc/fp8.hip; bit-identical
+    to the bf16 producer followed by vgpa_quant_fp8_rows), the vendor fp8 GEMM (hipBLASLt through torch._scaled_mm) does the four products, and the
+    backward adds the residual path's gradient inside the LN backward kernel (dres)."""
+
+    @staticmethod
+    def forward(ctx, x, gid, shift, scale, gate, eps, W1, b1, W2, b2):
+        rows, D = x.shape
+        x = x.contiguous()
+        dev = x.device
+        w1, w2 = ops.Fp8Weight.of(W1), ops.Fp8Weight.of(W2)
+        hq = torch.empty(rows, D, dtype=torch.float8_e4m3fn, device=dev)
+        hs = torch.empty(rows, 1, dtype=torch.float32, device=dev)
+        mean = torch.empty(rows, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        ms = shift.stride(0)
+        ops._timed("wan_ln_mod_fwd", (x.element_size() + 1.0) * rows * D, lambda: _lib.call(
+            "vgpa_wan_ln_mod_fwd", x, _ptr_dtype(x), gid, None, None, shift, scale, ms, rows, D, float(eps), 0, None, D, hq, hs, mean, rstd, _stream()), "byte")
+        u = ops._fp8_gemm(hq, hs, w1.q, w1.s, b1)
+        gq, gs = ops.gelu_tanh_fwd_q8(u)
+        y = ops._fp8_gemm(gq, gs, w2.q, w2.s, b2)
+        out = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        ops._timed("wan_gate_residual", 10.0 * rows * D, lambda: _lib.call("vgpa_wan_gate_residual", x, y, gid, gate, gate.stride(0), rows, D, out, _stream()), "byte")
+        ctx.save_for_backward(x, mean, rstd, u, gid, scale, gate)
+        ctx.w, ctx.ms = (w1, w2), ms
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mean, rstd, u, gid, scale, gate = ctx.saved_tensors
+        w1, w2 = ctx.w
+        rows, D = x.shape
+        dev = x.device
+        dout = dout.contiguous()
+        dq = torch.empty(rows, D, dtype=torch.float8_e4m3fn, device=dev)
+        ds = torch.empty(rows, 1, dtype=torch.float32, device=dev)
+        ops._timed("wan_gate_bwd", 5.0 * rows * D, lambda: _lib.call("vgpa_wan_gate_bwd_q8", dout, gid, gate, gate.stride(0), rows, D, dq, ds, _stream()), "byte")
+        dg = ops._fp8_gemm(dq, ds, w2.qt, w2.st)
+        duq, dus = ops.gelu_tanh_bwd_q8(u, dg)
+        dh = ops._fp8_gemm(duq, dus, w1.qt, w1.st)
+        dx = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        ops._timed("wan_ln_mod_bwd", (x.element_size() + 10.0) * rows * D, lambda: _lib.call(
+            "vgpa_wan_ln_mod_bwd", dh, x, _ptr_dtype(x), mean, rstd, gid, None, scale, ctx.ms, rows, D, dout, dx, _stream()), "byte")
+        return dx, None, None, None, None, None, None, None, None, None
 
 
-def rms_rope(u, w, cos=None, sin=None, head_dim=128, eps=1e-6):
-    return _RmsRopeFn.apply(u, w, cos, sin, head_dim, eps)
+def ln_mod(x, gid=None, ln_w=None, ln_b=None, shift=None, scale=None, eps=1e-6, round_xhat=False, pad=0):
+    return _LnModFn.apply(x, gid, ln_w, ln_b, shift, scale, eps, round_xhat, int(pad))
+
+
+def gate_residual(x, y, gid=None, gate=None, dy_pad=0):
+    return _GateResidualFn.apply(x, y, gid, gate, int(dy_pad))
+
+
+def rms_rope(u, w, cos=None, sin=None, head_dim=128, eps=1e-6, grad_pad=0):
+    return _RmsRopeFn.apply(u, w, cos, sin, head_dim, eps, int(grad_pad))
+
+
+def ffn_fp8(x, gid, shift, scale, gate, eps, W1, b1, W2, b2):
+    """x fp32 [rows, D] -> x + gate[g] * FFN(ln_mod(x)) with e4m3 GEMM operands (frozen weights)"""
+    if W1.requires_grad or W2.requires_grad or (b1 is not None and b1.requires_grad) or (b2 is not None and b2.requires_grad):
+        raise RuntimeError("videogpa_amd: the fp8 path is for frozen projections only")
+    if x.dtype != torch.float32:
+        raise TypeError("ffn_fp8: fp32 residual stream")
+    return _FfnFp8Fn.apply(x, gid, shift, scale, gate, eps, W1, b1, W2, b2)
 
 
 def sinusoidal_embedding_1d(dim, position):
@@ -174,34 +302,75 @@ class WanSelfAttention(nn.Module):
         self.q, self.k, self.v, self.o = nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim)
         self.norm_q = WanRMSNorm(dim, eps=eps) if qk_norm else None
         self.norm_k = WanRMSNorm(dim, eps=eps) if qk_norm else None
+        self._fused = None
+        self._qkv_ext = None
 
     def _heads(self, t, B, S):
         return t.view(B, S, self.num_heads, self.head_dim).permute(0, 2, 1, 3)
 
-    def _norm(self, norm, u, rope):
+    def _norm(self, norm, u, rope, grad_pad=0):
         if norm is None:
             if rope is not None:
                 raise NotImplementedError("RoPE without QK-norm")
             return u
-        return rms_rope(u, norm.weight, rope[0] if rope else None, rope[1] if rope else None, self.head_dim, norm.eps)
+        return rms_rope(u, norm.weight, rope[0] if rope else None, rope[1] if rope else None, self.head_dim, norm.eps, grad_pad)
+
+    # ---- the q / k / v linears as ONE projection (the CogVideoX path's AttentionCore, transformer.py): [3 dim, dim] weight cached while the frozen
+    # base weights are unchanged, the (up to three) adapters riding the GEMM as extra K (ops.LoraExt)
+    def fused_qkv(self):
+        ws = [_parts(m)[0] for m in (self.q, self.k, self.v)]
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        if self._fused is None or self._fused[0] != key:
+            bs = [_parts(m)[1] for m in (self.q, self.k, self.v)]
+            W = torch.cat([w.detach() for w in ws], dim=0)
+            b = torch.cat([x.detach() for x in bs], dim=0) if bs[0] is not None else None
+            self._fused = (key, W, b)
+        return self._fused[1], self._fused[2]
+
+    def lora_state(self):
+        """(adapters of q / k / v, adapter of o, enabled): all wrapped linears of one attention share the on / off state"""
+        qa = [_adapter(m) for m in (self.q, self.k, self.v)]
+        oa = _adapter(self.o)
+        on = [e for a, e in qa + [oa] if a is not None]
+        return [a for a, _ in qa], oa[0], (bool(on) and all(on))
+
+    def pads(self):
+        """(in_pad, out_pad): LoRA tail widths behind this attention's input rows (q/k/v adapters) and behind its output rows (o adapter)"""
+        qa, oa, _ = self.lora_state()
+        act = [a for a in qa if a is not None]
+        return (len(act) * ops._pad_rank(act[0][0].shape[0]) if act else 0), (ops._pad_rank(oa[0].shape[0]) if oa is not None else 0)
 
     def forward(self, x, B, L, rope):
-        """x [B*L, dim] bf16 -> [B*L, dim] bf16"""
-        q = self._norm(self.norm_q, self.q(x).view(B, L, self.dim), rope)
-        k = self._norm(self.norm_k, self.k(x).view(B, L, self.dim), rope)
-        v = self.v(x).view(B, L, self.dim)
-        o = ops.attention128(self._heads(q, B, L), self._heads(k, B, L), self._heads(v, B, L))
-        return self.o(o.permute(0, 2, 1, 3).reshape(B * L, self.dim))
+        """x [B*L, dim] bf16 (head of a buffer with pads()[0] tail columns when adapters are mounted) -> [B*L, dim] bf16"""
+        if self.norm_q is None:
+            raise NotImplementedError("the fused self-attention path normalises q and k (qk_norm=True in every released Wan model)")
+        W, b = self.fused_qkv()
+        qa, _, on = self.lora_state()
+        in_pad, out_pad = self.pads()
+        if in_pad:
+            if self._qkv_ext is None:
+                self._qkv_ext = ops.LoraExt()
+            qkv = ops.linear_lora_ext(x, W, b, self._qkv_ext, qa, enabled=on)
+        else:
+            qkv = ops.frozen_linear(x, W, b)
+        o = _SelfAttnFn.apply(qkv.view(B, L, 3 * self.dim), self.norm_q.weight, self.norm_k.weight, rope[0] if rope else None, rope[1] if rope else None,
+                              self.num_heads, self.norm_q.eps, out_pad, in_pad)
+        return self.o(o.reshape(B * L, self.dim))
 
 
 class WanCrossAttention(WanSelfAttention):
+    def pads(self):
+        qa, oa = _adapter(self.q)[0], _adapter(self.o)[0]
+        return (ops._pad_rank(qa[0].shape[0]) if qa is not None else 0), (ops._pad_rank(oa[0].shape[0]) if oa is not None else 0)
+
     def forward(self, x, context, B, L):
         """x [B*L, dim] bf16, context [B, T, dim] bf16 (every one of the T text positions is attended: upstream passes k_lens=None)"""
         T = context.shape[1]
-        q = self._norm(self.norm_q, self.q(x).view(B, L, self.dim), None)
+        in_pad, out_pad = self.pads()
+        q = self._norm(self.norm_q, self.q(x).view(B, L, self.dim), None, grad_pad=in_pad)
         k = self._norm(self.norm_k, self.k(context.reshape(B * T, self.dim)).view(B, T, self.dim), None)
         v = self.v(context.reshape(B * T, self.dim)).view(B, T, self.dim)
-        o = ops.attention128(self._heads(q, B, L), self._heads(k, B, T), self._heads(v, B, T))
+        o = ops.attention128(self._heads(q, B, L), self._heads(k, B, T), self._heads(v, B, T), o_pad=out_pad)
         return self.o(o.permute(0, 2, 1, 3).reshape(B * L, self.dim))
 
 
@@ -222,16 +391,20 @@ class WanAttentionBlock(nn.Module):
         """x [B*L, dim]: bf16 in the first block (the patch embedding's output), fp32 afterwards; e0 [G, 6, dim] fp32; -> fp32"""
         tab = (self.modulation.float() + e0).contiguous()          # [G, 6, dim] fp32: upstream adds under autocast(float32)
         first = x.dtype == torch.bfloat16                           # norm1(x).type_as(x) rounds only while the stream is still bf16
-        h = ln_mod(x, gid, None, None, tab[:, 0], tab[:, 1], self.eps, round_xhat=first)
-        x = gate_residual(x.float() if first else x, self.self_attn(h, B, L, rope), gid, tab[:, 2])
+        sa_in, sa_out = self.self_attn.pads()
+        ca_in, ca_out = self.cross_attn.pads()
+        h = ln_mod(x, gid, None, None, tab[:, 0], tab[:, 1], self.eps, round_xhat=first, pad=sa_in)
+        x = gate_residual(x.float() if first else x, self.self_attn(h, B, L, rope), gid, tab[:, 2], dy_pad=sa_out)
         if isinstance(self.norm3, nn.Identity):
             h = x.to(torch.bfloat16)
         else:
-            h = ln_mod(x, None, self.norm3.weight.float(), self.norm3.bias.float(), None, None, self.eps)
-        x = gate_residual(x, self.cross_attn(h, context, B, L), None, None)
+            h = ln_mod(x, None, _f32(self.norm3.weight), _f32(self.norm3.bias), None, None, self.eps, pad=ca_in)
+        x = gate_residual(x, self.cross_attn(h, context, B, L), None, None, dy_pad=ca_out)
+        f0, f2 = self.ffn[0], self.ffn[2]
+        if self.fp8_ffn:
+            return ffn_fp8(x, gid, tab[:, 3], tab[:, 4], tab[:, 5], self.eps, f0.weight, f0.bias, f2.weight, f2.bias)
         h = ln_mod(x, gid, None, None, tab[:, 3], tab[:, 4], self.eps)
-        lin = ops.frozen_linear_fp8 if self.fp8_ffn else ops.frozen_linear
-        y = lin(ops.gelu_tanh(lin(h, self.ffn[0].weight, self.ffn[0].bias)), self.ffn[2].weight, self.ffn[2].bias)
+        y = ops.frozen_linear(ops.gelu_tanh(ops.frozen_linear(h, f0.weight, f0.bias)), f2.weight, f2.bias)
         return gate_residual(x, y, gid, tab[:, 5])
 
 
@@ -266,6 +439,7 @@ class WanModel(nn.Module):
         self.blocks = nn.ModuleList([WanAttentionBlock(dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps) for _ in range(num_layers)])
         self.head = Head(dim, out_dim, self.patch_size, eps)
         self.gradient_checkpointing = False
+        self.checkpoint_stride = 1
         self._rope = {}
         self.init_weights()
 
@@ -285,9 +459,12 @@ class WanModel(nn.Module):
                 nn.init.normal_(m.weight, std=0.02)
         nn.init.zeros_(self.head.head.weight)
 
-    def enable_gradient_checkpointing(self, enabled=True):
-        """the reference wraps every block's forward in torch.utils.checkpoint (03_train.py:150-159)"""
-        self.gradient_checkpointing = enabled
+    def enable_gradient_checkpointing(self, enabled=True, stride=1):
+        """the reference wraps every block's forward in torch.utils.checkpoint (03_train.py:150-159: sized for 80 GB parts).  `stride` k
+        recomputes only every k-th block; 288 GB of HBM3E hold ALL activations of the full-size pair step (30 blocks x 2 samples x
+        18 480 tokens: DESIGN section 4.5), so the MI355X default of the trainer / bench is enabled=False -- one forward in five saved."""
+        self.gradient_checkpointing = bool(enabled)
+        self.checkpoint_stride = max(1, int(stride))
 
     def enable_fp8(self, enabled=True):
         """BASELINE.json configs[4] "fp8 MFMA path": the frozen feed-forward projections (61 % of the linear FLOPs per token) take
@@ -333,8 +510,8 @@ class WanModel(nn.Module):
         ctx = ctx.view(B, self.text_len, self.dim)
         rope = self._rope_tables((f, h, w), dev)
         xs = tok
-        for blk in self.blocks:
-            if self.gradient_checkpointing and torch.is_grad_enabled():
+        for i, blk in enumerate(self.blocks):
+            if self.gradient_checkpointing and torch.is_grad_enabled() and i % self.checkpoint_stride == 0:
                 from torch.utils.checkpoint import checkpoint
                 xs = checkpoint(blk, xs, e0, gid, B, L, rope, ctx, use_reentrant=False)
             else:
