@@ -7,7 +7,10 @@ parameters, flat-buffer gradient all-reduce (N>1), fused clip + AdamW.  Syntheti
 named shape, random-init weights of the named architecture (no network for checkpoints), all resident in HBM before
 the timed region.  Prints ONE JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
+
+cfg5 = BASELINE.json configs[4] (Wan2.2-TI2V-5B, 81f x 704x1280, fp8 feed-forward) is a separate bench line with its own metric name; the
+default (and what the driver runs) is cfg2, the configuration the headline metric is quoted on.
 
 `--gpus N` with N > 1 launches N ranks itself (one process per GPU under torch.distributed.run, RCCL); it can also be
 started under torchrun directly, in which case WORLD_SIZE must equal --gpus:
@@ -28,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP8_DENSE_TFLOPS = 5000.0    # same guide: ~5 PF dense fp8 (the vendor e4m3 GEMMs of cfg5 are priced against this)
 PEAK_HBM_GBS = 8000.0             # same guide: HBM3E ~8 TB/s
 TEXT_LEN = 226
 
@@ -39,7 +43,11 @@ CONFIGS = {
                  label="BASELINE configs[2]: CogVideoX-5B-I2V (32 input channels, learned positional table), 49f x 480x720 + image-cond latent"),
     "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=True, checkpoint_stride=4, cond=False,
                  label="BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t=2), 81f x 768x1360 (21 latent frames, even-cropped to 20)"),
+    "cfg5": dict(model="WAN22_TI2V_5B", frames=21, height=44, width=80, checkpoint=False, cond=True,
+                 label="BASELINE configs[4]: Wan2.2-TI2V-5B (30 blocks, dim 3072, 24x128 heads, ffn 14336, text 512), 81f x 704x1280 -> latent 48x21x44x80, "
+                       "e4m3 feed-forward GEMMs (fp8 MFMA path), bf16 attention and LoRA-carrying projections"),
 }
+WAN_TEXT_LEN = 512
 
 
 def build_model(cfg_kw, device, seed):
@@ -68,6 +76,17 @@ def flops_per_pair_step(S, D, L, r):
     f_lin, f_attn, f_lora = 24.0 * S * D * D, 4.0 * S * S * D, 16.0 * S * D * r
     fwd = L * (f_lin + f_attn)
     return 2 * fwd + 2 * (fwd + L * f_lora) + 2 * L * (f_lin + 2 * f_attn + 2 * f_lora)
+
+
+def flops_per_pair_step_wan(L_tok, D, F, T, layers, r):
+    """The same accounting for the Wan2.2 block: per token 6 D^2 weights in the attentions (self q,k,v,o + cross q,o) and 2 D F in the feed-forward,
+    cross k,v on the T text tokens, self-attention 4 L^2 D and cross-attention 4 L T D per forward; LoRA r on the eight attention linears.  Frozen
+    linears cost one forward-equivalent in the backward (dX only), attention two."""
+    f_lin = 2.0 * L_tok * (6 * D * D + 2 * D * F) + 2.0 * T * 2 * D * D
+    f_attn = 4.0 * L_tok * L_tok * D + 4.0 * L_tok * T * D
+    f_lora = 2.0 * (6 * L_tok + 2 * T) * 2 * D * r
+    fwd = layers * (f_lin + f_attn)
+    return 2 * fwd + 2 * (fwd + layers * f_lora) + 2 * layers * (f_lin + 2 * f_attn + 2 * f_lora)
 
 
 def cpu_baseline(F_step, budget_s=200.0):
@@ -148,6 +167,73 @@ def _pick_cpu_threads():
     return best, seen
 
 
+def add_kernel_report(out, ops, steps, ms):
+    """per-kernel live timings (HIP events on the launch stream, ops.KernelTimer) -> out["kernels"], out["roofline"], out["roofline_worst"]"""
+    if ops.TIMER is None:
+        return
+    if True:
+        summ = ops.TIMER.summary()
+        ops.TIMER = None
+        kernels = {}
+        for name, s in summ.items():
+            rate = s["work_per_launch"] / (s["avg_ms"] * 1e-3)
+            k = {"launches_per_step": s["launches"] / steps, "avg_ms": s["avg_ms"], "total_ms_per_step": s["total_ms"] / steps}
+            if s["unit"] == "flop":
+                peak = PEAK_FP8_DENSE_TFLOPS if "fp8" in name else PEAK_BF16_DENSE_TFLOPS
+                k.update(bound="mfma", algorithmic_flops_per_launch=s["work_per_launch"], achieved_tflops=rate / 1e12, frac=rate / 1e12 / peak)
+            else:
+                k.update(bound="hbm", algorithmic_bytes_per_launch=s["work_per_launch"], achieved_gbs=rate / 1e9,
+                         frac=rate / 1e9 / PEAK_HBM_GBS)
+            kernels[name] = k
+        # dominant kernel = largest share of the step among the HAND-WRITTEN kernels.  The dense projections are the vendor's
+        # hipBLASLt (north_star: MFMA by hand only for attention and LoRA); they are timed too and reported as one entry
+        # ("hipblaslt_gemm (vendor)": all shapes together) so that their share of the step is in the same JSON.
+        own = [k for k in kernels if "(vendor)" not in k]
+        dom = max(own, key=lambda k: kernels[k]["total_ms_per_step"])
+        kd = kernels[dom]
+        # traffic: HBM bytes per launch from the PMC pass of the same command (profiles/, collected per the guide's
+        # recipe: separate --pmc runs, FETCH_SIZE/WRITE_SIZE with the gfx950 corrections), when a summary is present
+        pmc_all = {}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                pmc_all = json.load(f)
+        traffic = pmc_all.get(dom, {}).get("hbm_bytes_per_launch")
+
+        def roof(name):
+            k = kernels[name]
+            r = {"kernel": name, "bound": k["bound"], "achieved": k.get("achieved_tflops", k.get("achieved_gbs")),
+                 "peak": PEAK_BF16_DENSE_TFLOPS if k["bound"] == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if k["bound"] == "mfma" else "GB/s",
+                 "frac": k["frac"], "avg_launch_ms": k["avg_ms"], "share_of_step": k["total_ms_per_step"] / ms,
+                 "traffic": pmc_all.get(name, {}).get("hbm_bytes_per_launch")}
+            for key in ("mfma_busy", "clock_mhz"):        # from the round's PMC pass (tools/profile_round.sh), when present
+                if key in pmc_all.get(name, {}):
+                    r[key] = pmc_all[name][key]
+            return r
+        if kd["bound"] == "mfma":
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["achieved_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS,
+                               "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"],
+                               "note": "largest hand-written kernel of the step; the vendor GEMMs are listed under kernels"}
+            for key in ("mfma_busy", "clock_mhz"):
+                if key in pmc_all.get(dom, {}):
+                    out["roofline"][key] = pmc_all[dom][key]
+        else:
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_gbs"], "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"]}
+        # the weakest hand-written kernel that matters (>= 5 % of the step), so that `roofline` cannot hide it
+        big = [k for k in own if kernels[k]["total_ms_per_step"] >= 0.05 * ms]
+        if big:
+            out["roofline_worst"] = roof(min(big, key=lambda k: kernels[k]["frac"]))
+        if "attn_bwd_dkv_kernel" in kernels and "attn_bwd_dq_kernel" in kernels:
+            a, b2 = kernels["attn_bwd_dkv_kernel"], kernels["attn_bwd_dq_kernel"]
+            fl = a["algorithmic_flops_per_launch"] + b2["algorithmic_flops_per_launch"]       # 8 S^2 d B H: the whole attention backward
+            t_ms = a["avg_ms"] + b2["avg_ms"]
+            out["attention_bwd_pair"] = {"algorithmic_flops_per_launch": fl, "avg_ms": t_ms, "achieved_tflops": fl / t_ms / 1e9,
+                                         "frac": fl / t_ms / 1e9 / PEAK_BF16_DENSE_TFLOPS,
+                                         "note": "dK/dV + dQ launches together against the algorithmic 8 S^2 d FLOPs (their S / dP recomputes are overhead)"}
+        out["kernels"] = kernels
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     have = torch.cuda.device_count()
@@ -159,6 +245,93 @@ def self_launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     sys.exit(subprocess.call(cmd, env=env))
+
+
+def main_wan(args, C, world, rank, dev, force_dist):
+    """cfg5: one Diffusion-DPO pair step of Wan2.2-TI2V-5B per rank (train/Wan2.2-TI2V-5B/03_train.py:189-242): shifted-sigma noising, clean first
+    latent frame, frozen-reference pass and policy pass over win + lose as one batch of two samples, DPO loss, backward to the LoRA r=64 adapters
+    on q/k/v/o of both attentions of every block, flat all-reduce (N > 1), clip + AdamW.  All activations resident (no block recompute)."""
+    from videogpa_amd import ops
+    from videogpa_amd.trainer import DPOEngine
+    from videogpa_amd.wan import WanDPOTrainer
+    from videogpa_amd.wan_model import WanModel
+    F_ = C["frames"] if args.frames is None else args.frames
+    H_ = C["height"] if args.height is None else args.height
+    W_ = C["width"] if args.width is None else args.width
+    layers = 30 if args.layers == 42 else args.layers
+    ckpt = bool(args.checkpoint)
+    stride = args.checkpoint_stride or 1
+    torch.manual_seed(0)                                 # identical base weights and adapter init on every rank
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            model = WanModel(num_layers=layers)          # TI2V-5B defaults: dim 3072, ffn 14336, 24 heads, in / out 48, text 512
+    finally:
+        torch.set_default_dtype(prev)
+    with torch.no_grad():
+        torch.nn.init.normal_(model.head.head.weight, std=0.02)      # upstream zero-inits the output layer: give the loss a signal
+    model.enable_fp8(not args.no_fp8)
+    trainer = WanDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2.0 * args.rank_r, "accumulate_grad_batches": 1, "seed": 1234,
+                             "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": stride}, model)
+    gB = torch.Generator(device=dev).manual_seed(1)
+    with torch.no_grad():
+        for n, p in trainer.transformer.named_parameters():
+            if ".lora_B." in n:
+                p.normal_(0.0, 1e-3, generator=gB)
+    trainer.train()
+    engine = DPOEngine(trainer)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    lat = lambda f: torch.randn(1, 48, f, H_, W_, generator=g, device=dev).to(torch.bfloat16)
+    batch = {"x_win": lat(F_), "x_lose": lat(F_), "prompt_emb": torch.randn(1, 300, 4096, generator=g, device=dev).to(torch.bfloat16), "image_latent": lat(1)}
+    L_tok = F_ * (H_ // 2) * (W_ // 2)
+    F_step = flops_per_pair_step_wan(L_tok, model.dim, model.ffn_dim, WAN_TEXT_LEN, layers, args.rank_r)
+
+    def barrier():
+        if world > 1 or force_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.micro_step(batch)
+    engine.flush()
+    if rank == 0 and not args.no_kernel_timer:
+        ops.TIMER = ops.KernelTimer()
+    barrier()
+    t0 = time.perf_counter()
+    logs = None
+    for _ in range(args.steps):
+        logs = engine.micro_step(batch)
+    logs.update(engine.flush())
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1 or force_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8) == (30, C["frames"], C["height"], C["width"], 64, False, False)
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "DPO preference-pair steps/sec, Wan2.2-TI2V-5B 81f@704x1280", "value": world * args.steps / dt, "unit": "pair-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.no_fp8 else "bf16 (attention, LoRA-carrying projections) + fp8 e4m3 (feed-forward GEMMs)",
+            "data": "synthetic",
+            "config": {"workload": (C["label"] + " -> " if named else "NOT a BASELINE config (debug flags): Wan2.2-shaped denoiser, ")
+                                   + f"paired latents 2 x [1,48,{F_},{H_},{W_}], {L_tok} tokens, {layers} blocks, LoRA r={args.rank_r} on q/k/v/o of self- and "
+                                   "cross-attention, 1 pair/GPU/step, optimizer step every step; random-init weights"
+                                   + (f"; activation recompute of every {stride}. block" if ckpt else "; all activations resident (no recompute)"),
+                       "name": "cfg5", "layers": layers, "tokens": L_tok, "pairs_per_gpu": 1, "parallelism": f"dp{world}"},
+            "note": "NOT the headline line: BASELINE.json's metric is quoted on cfg2 (python bench.py without --config)",
+            "loss": float(logs["train/loss"]), "loss_rank_mean": logs["sync"].tolist()[0],
+            "step_flops_algorithmic": F_step,
+            "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+            "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+        }
+        add_kernel_report(out, ops, args.steps, ms)
+        print(json.dumps(out), flush=True)
+    if world > 1 or force_dist:
+        dist.destroy_process_group()
 
 
 def main():
@@ -174,6 +347,7 @@ def main():
     ap.add_argument("--rank-r", type=int, default=64)
     ap.add_argument("--checkpoint", action="store_true", default=None, help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
     ap.add_argument("--checkpoint-stride", type=int, default=None, help="with --checkpoint: recompute only every k-th block (1 = all, like the reference)")
+    ap.add_argument("--no-fp8", action="store_true", help="cfg5 only: bf16 feed-forward GEMMs instead of the e4m3 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -203,6 +377,8 @@ def main():
     from videogpa_amd.trainer import CogVideoXDPOTrainer, DPOEngine
 
     C = CONFIGS[args.config]
+    if args.config == "cfg5":
+        return main_wan(args, C, world, rank, dev, force_dist)
     F_ = C["frames"] if args.frames is None else args.frames
     H_ = C["height"] if args.height is None else args.height
     W_ = C["width"] if args.width is None else args.width
@@ -279,67 +455,7 @@ def main():
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
-        if ops.TIMER is not None:
-            summ = ops.TIMER.summary()
-            ops.TIMER = None
-            kernels = {}
-            for name, s in summ.items():
-                rate = s["work_per_launch"] / (s["avg_ms"] * 1e-3)
-                k = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "total_ms_per_step": s["total_ms"] / args.steps}
-                if s["unit"] == "flop":
-                    k.update(bound="mfma", algorithmic_flops_per_launch=s["work_per_launch"], achieved_tflops=rate / 1e12,
-                             frac=rate / 1e12 / PEAK_BF16_DENSE_TFLOPS)
-                else:
-                    k.update(bound="hbm", algorithmic_bytes_per_launch=s["work_per_launch"], achieved_gbs=rate / 1e9,
-                             frac=rate / 1e9 / PEAK_HBM_GBS)
-                kernels[name] = k
-            # dominant kernel = largest share of the step among the HAND-WRITTEN kernels.  The dense projections are the vendor's
-            # hipBLASLt (north_star: MFMA by hand only for attention and LoRA); they are timed too and reported as one entry
-            # ("hipblaslt_gemm (vendor)": all shapes together) so that their share of the step is in the same JSON.
-            own = [k for k in kernels if "(vendor)" not in k]
-            dom = max(own, key=lambda k: kernels[k]["total_ms_per_step"])
-            kd = kernels[dom]
-            # traffic: HBM bytes per launch from the PMC pass of the same command (profiles/, collected per the guide's
-            # recipe: separate --pmc runs, FETCH_SIZE/WRITE_SIZE with the gfx950 corrections), when a summary is present
-            pmc_all = {}
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                with open(pmc) as f:
-                    pmc_all = json.load(f)
-            traffic = pmc_all.get(dom, {}).get("hbm_bytes_per_launch")
-
-            def roof(name):
-                k = kernels[name]
-                r = {"kernel": name, "bound": k["bound"], "achieved": k.get("achieved_tflops", k.get("achieved_gbs")),
-                     "peak": PEAK_BF16_DENSE_TFLOPS if k["bound"] == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if k["bound"] == "mfma" else "GB/s",
-                     "frac": k["frac"], "avg_launch_ms": k["avg_ms"], "share_of_step": k["total_ms_per_step"] / ms,
-                     "traffic": pmc_all.get(name, {}).get("hbm_bytes_per_launch")}
-                for key in ("mfma_busy", "clock_mhz"):        # from the round's PMC pass (tools/profile_round.sh), when present
-                    if key in pmc_all.get(name, {}):
-                        r[key] = pmc_all[name][key]
-                return r
-            if kd["bound"] == "mfma":
-                out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["achieved_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"],
-                                   "note": "largest hand-written kernel of the step; the vendor GEMMs are listed under kernels"}
-                for key in ("mfma_busy", "clock_mhz"):
-                    if key in pmc_all.get(dom, {}):
-                        out["roofline"][key] = pmc_all[dom][key]
-            else:
-                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_gbs"], "peak": PEAK_HBM_GBS,
-                                   "unit": "GB/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"]}
-            # the weakest hand-written kernel that matters (>= 5 % of the step), so that `roofline` cannot hide it
-            big = [k for k in own if kernels[k]["total_ms_per_step"] >= 0.05 * ms]
-            if big:
-                out["roofline_worst"] = roof(min(big, key=lambda k: kernels[k]["frac"]))
-            if "attn_bwd_dkv_kernel" in kernels and "attn_bwd_dq_kernel" in kernels:
-                a, b2 = kernels["attn_bwd_dkv_kernel"], kernels["attn_bwd_dq_kernel"]
-                fl = a["algorithmic_flops_per_launch"] + b2["algorithmic_flops_per_launch"]       # 8 S^2 d B H: the whole attention backward
-                t_ms = a["avg_ms"] + b2["avg_ms"]
-                out["attention_bwd_pair"] = {"algorithmic_flops_per_launch": fl, "avg_ms": t_ms, "achieved_tflops": fl / t_ms / 1e9,
-                                             "frac": fl / t_ms / 1e9 / PEAK_BF16_DENSE_TFLOPS,
-                                             "note": "dK/dV + dQ launches together against the algorithmic 8 S^2 d FLOPs (their S / dP recomputes are overhead)"}
-            out["kernels"] = kernels
+        add_kernel_report(out, ops, args.steps, ms)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_step)
         print(json.dumps(out), flush=True)

@@ -169,3 +169,40 @@ def test_wan_adapter_mount_scale_merge_as_the_generate_script_does(tmp_path):
         got = merged(x, t=t, context=ctx, seq_len=L)
     for b in range(2):
         _close(got[b], want[b], f"merged out[{b}]", tol=0.03, cos_min=0.999)
+
+
+def test_wan_trainer_under_the_dpo_engine_deferred_step_is_bit_identical():
+    """DPOEngine (flat AdamW, all-reduce slot, optimizer step deferred to the hook between the reference and the policy pass) driving WanDPOTrainer
+    without block recompute: three micro-steps with the deferred step land on exactly the adapters of the immediate-step engine"""
+    from videogpa_amd.trainer import DPOEngine
+    from videogpa_amd.wan import WanDPOTrainer
+    from videogpa_amd.wan_model import WanModel
+    g = torch.Generator(device="cuda").manual_seed(1)
+    batch = {"x_win": torch.randn(1, 4, 3, 8, 12, device="cuda", generator=g).bfloat16(), "x_lose": torch.randn(1, 4, 3, 8, 12, device="cuda", generator=g).bfloat16(),
+             "prompt_emb": torch.randn(1, 24, CFG["text_dim"], device="cuda", generator=g).bfloat16(),
+             "image_latent": torch.randn(1, 4, 1, 8, 12, device="cuda", generator=g).bfloat16()}
+    finals = []
+    for overlap in (False, True):
+        torch.manual_seed(0)
+        m = WanModel(**CFG)
+        with torch.no_grad():
+            torch.nn.init.normal_(m.head.head.weight, std=0.05)
+        m = m.to(device="cuda", dtype=torch.bfloat16)
+        m.enable_fp8(True)
+        tr = WanDPOTrainer({"lora_rank": 8, "lora_alpha": 16.0, "accumulate_grad_batches": 1, "learning_rate": 1e-3, "warmup_steps": 0,
+                            "enable_gradient_checkpointing": False}, m)
+        assert not m.gradient_checkpointing
+        with torch.no_grad():
+            gb = torch.Generator(device="cuda").manual_seed(2)
+            for n, p in tr.transformer.named_parameters():
+                if ".lora_B." in n:
+                    p.normal_(0.0, 0.02, generator=gb)
+        eng = DPOEngine(tr, overlap=overlap)
+        for _ in range(3):
+            logs = eng.micro_step(batch)
+            assert torch.isfinite(logs["train/loss"])
+        eng.flush()
+        assert tr.global_step == 3
+        finals.append(eng.opt.flat.flat.clone())
+    assert torch.equal(finals[0], finals[1])
+    assert (finals[0] != 0).any()

@@ -833,7 +833,8 @@ def attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale):
     Skv = k.shape[2]
     ws_bytes = _lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, Sq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-    _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 10.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+    # algorithmic work as SURVEY 8d counts it: backward = 2 x forward (dV, dP, dK, dQ); the S = QK^T recomputes of the split kernels are overhead
+    _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 8.0 * B * H * Sq * Skv * D, lambda: _lib.call(
         "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
         _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, float(scale), -1 if ATTN128_W1 else 0, ws, ws_bytes, _stream()))
 

@@ -63,6 +63,7 @@ class WanDPOTrainer(nn.Module):
         self.num_train_timesteps, self.shift, self.patch_size = cfg["num_train_timesteps"], cfg["shift"], tuple(cfg["patch_size"])
         self.global_step = 0
         self._rng = None
+        self.after_reference = None      # DPOEngine's hook: a deferred optimizer step lands between the reference and the policy pass
         if cfg["enable_gradient_checkpointing"] is not None:
             base = self.transformer.get_base_model()
             if not hasattr(base, "enable_gradient_checkpointing"):
@@ -114,10 +115,14 @@ class WanDPOTrainer(nn.Module):
             kw2 = dict(t=torch.cat([t_batch, t_batch]), context=ctx + ctx, seq_len=seq_len)
             r = self._ref(xw_in + xl_in, **kw2)                                                                             # reference first (:227-229)
             v_wr, v_lr = torch.stack(r[:B]), torch.stack(r[B:])
+            if self.after_reference is not None:
+                self.after_reference()
             p = self.transformer(xw_in + xl_in, **kw2)
             v_w, v_l = torch.stack(p[:B]), torch.stack(p[B:])
         else:
             v_wr, v_lr = torch.stack(self._ref(xw_in, **kw)), torch.stack(self._ref(xl_in, **kw))                         # reference first (:227-229)
+            if self.after_reference is not None:
+                self.after_reference()
             v_w, v_l = torch.stack(self.transformer(xw_in, **kw)), torch.stack(self.transformer(xl_in, **kw))
         v_pol = torch.stack([v_w, v_l], dim=1).to(x_win.dtype).contiguous()
         v_ref = torch.stack([v_wr, v_lr], dim=1).to(x_win.dtype).contiguous()
