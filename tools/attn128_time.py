@@ -1,9 +1,16 @@
 """Timing of the head_dim-128 attention entry points at the Wan2.2 self-attention shape (B*H = 24, S = 18480), per kernel family:
 forward (w1 / compiler-scheduled), backward with the dK/dV kernel in either form.   gpurun -- 'PYTHONPATH=. python tools/attn128_time.py'"""
+import argparse
+
 import torch
 from videogpa_amd import _lib, ops
 
-B, H, S, D = 1, 24, 18480, 128
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=1, help="2 = win and lose as one batch, as the cfg5 step runs them")
+ap.add_argument("--product-only", action="store_true", help="only the kernels the cfg5 step launches (for rocprofv3 --pmc passes)")
+ap.add_argument("--iters", type=int, default=5)
+a_ = ap.parse_args()
+B, H, S, D = a_.B, 24, 18480, 128
 g = torch.Generator(device="cuda").manual_seed(0)
 q, k, v, do = (torch.randn(B, H, S, D, device="cuda", generator=g).bfloat16() for _ in range(4))
 st = lambda t: ops._bhs_strides(t)
@@ -23,7 +30,7 @@ def bwd(mode):
     _lib.call("vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv), B, H, S, S, scale, mode, wsb, wsb.numel(), stream)
 
 
-def timeit(fn, n=5):
+def timeit(fn, n=a_.iters):
     fn(); fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,7 +41,10 @@ def timeit(fn, n=5):
 
 
 ff = 4.0 * B * H * S * S * D
-for name, fn, fl in [("fwd w1", lambda: fwd(True), ff), ("fwd simple", lambda: fwd(False), ff), ("bwd (w1 dq + w1 dkv)", lambda: bwd(1), 2.5 * ff),
-                     ("bwd (compiler-scheduled)", lambda: bwd(0), 2.5 * ff)]:
+cases = [("fwd w1", lambda: fwd(True), ff), ("fwd simple", lambda: fwd(False), ff), ("bwd (w1 dq + w1 dkv)", lambda: bwd(1), 2.0 * ff),
+         ("bwd (compiler-scheduled)", lambda: bwd(0), 2.0 * ff)]
+if a_.product_only:
+    cases = [cases[0], cases[2]]
+for name, fn, fl in cases:
     t = timeit(fn)
     print(f"{name:32s} {t:8.3f} ms   {fl / t / 1e9:7.0f} TFLOP/s algorithmic")

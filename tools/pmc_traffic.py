@@ -31,16 +31,17 @@ for f in glob.glob(f"{root}/pmc_{tag}_*/**/*counter_collection.csv", recursive=T
     for r in csv.DictReader(open(f)):
         acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = {}
-try:
-    for r in csv.DictReader(open(f"{root}/{tag}_attn_kernel_stats.csv")):
-        dur[kname(r["Name"])] = float(r["AverageNs"])
-except OSError as e:
-    print("no attention kernel stats:", e)
+for stats in (f"{root}/{tag}_attn_kernel_stats.csv", f"{root}/{tag}_attn128_kernel_stats.csv"):
+    try:
+        for r in csv.DictReader(open(stats)):
+            dur[kname(r["Name"])] = float(r["AverageNs"])
+    except OSError as e:
+        print("no attention kernel stats:", e)
 # the full-round launches carry the bench names; tail-split (<true>) launches, merges and the redo pass keep their own
 alias = {"attn_fwd_pipe_kernel<2, 4, false>": "attn_fwd_kernel (online-softmax form)", "attn_fwd_w1_kernel<false>": "attn_fwd_kernel",
          "attn_bwd_dkv_w1_kernel<false>": "attn_bwd_dkv_kernel", "attn_bwd_dq_w1_kernel<false>": "attn_bwd_dq_kernel",
          "attn_bwd_dkv_kernel<false>": "attn_bwd_dkv_kernel (2 waves per SIMD)", "attn_bwd_dq_kernel<2, false>": "attn_bwd_dq_kernel (2 waves per SIMD)",
-         "w1_bwd_prep_kernel": "attn_delta_kernel"}
+         "w1_bwd_prep_kernel": "attn_delta_kernel", "attn128_fwd_w1_kernel": "attn128_fwd"}
 out = {}
 for k, cs in acc.items():
     if k.startswith("at::") or "Cijk" in k or "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
@@ -60,6 +61,19 @@ for k, cs in acc.items():
     if mean("SQ_LDS_IDX_ACTIVE"):
         e["lds_bank_conflict_frac"] = mean("SQ_LDS_BANK_CONFLICT") / mean("SQ_LDS_IDX_ACTIVE")
     out[alias.get(k, k)] = e
+# bench.py times the head_dim-128 backward as ONE entry (delta + dK/dV + dQ launches of vgpa_attn128_bwd): bytes add up, occupancy and clock are
+# duration-weighted means of the two matrix kernels
+parts = [out[k] for k in ("attn128_dkv_w1_kernel", "attn128_dq_w1_kernel") if k in out]
+if len(parts) == 2:
+    e = {"hbm_bytes_per_launch": sum(p["hbm_bytes_per_launch"] for p in parts) + out.get("attn128_delta_kernel", {}).get("hbm_bytes_per_launch", 0.0),
+         "note": "attn128_dkv_w1_kernel + attn128_dq_w1_kernel (+ attn128_delta_kernel) of one vgpa_attn128_bwd call"}
+    if all("avg_ns_under_rocprof" in p for p in parts):
+        w = [p["avg_ns_under_rocprof"] for p in parts]
+        for key in ("mfma_busy", "clock_mhz"):
+            if all(key in p for p in parts):
+                e[key] = sum(p[key] * wi for p, wi in zip(parts, w)) / sum(w)
+        e["avg_ns_under_rocprof"] = sum(w)
+    out["attn128_bwd"] = e
 json.dump(out, open(f"{root}/pmc_traffic_{tag}.json", "w"), indent=1)
 for k, v in out.items():
     print(f"{k:48s} hbm {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  mfma_busy {v.get('mfma_busy', float('nan')):.3f}  clock {v.get('clock_mhz', float('nan')):7.0f} MHz")

@@ -24,4 +24,24 @@ fa=$(find $R/gpurun_out/prof_${tag}_attn -name "*kernel_stats.csv" | head -1)
 find $R/gpurun_out/prof_${tag}_attn -name "*kernel_trace.csv" -delete
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch_ew --output-format csv -- python $R/tools/ew_bench.py > $R/gpurun_out/pmc_${tag}_fetch_ew.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write_ew --output-format csv -- python $R/tools/ew_bench.py > $R/gpurun_out/pmc_${tag}_write_ew.log 2>&1
+# cfg5 (Wan2.2-TI2V-5B): kernel stats of its bench line, and the same PMC passes over the head_dim-128 attention kernels at the pair-batch shape
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_cfg5 --output-format csv -- python $R/bench.py --config cfg5 --steps 2 --warmup 1 \
+    > $R/gpurun_out/prof_${tag}_bench_cfg5.json 2> $R/gpurun_out/prof_${tag}_cfg5.log
+f5=$(find $R/gpurun_out/prof_${tag}_cfg5 -name "*kernel_stats.csv" | head -1)
+[ -n "$f5" ] && cp $f5 $R/gpurun_out/${tag}_bench_cfg5_kernel_stats.csv && python $R/profiles/summarize.py $f5 40 > $R/gpurun_out/${tag}_bench_cfg5_kernel_stats_summary.txt
+find $R/gpurun_out/prof_${tag}_cfg5 -name "*kernel_trace.csv" -delete
+export PYTHONPATH=$R
+A128="python $R/tools/attn128_time.py --B 2 --product-only --iters 2"
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch_a128 --output-format csv -- $A128 > $R/gpurun_out/pmc_${tag}_fetch_a128.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write_a128 --output-format csv -- $A128 > $R/gpurun_out/pmc_${tag}_write_a128.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $R/gpurun_out/pmc_${tag}_sq_a128 --output-format csv -- $A128 > $R/gpurun_out/pmc_${tag}_sq_a128.log 2>&1
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_${tag}_grbm_a128 --output-format csv -- $A128 > $R/gpurun_out/pmc_${tag}_grbm_a128.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_a128 --output-format csv -- $A128 > $R/gpurun_out/prof_${tag}_a128.log 2>&1
+fb=$(find $R/gpurun_out/prof_${tag}_a128 -name "*kernel_stats.csv" | head -1)
+[ -n "$fb" ] && cp $fb $R/gpurun_out/${tag}_attn128_kernel_stats.csv
+find $R/gpurun_out/prof_${tag}_a128 -name "*kernel_trace.csv" -delete
+# socket power / shader clock during the default bench command (the power-limit evidence of DESIGN section 4.0)
+rocm-smi --showpower --showclocks --showmaxpower --json > $R/gpurun_out/${tag}_rocm_smi_idle.json 2>&1
+timeout 300 python $R/tools/power_trace.py --out $R/gpurun_out/power_${tag}.json -- python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-kernel-timer \
+    > $R/gpurun_out/power_${tag}_bench.json 2> $R/gpurun_out/power_${tag}.log
 python $R/tools/pmc_traffic.py $R/gpurun_out $tag
