@@ -258,7 +258,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
     F_ = C["frames"] if args.frames is None else args.frames
     H_ = C["height"] if args.height is None else args.height
     W_ = C["width"] if args.width is None else args.width
-    layers = 30 if args.layers == 42 else args.layers
+    layers = 30 if args.layers is None else args.layers
     ckpt = bool(args.checkpoint)
     stride = args.checkpoint_stride or 1
     torch.manual_seed(0)                                 # identical base weights and adapter init on every rank
@@ -340,7 +340,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json configuration (cfg2 = the headline)")
-    ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is NOT a BASELINE config")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: anything but the model's own depth (42; cfg5: 30) is NOT a BASELINE config")
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -379,6 +379,8 @@ def main():
     C = CONFIGS[args.config]
     if args.config == "cfg5":
         return main_wan(args, C, world, rank, dev, force_dist)
+    if args.layers is None:
+        args.layers = 42
     F_ = C["frames"] if args.frames is None else args.frames
     H_ = C["height"] if args.height is None else args.height
     W_ = C["width"] if args.width is None else args.width

@@ -348,3 +348,28 @@ def test_wan_self_attention_core_on_the_fused_qkv_buffer():
     ob.backward(do)
     assert torch.equal(oa, ob)
     assert torch.equal(a.grad, b.grad)
+
+
+def test_wan_ln_mod_passthrough_adds_the_residual_gradient_in_the_kernel():
+    """h, xp = ln_mod(x, passthrough=True); loss through both outputs: dx = LN-backward(dh) + dxp, equal to autograd's own sum of the two paths"""
+    from videogpa_amd.wan_model import ln_mod
+    g = torch.Generator(device="cuda").manual_seed(31)
+    rows, C, G = 130, 3072, 2
+    x = torch.randn(rows, C, device="cuda", generator=g)
+    gid = torch.randint(0, G, (rows,), device="cuda", generator=g).int()
+    tab = _tab(G, 6, C, g)
+    dh = torch.randn(rows, C, device="cuda", generator=g).bfloat16()
+    dxp = torch.randn(rows, C, device="cuda", generator=g)
+    a = x.clone().requires_grad_(True)
+    h, xp = ln_mod(a, gid, None, None, tab[:, 3], tab[:, 4], 1e-6, passthrough=True)
+    torch.autograd.backward([h, xp], [dh, dxp])
+    b = x.clone().requires_grad_(True)
+    h2 = ln_mod(b, gid, None, None, tab[:, 3], tab[:, 4], 1e-6)
+    torch.autograd.backward([h2, b * 1.0], [dh, dxp])
+    assert torch.equal(h, h2) and torch.equal(xp, x)
+    # the same two fp32 terms added once inside the kernel (contracted into an fma) and once by autograd: one rounding apart
+    assert (a.grad - b.grad).abs().max().item() <= 1e-6 * b.grad.abs().max().item()
+    c = x.clone().requires_grad_(True)
+    h3, xp3 = ln_mod(c, gid, None, None, tab[:, 3], tab[:, 4], 1e-6, passthrough=True)
+    xp3.backward(dxp)                                        # LN output unused: the residual gradient passes through
+    assert torch.equal(c.grad, dxp)

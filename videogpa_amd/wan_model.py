@@ -43,10 +43,13 @@ def _ptr_dtype(x):
 class _LnModFn(torch.autograd.Function):
     """bf16( LN_eps(x) [rounded to bf16] * ln_w + ln_b, then * (1 + scale[gid]) + shift[gid] );   x [rows, D] fp32 or bf16.
     pad > 0: the result is the head of a [rows, D + pad] buffer (ops._padded_empty) whose tail the consuming projection fills with its LoRA
-    down-projection, so the K-extended GEMM (ops.LoraExt) reads its operand in place."""
+    down-projection, so the K-extended GEMM (ops.LoraExt) reads its operand in place.
+    passthrough: x is returned as a second output for the residual path of the same branch (x' = x + gate * f(LN(x))); the backward then gets
+    the residual path's gradient as an argument and adds it inside the LN backward kernel (`dres`) instead of autograd adding two [rows, D] fp32
+    tensors in a pass of its own."""
 
     @staticmethod
-    def forward(ctx, x, gid, ln_w, ln_b, shift, scale, eps, round_xhat, pad):
+    def forward(ctx, x, gid, ln_w, ln_b, shift, scale, eps, round_xhat, pad, passthrough):
         rows, D = x.shape
         x = x.contiguous()
         out = ops._padded_empty((rows,), D, pad, torch.bfloat16, x.device) if pad else torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
@@ -58,16 +61,23 @@ class _LnModFn(torch.autograd.Function):
             mean, rstd, _stream()), "byte")
         ctx.save_for_backward(x, mean, rstd, gid, ln_w, scale)
         ctx.ms = ms
+        ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None, not as a zero tensor to be added
+        if passthrough:
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, mean, rstd, gid, ln_w, scale = ctx.saved_tensors
         rows, D = x.shape
+        if dy is None:
+            return (None if dres is None else dres.to(x.dtype)), None, None, None, None, None, None, None, None, None
+        if dres is not None and (dres.dtype != torch.float32 or not dres.is_contiguous()):
+            dres = dres.float().contiguous()
         dx = torch.empty(rows, D, dtype=torch.float32, device=x.device)
-        ops._timed("wan_ln_mod_bwd", (x.element_size() + 6.0) * rows * D, lambda: _lib.call(
-            "vgpa_wan_ln_mod_bwd", dy.contiguous(), x, _ptr_dtype(x), mean, rstd, gid, ln_w, scale, ctx.ms, rows, D, None, dx, _stream()), "byte")
-        return dx.to(x.dtype), None, None, None, None, None, None, None, None
+        ops._timed("wan_ln_mod_bwd", (x.element_size() + (6.0 if dres is None else 10.0)) * rows * D, lambda: _lib.call(
+            "vgpa_wan_ln_mod_bwd", dy.contiguous(), x, _ptr_dtype(x), mean, rstd, gid, ln_w, scale, ctx.ms, rows, D, dres, dx, _stream()), "byte")
+        return dx.to(x.dtype), None, None, None, None, None, None, None, None, None
 
 
 class _GateResidualFn(torch.autograd.Function):
@@ -234,8 +244,9 @@ class _FfnFp8Fn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None, None, None
 
 
-def ln_mod(x, gid=None, ln_w=None, ln_b=None, shift=None, scale=None, eps=1e-6, round_xhat=False, pad=0):
-    return _LnModFn.apply(x, gid, ln_w, ln_b, shift, scale, eps, round_xhat, int(pad))
+def ln_mod(x, gid=None, ln_w=None, ln_b=None, shift=None, scale=None, eps=1e-6, round_xhat=False, pad=0, passthrough=False):
+    """passthrough=True returns (LN output, x): feed THAT x into the branch's residual add (see _LnModFn)"""
+    return _LnModFn.apply(x, gid, ln_w, ln_b, shift, scale, eps, round_xhat, int(pad), bool(passthrough))
 
 
 def gate_residual(x, y, gid=None, gate=None, dy_pad=0):
@@ -393,12 +404,16 @@ class WanAttentionBlock(nn.Module):
         first = x.dtype == torch.bfloat16                           # norm1(x).type_as(x) rounds only while the stream is still bf16
         sa_in, sa_out = self.self_attn.pads()
         ca_in, ca_out = self.cross_attn.pads()
-        h = ln_mod(x, gid, None, None, tab[:, 0], tab[:, 1], self.eps, round_xhat=first, pad=sa_in)
-        x = gate_residual(x.float() if first else x, self.self_attn(h, B, L, rope), gid, tab[:, 2], dy_pad=sa_out)
+        if first:         # block 0 takes the bf16 patch embedding; the stream is fp32 from its first residual add on
+            h = ln_mod(x, gid, None, None, tab[:, 0], tab[:, 1], self.eps, round_xhat=True, pad=sa_in)
+            x = x.float()
+        else:
+            h, x = ln_mod(x, gid, None, None, tab[:, 0], tab[:, 1], self.eps, pad=sa_in, passthrough=True)
+        x = gate_residual(x, self.self_attn(h, B, L, rope), gid, tab[:, 2], dy_pad=sa_out)
         if isinstance(self.norm3, nn.Identity):
             h = x.to(torch.bfloat16)
         else:
-            h = ln_mod(x, None, _f32(self.norm3.weight), _f32(self.norm3.bias), None, None, self.eps, pad=ca_in)
+            h, x = ln_mod(x, None, _f32(self.norm3.weight), _f32(self.norm3.bias), None, None, self.eps, pad=ca_in, passthrough=True)
         x = gate_residual(x, self.cross_attn(h, context, B, L), None, None, dy_pad=ca_out)
         f0, f2 = self.ffn[0], self.ffn[2]
         if self.fp8_ffn:
