@@ -138,11 +138,13 @@ def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):
     assert torch.equal(plain[0], rccl[0]) and torch.equal(plain[1], rccl[1])
 
 
-def test_cfg5_wan22_ti2v_5b_full_size_pair_step():
+@pytest.mark.parametrize("recompute,mem_gb", [(True, 80), (False, 230)])
+def test_cfg5_wan22_ti2v_5b_full_size_pair_step(recompute, mem_gb):
     """BASELINE configs[4]: Wan2.2-TI2V-5B at 81 f x 704 x 1280 (latent 48 x 21 x 44 x 80 -> 18 480 tokens, 30 blocks, 24 heads of 128, text 512),
-    LoRA r = 64 on q/k/v/o, per-block checkpointing, e4m3 feed-forward.  Random weights: with B = 0 the policy equals the reference, so the loss is
-    ln 2 after 30 layers (the fp8 and bf16 paths are deterministic per input), gradients reach exactly the 240 lora_B tensors and are finite;
-    after one optimizer step the policy has moved and the loss is still finite.  44 GB."""
+    LoRA r = 64 on q/k/v/o, e4m3 feed-forward; with the reference's per-block checkpointing (48 GB) and with every activation resident (the
+    bench.py --config cfg5 setting: 168-206 GB of the 288).  Random weights: with B = 0 the policy equals the reference, so the loss is ln 2 after 30
+    layers (the fp8 and bf16 paths are deterministic per input), gradients reach exactly the 240 lora_B tensors and are finite; after one optimizer
+    step the policy has moved and the loss is still finite."""
     from videogpa_amd.wan import WanDPOTrainer
     from videogpa_amd.wan_model import WanModel
     import gc
@@ -158,9 +160,9 @@ def test_cfg5_wan22_ti2v_5b_full_size_pair_step():
     assert sum(p.numel() for p in m.parameters()) > 4.9e9
     with torch.no_grad():
         torch.nn.init.normal_(m.head.head.weight, std=0.02)
-    m.enable_gradient_checkpointing(True)
     m.enable_fp8(True)
-    tr = WanDPOTrainer({}, m)
+    tr = WanDPOTrainer({"enable_gradient_checkpointing": recompute}, m)
+    assert m.gradient_checkpointing == recompute
     opt = tr.configure_optimizers()
     g = torch.Generator(device="cuda").manual_seed(1)
     batch = {"x_win": torch.randn(1, 48, 21, 44, 80, device="cuda", generator=g).bfloat16(), "x_lose": torch.randn(1, 48, 21, 44, 80, device="cuda", generator=g).bfloat16(),
@@ -176,4 +178,6 @@ def test_cfg5_wan22_ti2v_5b_full_size_pair_step():
     opt.step(); opt.zero_grad()
     loss2, _ = tr.training_step(batch)
     assert torch.isfinite(loss2) and abs(loss2.item() - math.log(2.0)) < 0.05
-    assert torch.cuda.max_memory_allocated() / 2 ** 30 < 80
+    assert torch.cuda.max_memory_allocated() / 2 ** 30 < mem_gb
+    del tr, opt, m, loss, loss2, named, gb, ga
+    gc.collect(); torch.cuda.empty_cache()

@@ -181,6 +181,8 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(const bf16_t* __res
 // attn128_fwd_kernel.
 #include "attn_w1.h"
 
+#include <cstdlib>
+
 typedef __attribute__((ext_vector_type(16))) uint32_t u32x16_t;
 typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
 #define W1H_TILE_BYTES 16384
@@ -752,6 +754,15 @@ extern "C" size_t vgpa_attn128_fwd_workspace_bytes(int64_t B, int64_t H, int64_t
 
 // workspace NULL (or too few keys for the pipeline to pay): the compiler-scheduled kernel
 #define ATTN128_W1_MIN_KEYS 1024
+// the sweep length from which the one-wave-per-SIMD kernels are used; VGPA_ATTN128_MIN_SWEEP overrides it (measurements, tests)
+static int64_t attn128_min_sweep() {
+    static const int64_t v = [] {
+        const char* e = getenv("VGPA_ATTN128_MIN_SWEEP");
+        const long n = e ? atol(e) : 0;
+        return (int64_t)(n >= 256 ? n : ATTN128_W1_MIN_KEYS);
+    }();
+    return v;
+}
 extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                                     const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
                                     void* workspace, size_t ws_bytes, hipStream_t stream) {
@@ -761,7 +772,7 @@ extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v,
     const int64_t n_qt = (Sq + 127) / 128, tasks = B * H * n_qt;
     if (tasks >= ((int64_t)1 << 31)) return VGPA_ERR_INVALID;
     const float c = scale * LOG2E_F;
-    if (workspace && Skv >= ATTN128_W1_MIN_KEYS) {
+    if (workspace && Skv >= attn128_min_sweep()) {
         if (ws_bytes < vgpa_attn128_fwd_workspace_bytes(B, H, Sq) || ((uintptr_t)workspace & 3)) return VGPA_ERR_WORKSPACE;
         const int64_t n_q256 = (Sq + 255) / 256, tasks256 = B * H * n_q256;
         unsigned* kmax2 = (unsigned*)workspace;
@@ -807,8 +818,8 @@ extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v,
     const float c = scale * LOG2E_F;
     float* delta = (float*)workspace;
     float* stats = delta + total;
-    const bool w1 = dkv_mode == 1 || (dkv_mode < 0 && Sq >= 1024);
-    const bool w1q = dkv_mode == 1 || (dkv_mode < 0 && Skv >= 1024);     // the dQ kernel sweeps the keys
+    const bool w1 = dkv_mode == 1 || (dkv_mode < 0 && Sq >= attn128_min_sweep());
+    const bool w1q = dkv_mode == 1 || (dkv_mode < 0 && Skv >= attn128_min_sweep());     // the dQ kernel sweeps the keys
     VGPA_LAUNCH(attn128_delta_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, mk128(do_strides),
                 mk128(o_strides), (int)Sq, (int)H, total, delta, lse2, 1.f / c, (w1 || w1q) ? stats : (float*)nullptr);
     if (w1q)

@@ -12,7 +12,14 @@ MI355X-first choices (everything else is the upstream arithmetic):
     the batch (2 per sample for TI2V) + an int32 group id per token; the time MLP runs on the distinct values only;
   * fp32 residual stream, bf16 GEMM operands, fused LN + modulation, RMS-norm + weight + RoPE, gate + residual row kernels
     (csrc/wan.hip); attention is csrc/attention_hd128.hip (self: Sq = Skv = L; cross: Skv = text_len);
-  * the four LoRA projections of each attention run ops.linear_lora_ext through lora.LoraLinear once wrapped by get_peft_model.
+  * q / k / v of the self-attention are ONE projection [3 dim, dim] with the (up to three) LoRA adapters riding the GEMM as extra K
+    (ops.LoraExt): the LN kernel writes its rows with the adapters' tail columns behind them, q / k are normalised out of the fused output
+    by stride, v is read in place, and the backward assembles d(qkv) in one buffer (_SelfAttnFn); the o projections and the cross-attention's
+    q get their tails from the attention kernel / the gate's backward the same way (no operand copies anywhere);
+  * the residual path's gradient of each branch is added inside the LN backward kernel (ln_mod passthrough, _FfnFp8Fn);
+  * enable_fp8(): the frozen feed-forward runs on e4m3 operands written by their producers (csrc/fp8.hip), one autograd node per branch;
+  * no block recompute by default: 288 GB hold the activations of the full-size pair step (enable_gradient_checkpointing(True, stride=k)
+    restores the reference's behaviour, every k-th block).
 Call convention as upstream:  model(list of [C,F,H,W], t=[B] or [B, seq_len], context=list of [n, text_dim], seq_len=int) -> list of
 [C_out,F,H,W] fp32.  All samples of a call must share one latent shape (the reference's batches do), and seq_len must equal the token
 count (it does: 03_train.py:176-179 computes it from the latent)."""
