@@ -41,7 +41,9 @@ CONFIGS = {
                  label="BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720"),
     "cfg3": dict(model="COGVIDEOX_5B_I2V", frames=13, height=60, width=90, checkpoint=False, cond=True,
                  label="BASELINE configs[2]: CogVideoX-5B-I2V (32 input channels, learned positional table), 49f x 480x720 + image-cond latent"),
-    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=True, checkpoint_stride=4, cond=False,
+    # S = 41 026: 6.6 GB of saved activations per block and pair would need 277 GB + weights; with lean activations (5.1 GB per block) all 42
+    # blocks stay resident in 230 GB and nothing is recomputed (9.17 s; every 4th block recomputed without lean: 9.70 s in 227 GB)
+    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=False, cond=False, lean=True,
                  label="BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t=2), 81f x 768x1360 (21 latent frames, even-cropped to 20)"),
     "cfg5": dict(model="WAN22_TI2V_5B", frames=21, height=44, width=80, checkpoint=False, cond=True,
                  label="BASELINE configs[4]: Wan2.2-TI2V-5B (30 blocks, dim 3072, 24x128 heads, ffn 14336, text 512), 81f x 704x1280 -> latent 48x21x44x80, "
@@ -167,7 +169,7 @@ def _pick_cpu_threads():
     return best, seen
 
 
-def add_kernel_report(out, ops, steps, ms):
+def add_kernel_report(out, ops, steps, ms, use_pmc=True):
     """per-kernel live timings (HIP events on the launch stream, ops.KernelTimer) -> out["kernels"], out["roofline"], out["roofline_worst"]"""
     if ops.TIMER is None:
         return
@@ -195,7 +197,7 @@ def add_kernel_report(out, ops, steps, ms):
         # recipe: separate --pmc runs, FETCH_SIZE/WRITE_SIZE with the gfx950 corrections), when a summary is present
         pmc_all = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if use_pmc and os.path.exists(pmc):        # the PMC pass ran at the cfg2 / cfg5 kernel shapes: other shapes report no traffic / occupancy
             with open(pmc) as f:
                 pmc_all = json.load(f)
         traffic = pmc_all.get(dom, {}).get("hbm_bytes_per_launch")
@@ -328,7 +330,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
-        add_kernel_report(out, ops, args.steps, ms)
+        add_kernel_report(out, ops, args.steps, ms, use_pmc=named)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
@@ -346,7 +348,9 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--rank-r", type=int, default=64)
     ap.add_argument("--checkpoint", action="store_true", default=None, help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
+    ap.add_argument("--no-checkpoint", dest="checkpoint", action="store_false", help="keep every block's activations (overrides a config's default recompute)")
     ap.add_argument("--checkpoint-stride", type=int, default=None, help="with --checkpoint: recompute only every k-th block (1 = all, like the reference)")
+    ap.add_argument("--lean", action="store_true", default=None, help="lean activations: the LN output and the normalised q / k are made again in the backward (23 %% fewer saved bytes per block)")
     ap.add_argument("--no-fp8", action="store_true", help="cfg5 only: bf16 feed-forward GEMMs instead of the e4m3 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -389,8 +393,10 @@ def main():
     cfg_kw = dict(getattr(vtr, C["model"]), num_layers=args.layers)
     torch.manual_seed(0)                           # identical adapter init (PEFT kaiming-uniform A) on every rank
     model = build_model(cfg_kw, dev, seed=0)       # identical base weights on every rank
+    lean = bool(C.get("lean", False) if args.lean is None else args.lean)
     trainer = CogVideoXDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2 * args.rank_r, "beta": 1.0, "accumulate_grad_batches": 1,
-                                   "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": ckpt_stride, "seed": 1234}, transformer=model)
+                                   "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": ckpt_stride, "lean_activations": lean,
+                                   "seed": 1234}, transformer=model)
     # LoRA B ~ N(0, 1e-3) so the step is beyond the trivial B=0 point
     gB = torch.Generator(device=dev).manual_seed(1)
     with torch.no_grad():
@@ -438,7 +444,7 @@ def main():
     dt = float(tt.item())
 
     if rank == 0:
-        named = (args.layers, F_, H_, W_, args.rank_r, ckpt) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"])
+        named = (args.layers, F_, H_, W_, args.rank_r, ckpt, lean) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"], bool(C.get("lean", False)))
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
         sync = logs["sync"].tolist()
@@ -450,14 +456,15 @@ def main():
                                    + f"paired latents [1,2,{F_},16,{H_},{W_}], S={S} tokens, {args.layers} blocks, LoRA r={args.rank_r} on "
                                    "to_q/to_k/to_v/to_out.0, 1 pair/GPU/step, optimizer step every step; random-init weights"
                                    + (f"; activation recompute of every {ckpt_stride}. block" if ckpt and ckpt_stride > 1 else
-                                      "; per-block activation recompute" if ckpt else ""),
+                                      "; per-block activation recompute" if ckpt else "")
+                                   + ("; lean activations (LN output and normalised q / k made again in the backward)" if lean else ""),
                        "name": args.config, "layers": args.layers, "tokens": S, "pairs_per_gpu": 1, "parallelism": f"dp{world}"},
             "loss": float(logs["train/loss"]), "loss_rank_mean": sync[0],
             "step_flops_algorithmic": F_step,
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
-        add_kernel_report(out, ops, args.steps, ms)
+        add_kernel_report(out, ops, args.steps, ms, use_pmc=named and args.config in ("cfg2", "cfg3"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_step)
         print(json.dumps(out), flush=True)

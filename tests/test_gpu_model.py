@@ -391,3 +391,29 @@ def test_gradient_checkpointing_gives_same_grads():
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) == 2 * 4 * cfg.num_layers
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n     # same kernels, same order -> bit-identical
+
+
+@pytest.mark.parametrize("rope", [True, False])
+def test_lean_activations_give_bit_identical_outputs_and_grads(rope):
+    """enable_lean_activations(): the LN output feeding q/k/v and the normalised q / k are made again in the backward instead of being kept;
+    same kernels on the same bf16 inputs -> bit-identical sample and adapter gradients, with and without per-block recompute on top."""
+    cfg, sd64, lora64, pm = _setup(b_std=0.05, rope=rope)
+    x, txt, t = _inputs(cfg, B=2, seed=13)
+    g = torch.Generator().manual_seed(6)
+    dy = torch.randn(x.shape, generator=g).to(torch.bfloat16).cuda()
+    pm.train()
+    runs = []
+    for lean, ckpt in ((False, False), (True, False), (True, True)):
+        pm.enable_lean_activations(lean)
+        if ckpt:
+            pm.enable_gradient_checkpointing()
+        for p in pm.parameters():
+            p.grad = None
+        y = pm(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
+        y.backward(dy)
+        runs.append((y.detach().clone(), {n: p.grad.clone() for n, p in pm.named_parameters() if p.grad is not None}))
+    assert len(runs[0][1]) == 2 * 4 * cfg.num_layers
+    for y, gr in runs[1:]:
+        assert torch.equal(y, runs[0][0])
+        for n in gr:
+            assert torch.equal(gr[n], runs[0][1][n]), n

@@ -252,6 +252,19 @@ def ln_modulate(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5, n_pad=0):
     return _ResidualLNFn.apply(x, None, None, ln_w, ln_b, mod, text_len, eps, n_pad, 0)[1]
 
 
+def ln_modulate_recompute(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
+    """The LN-modulate output again, outside autograd: the residual+LN kernel with no residual branch normalises the (already bf16) x exactly
+    as the fused pass that produced it did, so the result is bit-identical to the n that pass returned (lean activations)."""
+    B, S, D = x.shape
+    n = torch.empty_like(x)
+    mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    sv, s1v, st, s1t, mstride = _mod_ptrs(mod)
+    _timed("ln_modulate_fwd", 4.0 * B * S * D, lambda: _lib.call("vgpa_residual_ln_fwd", x, None, None, None, 0, ln_w, ln_b, sv, s1v, st, s1t, mstride, B, S, D,
+                                                                  text_len, float(eps), None, n, D, mean, rstd, _stream()), "byte")
+    return n
+
+
 def ln_modulate_v1(x, ln_w, ln_b, mod=None, text_len=0, eps=1e-5):
     """First-generation LN-modulate kernels (kept for A/B and as a second implementation under test)."""
     return _LNModulateFn.apply(x, ln_w, ln_b, mod, text_len, eps)
@@ -638,10 +651,12 @@ def frozen_linear_fp8(x, W, bias):
 
 class _LinearLoraExtFn(torch.autograd.Function):
     """y = x W^T + b (+ LoRA when `enabled`), W / b frozen; see LoraExt.  x / dy are used in place when they are the heads of
-    padded buffers (produced by ops.residual_ln / qknorm_attention with n_pad / o_pad / grad pads), copied into one otherwise."""
+    padded buffers (produced by ops.residual_ln / qknorm_attention with n_pad / o_pad / grad pads), copied into one otherwise.
+    x_recompute: a callable that returns x [M, K] again (bit-identical) in the backward; the forward then keeps only the [M, R] LoRA
+    down-projections instead of the whole [M, K + R] operand ("lean activations": x is a cheap function of a tensor that is saved anyway)."""
 
     @staticmethod
-    def forward(ctx, x, bias, ext, enabled, scalings, *AB):
+    def forward(ctx, x, bias, ext, enabled, scalings, x_recompute, *AB):
         K, R, N = ext.K, ext.R, ext.N
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
@@ -654,14 +669,19 @@ class _LinearLoraExtFn(torch.autograd.Function):
             lora_down(xv, ext.A_cat, out=tv)       # raw kernel write into the tail (no autograd version bump on the producer's buffer)
         # disabled (reference pass): the tail of a `_padded_empty` buffer is zero since its allocation
         y = _gemm(x_ext, ext.W_ext, bias)
-        ctx.save_for_backward(x_ext)
+        if x_recompute is not None and enabled:
+            ctx.save_for_backward(tv.contiguous())
+            ctx.x_fn = x_recompute
+        else:
+            ctx.save_for_backward(x_ext)
+            ctx.x_fn = None
         ctx.ext, ctx.enabled, ctx.xshape, ctx.scalings = ext, enabled, x.shape, scalings
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         ext, enabled = ctx.ext, ctx.enabled
-        (x_ext,) = ctx.saved_tensors
+        (saved,) = ctx.saved_tensors
         K, R, N, Dn, rp, r, act = ext.K, ext.R, ext.N, ext.Dn, ext.rp, ext.r, ext.act
         dy2 = dy.reshape(-1, N)
         M = dy2.shape[0]
@@ -673,27 +693,31 @@ class _LinearLoraExtFn(torch.autograd.Function):
             for j, i in enumerate(act):
                 lora_down(dy_ext[:, i * Dn:(i + 1) * Dn], ext.sBt[j], out=dy_ext[:, N + j * rp:N + (j + 1) * rp])      # dT_i = dy_i (s B_i)
         dx = _gemm(dy_ext, ext.Wt_ext)                                                                                # dy W + dT A
-        out_grads = [None] * len(ctx.needs_input_grad[5:])
+        out_grads = [None] * len(ctx.needs_input_grad[6:])
         if enabled:
+            if ctx.x_fn is not None:
+                t_all, xh = saved, ctx.x_fn().reshape(M, K)          # [M, R] kept, x made again
+            else:
+                t_all, xh = saved[:, K:], saved[:, :K]
             for j, i in enumerate(act):
                 # dB_i = s dy_i^T T_i (T_i = x A_i^T sits in the tail of x_ext); the scale is applied to the fp32 result
-                out_grads[2 * i + 1] = lora_grad(dy_ext[:, i * Dn:(i + 1) * Dn], x_ext[:, K + j * rp:K + (j + 1) * rp], ctx.scalings[j])[:, :r]
-            dA = lora_grad(dy_ext[:, N:], x_ext[:, :K])                                                               # dT^T x, all adapters at once
+                out_grads[2 * i + 1] = lora_grad(dy_ext[:, i * Dn:(i + 1) * Dn], t_all[:, j * rp:(j + 1) * rp], ctx.scalings[j])[:, :r]
+            dA = lora_grad(dy_ext[:, N:], xh)                                                                        # dT^T x, all adapters at once
             for j, i in enumerate(act):
                 out_grads[2 * i] = dA[j * rp:j * rp + r]
-        return (dx.view(ctx.xshape), None, None, None, None, *out_grads)
+        return (dx.view(ctx.xshape), None, None, None, None, None, *out_grads)
 
 
-def linear_lora_ext(x, W, bias, ext, loras, enabled=True):
+def linear_lora_ext(x, W, bias, ext, loras, enabled=True, x_recompute=None):
     """loras: list (one per equal output slice) of None or (A [r,in] fp32, B [out_i,r] fp32, scaling) -- the adapters that EXIST
-    on this projection; `enabled` False = the reference pass (same GEMM, zero LoRA tail)."""
+    on this projection; `enabled` False = the reference pass (same GEMM, zero LoRA tail).  x_recompute: see _LinearLoraExtFn."""
     if W.requires_grad or (bias is not None and bias.requires_grad):
         raise RuntimeError("videogpa_amd: base weights are frozen on this path (LoRA-only training, as in the reference)")
     ext.refresh(W, len(loras), loras)
     flat = []
     for l in loras:
         flat += [None, None] if l is None else [l[0], l[1]]
-    return _LinearLoraExtFn.apply(x, bias, ext, bool(enabled), tuple(float(loras[i][2]) for i in ext.act), *flat)
+    return _LinearLoraExtFn.apply(x, bias, ext, bool(enabled), tuple(float(loras[i][2]) for i in ext.act), x_recompute, *flat)
 
 
 def linear_lora(x, W, bias, loras, ext=None):
@@ -873,9 +897,10 @@ class _QKNormAttentionFn(torch.autograd.Function):
     QK-norm (+ optional 3D RoPE on tokens >= text_len) -> flash attention; backward returns dqkv in the same layout."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad, rope_mode=0):
+    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad, rope_mode=0, recompute_qk=False):
         """o_pad / grad_pad: the attention output / the gradient of qkv are returned as heads of buffers that much wider (the
-        LoRA tails of the projections on either side, see LoraExt)."""
+        LoRA tails of the projections on either side, see LoraExt).  recompute_qk: the normalised q / k are not kept for the backward
+        but made again from qkv (one more pass of the QK-norm kernel, bit-identical) -- a third of this node's saved bytes."""
         _req(qkv, torch.bfloat16)
         B, S, W = qkv.shape
         Dh = W // (3 * H)
@@ -887,19 +912,31 @@ class _QKNormAttentionFn(torch.autograd.Function):
             "vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
             wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), int(rope_mode), _stream()), "byte")
         o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad)
-        ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
-        ctx.meta = (text_len, H, eps, grad_pad, int(rope_mode))
+        if recompute_qk:
+            ctx.save_for_backward(qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk)
+        else:
+            ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
+        ctx.meta = (text_len, H, eps, grad_pad, int(rope_mode), bool(recompute_qk))
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin = ctx.saved_tensors
-        text_len, H, eps, grad_pad, rope_mode = ctx.meta
+        text_len, H, eps, grad_pad, rope_mode, recompute_qk = ctx.meta
+        if recompute_qk:
+            qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk = ctx.saved_tensors
+        else:
+            qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin = ctx.saved_tensors
         B, S, W = qkv.shape
         Dh = W // (3 * H)
         do = do.contiguous()
         qkv5 = qkv.view(B, S, 3, H, Dh)
         q_in, k_in, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        if recompute_qk:
+            qn = torch.empty(B, H, S, Dh, dtype=torch.bfloat16, device=qkv.device)
+            kn = torch.empty_like(qn)
+            _timed("qknorm_rope_fwd", 8.0 * B * H * S * Dh, lambda: _lib.call(
+                "vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
+                wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), int(rope_mode), _stream()), "byte")
         dqkv = _padded_empty((B, S), W, grad_pad, qkv.dtype, qkv.device) if grad_pad else torch.empty_like(qkv)
         d5 = dqkv.unflatten(-1, (3, H, Dh))
         dq_in, dk_in, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
@@ -912,14 +949,14 @@ class _QKNormAttentionFn(torch.autograd.Function):
             "vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
             _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
             float(eps), rope_mode, _stream()), "byte")
-        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0, rope_mode=0):
+def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0, rope_mode=0, recompute_qk=False):
     """rope = (cos, sin) fp32 [S - text_len, 64]; rope_mode 0: interleaved pairs (diffusers' CogVideoX), 1: half-split pairs inside each
     32-feature half (VGGT's RotaryPositionEmbedding2D, tables from `rope2d_tables`)."""
     cos, sin = (None, None) if rope is None else rope
-    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad, rope_mode)
+    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad, rope_mode, bool(recompute_qk))
 
 
 def rope2d_tables(pos, head_dim=64, frequency=100.0):
