@@ -34,6 +34,10 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5
 PEAK_FP8_DENSE_TFLOPS = 5000.0    # same guide: ~5 PF dense fp8 (the vendor e4m3 GEMMs of cfg5 are priced against this)
 PEAK_HBM_GBS = 8000.0             # same guide: HBM3E ~8 TB/s
 TEXT_LEN = 226
+# live per-kernel HIP events (ops.KernelTimer): every launch during the first TIMER_FULL_STEPS timed steps, afterwards only the attention kernels
+# the roofline objects are computed from -- event packets between ALL ~1500 launches of a step cost 1.3 % of it
+TIMER_FULL_STEPS = 3
+TIMER_ALWAYS = ("attn_fwd_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn128_fwd", "attn128_bwd")
 
 # BASELINE.json configs that fit a bench line (SURVEY section 8 sizes).  cfg2 is the headline the metric is quoted on.
 CONFIGS = {
@@ -179,7 +183,8 @@ def add_kernel_report(out, ops, steps, ms, use_pmc=True):
         kernels = {}
         for name, s in summ.items():
             rate = s["work_per_launch"] / (s["avg_ms"] * 1e-3)
-            k = {"launches_per_step": s["launches"] / steps, "avg_ms": s["avg_ms"], "total_ms_per_step": s["total_ms"] / steps}
+            n_st = s.get("steps") or steps            # kernels outside the roofline set are sampled on the first timed steps only (ops.KernelTimer)
+            k = {"launches_per_step": s["launches"] / n_st, "avg_ms": s["avg_ms"], "total_ms_per_step": s["total_ms"] / n_st, "timed_steps": n_st}
             if s["unit"] == "flop":
                 peak = PEAK_FP8_DENSE_TFLOPS if "fp8" in name else PEAK_BF16_DENSE_TFLOPS
                 k.update(bound="mfma", algorithmic_flops_per_launch=s["work_per_launch"], achieved_tflops=rate / 1e12, frac=rate / 1e12 / peak)
@@ -298,12 +303,14 @@ def main_wan(args, C, world, rank, dev, force_dist):
         engine.micro_step(batch)
     engine.flush()
     if rank == 0 and not args.no_kernel_timer:
-        ops.TIMER = ops.KernelTimer()
+        ops.TIMER = ops.KernelTimer(full_steps=TIMER_FULL_STEPS, always=TIMER_ALWAYS)
     barrier()
     t0 = time.perf_counter()
     logs = None
     for _ in range(args.steps):
         logs = engine.micro_step(batch)
+        if ops.TIMER is not None:
+            ops.TIMER.next_step()
     logs.update(engine.flush())
     barrier()
     dt = time.perf_counter() - t0
@@ -429,12 +436,14 @@ def main():
         engine.micro_step(batch)
     engine.flush()
     if rank == 0 and not args.no_kernel_timer:
-        ops.TIMER = ops.KernelTimer()
+        ops.TIMER = ops.KernelTimer(full_steps=TIMER_FULL_STEPS, always=TIMER_ALWAYS)
     barrier()
     t0 = time.perf_counter()
     logs = None
     for _ in range(args.steps):
         logs = engine.micro_step(batch)
+        if ops.TIMER is not None:
+            ops.TIMER.next_step()
     logs.update(engine.flush())       # the last optimizer step (applied one micro-step late when the all-reduce is overlapped) is inside the timed region
     barrier()
     dt = time.perf_counter() - t0

@@ -30,17 +30,32 @@ def _i64x3(*v):
 
 class KernelTimer:
     """Optional HIP-event timing of individual kernel launches on the launch stream (bench.py's live roofline leg).
-    Disabled (None) by default: zero overhead in the product path."""
+    Disabled (None) by default: zero overhead in the product path.
 
-    def __init__(self):
+    Every event pair is a packet between two kernels that keeps the next launch from overlapping the tail of the previous one: timing all
+    ~1500 launches of a cfg2 step costs 1.3 % of the step (2.301 vs 2.331 s).  `full_steps` / `always`: after `full_steps` calls of next_step()
+    only the kernels named in `always` (the dominant ones the roofline is computed from) are still timed; the others were sampled on the
+    first steps of the timed region and run unobserved afterwards."""
+
+    def __init__(self, full_steps=None, always=()):
         self.records = {}
+        self.full_steps, self.always = full_steps, frozenset(always)
+        self.step = 0
+        self.steps_seen = {}
+
+    def next_step(self):
+        self.step += 1
 
     def run(self, name, work, fn, unit="flop"):
+        if self.full_steps is not None and self.step >= self.full_steps and name not in self.always:
+            fn()
+            return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
         self.records.setdefault(name, []).append((a, b, work, unit))
+        self.steps_seen.setdefault(name, set()).add(self.step)
 
     def summary(self):
         out = {}
@@ -48,7 +63,7 @@ class KernelTimer:
             ms = [a.elapsed_time(b) for a, b, _, _ in recs]
             work = sum(r[2] for r in recs) / len(recs)      # launches of one kernel can differ in size (q,k,v vs out LoRA)
             out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "work_per_launch": work,
-                         "unit": recs[0][3]}
+                         "unit": recs[0][3], "steps": len(self.steps_seen[name])}
         return out
 
 
