@@ -338,7 +338,7 @@ class CogVideoXTransformer3DModel(nn.Module):
     def enable_lean_activations(self, enabled=True):
         """Keep less per block for the backward: the LN output n1 (LoRA dA needs it) and the normalised q / k are made again from tensors that
         are saved anyway (the residual stream, the fused projection output) -- 23 % fewer saved bytes for two more row-kernel passes per block
-        (+1.5 % of a step).  What it buys: CogVideoX1.5 at S = 41 026 keeps ALL 42 blocks resident in 288 GB instead of recomputing every
+        (+0.3 % of a step).  What it buys: CogVideoX1.5 at S = 41 026 keeps ALL 42 blocks resident in 288 GB instead of recomputing every
         fourth block (bench.py --config cfg4).  Results are bit-identical either way."""
         self.lean_activations = bool(enabled)
 
