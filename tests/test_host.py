@@ -182,3 +182,41 @@ def test_variant_configs_match_the_reference_scripts():
     import pytest
     with pytest.raises(ValueError):
         variant_config("2b")
+
+
+def test_kernel_timer_samples_all_launches_on_the_first_steps_and_the_roofline_kernels_throughout(monkeypatch):
+    """ops.KernelTimer(full_steps, always): bench.py's live per-kernel timing -- every launch is timed during the first `full_steps` steps, afterwards
+    only the kernels the roofline objects are computed from; per-step figures divide by the steps a kernel was actually timed on."""
+    import torch
+    from videogpa_amd import ops
+
+    class FakeEvent:
+        clock = 0.0
+
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            FakeEvent.clock += 1.0
+            self.t = FakeEvent.clock
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    t = ops.KernelTimer(full_steps=2, always=("attn",))
+    ran = []
+    for step in range(5):
+        for name in ("attn", "ln", "attn", "gelu"):
+            t.run(name, 10.0, lambda n=name: ran.append(n), "flop" if name == "attn" else "byte")
+        t.next_step()
+    assert len(ran) == 20                                   # every launch runs, timed or not
+    s = t.summary()
+    assert s["attn"]["launches"] == 10 and s["attn"]["steps"] == 5
+    assert s["ln"]["launches"] == 2 and s["ln"]["steps"] == 2 and s["gelu"]["launches"] == 2
+    assert s["attn"]["avg_ms"] == 1.0 and s["attn"]["unit"] == "flop" and s["ln"]["unit"] == "byte"
+    full = ops.KernelTimer()                                # default: everything, always
+    for step in range(3):
+        full.run("ln", 1.0, lambda: None, "byte")
+        full.next_step()
+    assert full.summary()["ln"]["launches"] == 3 and full.summary()["ln"]["steps"] == 3
