@@ -16,14 +16,22 @@ ap.add_argument("--B", type=int, default=2)
 ap.add_argument("--H", type=int, default=48)
 ap.add_argument("--which", default="fwd,dkv,dq")
 ap.add_argument("--split", type=int, default=-1, help="forward split_mode: -1 automatic, 0 never")
+ap.add_argument("--data", default="randn", choices=["randn", "zeros", "const"], help="operand values: zeros / one constant toggle almost no datapath bits -> the time of the "
+                "instruction stream without the power throttle that random data brings (DESIGN section 4.0)")
 a = ap.parse_args()
 B, H, S = a.B, a.H, a.S
 g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B, S, 3, H, 64, generator=g, device="cuda").to(torch.bfloat16)
+if a.data == "zeros":
+    qkv.zero_()
+elif a.data == "const":
+    qkv.fill_(0.125)
 q = qkv[:, :, 0].permute(0, 2, 1, 3).contiguous()
 k = qkv[:, :, 1].permute(0, 2, 1, 3).contiguous()
 v = qkv[:, :, 2].permute(0, 2, 1, 3)           # token-major view, as in the model
 do = torch.randn(B, S, H * 64, generator=g, device="cuda").to(torch.bfloat16)
+if a.data != "randn":
+    do.fill_(0.0 if a.data == "zeros" else 0.125)
 dov = do.view(B, S, H, 64).permute(0, 2, 1, 3)
 dq, dk = torch.empty_like(q), torch.empty_like(k)
 dv = torch.empty(B, S, H, 64, dtype=torch.bfloat16, device="cuda").permute(0, 2, 1, 3)
