@@ -206,3 +206,47 @@ def test_wan_trainer_under_the_dpo_engine_deferred_step_is_bit_identical():
         finals.append(eng.opt.flat.flat.clone())
     assert torch.equal(finals[0], finals[1])
     assert (finals[0] != 0).any()
+
+
+def test_wan_fit_end_to_end_from_disk(tmp_path):
+    """main_train of train/Wan2.2-TI2V-5B/03_train.py:309-387 without Lightning: latents / conditions on disk (x [C,F,H,W], encoder_hidden_states,
+    image_latent) + meta json -> DPODataset -> the reference's collate_fn keys -> prefetching loader -> DPOEngine(WanDPOTrainer) -> periodic
+    checkpoint + final_lora; resume continues from the checkpoint's step."""
+    import json
+    from videogpa_amd.fit import fit
+    from videogpa_amd.wan_model import WanModel
+    g = torch.Generator().manual_seed(3)
+    groups = []
+    for gi in range(6):
+        vids = []
+        for vi in range(2):
+            torch.save(torch.randn(4, 3, 8, 12, generator=g).to(torch.bfloat16), tmp_path / f"lat_{gi}_{vi}.pt")
+            torch.save({"encoder_hidden_states": torch.randn(20, CFG["text_dim"], generator=g).to(torch.bfloat16),
+                        "image_latent": torch.randn(4, 1, 8, 12, generator=g).to(torch.bfloat16)}, tmp_path / f"cond_{gi}_{vi}.pt")
+            vids.append({"video_path": f"v{gi}_{vi}.mp4", "consistency_score": 0.2 + 0.5 * vi, "motion_norm": 1.0,
+                         "latent_path": f"lat_{gi}_{vi}.pt", "condition_path": f"cond_{gi}_{vi}.pt"})
+        groups.append({"group_id": f"g{gi}", "prompt": "p", "videos": vids})
+    (tmp_path / "meta_wan_data.json").write_text(json.dumps({"groups": groups}))
+
+    def model():
+        torch.manual_seed(0)
+        m = WanModel(**CFG)
+        with torch.no_grad():
+            torch.nn.init.normal_(m.head.head.weight, std=0.05)
+        m = m.to(device="cuda", dtype=torch.bfloat16)
+        m.enable_fp8(True)
+        return m
+
+    base = {"base_path": str(tmp_path), "metadata_path": str(tmp_path / "meta_wan_data.json"), "accumulate_grad_batches": 2, "batch_size": 1, "num_workers": 0,
+            "learning_rate": 1e-3, "warmup_steps": 1, "lora_rank": 8, "lora_alpha": 16.0}
+    logs = []
+    tr = fit(dict(base, max_steps=3, log_every_n_steps=1, checkpoint_every_n_steps=2, output_dir=str(tmp_path / "out")), transformer=model(), log=logs.append, model="wan")
+    assert type(tr).__name__ == "WanDPOTrainer" and tr.global_step == 3 and len(logs) >= 3
+    assert (tmp_path / "out" / "final_lora" / "adapter_model.safetensors").exists()
+    assert any(float(p.detach().abs().max()) > 0 for n, p in tr.transformer.named_parameters() if "lora_B" in n)     # B starts at zero: trained
+    ck = tmp_path / "out" / "checkpoints" / "step=2"
+    assert (ck / "adapter_model.safetensors").exists() and (ck / "optimizer.pt").exists() and (ck / "rng_rank0.pt").exists()
+    tr2 = fit(dict(base, max_steps=4, checkpoint_every_n_steps=0, resume_from=str(ck)), transformer=model(), log=lambda m: None, model="wan")
+    assert tr2.global_step == 4
+    with pytest.raises(ValueError):
+        fit(dict(base, max_steps=1), transformer=model(), model="dit")

@@ -1,6 +1,6 @@
-"""`main_train` of the reference (train/CogVideoX-5B/03_train.py:219-288) without Lightning / wandb: dataset ->
-98/2 split (seed 42) -> per-rank shard -> prefetching loader -> DPOEngine steps -> final_lora adapter.  One process per
-GPU (torchrun); rank 0 logs and saves."""
+"""`main_train` of the reference (train/CogVideoX-5B/03_train.py:219-288; train/Wan2.2-TI2V-5B/03_train.py:309-387 is the same loop around
+WanDPOTrainer and the unpaired collate_fn) without Lightning / wandb: dataset -> 98/2 split (seed 42) -> per-rank shard -> prefetching
+loader -> DPOEngine steps -> final_lora adapter.  One process per GPU (torchrun); rank 0 logs and saves."""
 import os
 import time
 from typing import Any, Dict, Optional
@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader, Subset
 
-from .dataset import DPODataset, collate_paired, shard_indices
+from .dataset import DPODataset, collate_fn, collate_paired, shard_indices
 from .loader import PairedPrefetcher
 from .trainer import DEFAULT_CONFIG, CogVideoXDPOTrainer, DPOEngine
 
@@ -58,17 +58,17 @@ def load_checkpoint(engine: DPOEngine, path: str) -> Dict[str, int]:
 
 
 @torch.no_grad()
-def validate(trainer, dataset, val_idx, cfg, rank=0, world=1) -> Dict[str, float]:
+def validate(trainer, dataset, val_idx, cfg, rank=0, world=1, collate=collate_paired) -> Dict[str, float]:
     """validation_step over the 2 % split (train/CogVideoX-5B/03_train.py:190-206), mean over pairs and ranks."""
     local = val_idx[rank::world]
     acc = torch.zeros(4, dtype=torch.float64, device="cuda")
     if local:
-        loader = DataLoader(Subset(dataset, local), batch_size=cfg["batch_size"], shuffle=False, num_workers=0, collate_fn=collate_paired)
+        loader = DataLoader(Subset(dataset, local), batch_size=cfg["batch_size"], shuffle=False, num_workers=0, collate_fn=collate)
         was = trainer.training
         trainer.eval()
         for batch in PairedPrefetcher(loader):
             out = trainer.validation_step(batch)
-            b = batch["x_pair"].shape[0]
+            b = (batch["x_pair"] if "x_pair" in batch else batch["x_win"]).shape[0]
             acc += torch.stack([out["val/loss"].double() * b, out["val/reward_margin"].double() * b,
                                 out["val/reward_accuracy"].double() * b, torch.tensor(float(b), dtype=torch.float64, device="cuda")])
         trainer.train(was)
@@ -79,9 +79,17 @@ def validate(trainer, dataset, val_idx, cfg, rank=0, world=1) -> Dict[str, float
     return {"val/loss": a[0] / n, "val/reward_margin": a[1] / n, "val/reward_accuracy": a[2] / n}
 
 
-def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] = None, log=print, image_encoder=None) -> CogVideoXDPOTrainer:
+def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] = None, log=print, image_encoder=None, model: str = "cogvideox"):
+    """model = "cogvideox" (CogVideoXDPOTrainer over the paired [B,2,F,C,H,W] layout) or "wan" (WanDPOTrainer over the reference's own batch keys
+    x_win / x_lose [B,C,F,H,W], prompt_emb, image_latent: train/Wan2.2-TI2V-5B/03_train.py:309-387)."""
+    if model not in ("cogvideox", "wan"):
+        raise ValueError(f"fit: model must be 'cogvideox' or 'wan', got {model!r}")
     cfg = dict(DEFAULT_CONFIG)
+    if model == "wan":
+        from .wan import DEFAULT_CONFIG as WAN_DEFAULTS, WanDPOTrainer
+        cfg.update(WAN_DEFAULTS)
     cfg.update(config)
+    collate = collate_paired if model == "cogvideox" else collate_fn
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     if dataset is None:
@@ -95,7 +103,12 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
     n_train = int(0.98 * n) if n > 1 else n
     train_idx = perm[:n_train] or perm
     val_idx = perm[n_train:]
-    trainer = CogVideoXDPOTrainer(cfg, transformer=transformer, image_encoder=image_encoder).cuda()
+    if model == "wan":
+        if transformer is None:
+            raise ValueError("fit(model='wan') needs the denoiser (videogpa_amd.wan_model.WanModel or a module with its call convention)")
+        trainer = WanDPOTrainer(cfg, transformer).cuda()
+    else:
+        trainer = CogVideoXDPOTrainer(cfg, transformer=transformer, image_encoder=image_encoder).cuda()
     trainer.train()
     engine = DPOEngine(trainer)
     pos = {"epoch": 0, "batch": 0}
@@ -110,7 +123,7 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
         local = [train_idx[i] for i in shard_indices(len(train_idx), rank, world, epoch=epoch)]
         local = local[skip * cfg["batch_size"]:]                    # a resumed run continues inside the epoch it was in
         loader = DataLoader(Subset(dataset, local), batch_size=cfg["batch_size"], shuffle=False, num_workers=cfg.get("num_workers", 4),
-                            collate_fn=collate_paired, drop_last=False)
+                            collate_fn=collate, drop_last=False)
         batch_in_epoch = skip
         skip = 0
         for batch in PairedPrefetcher(loader):
@@ -127,7 +140,7 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
                     f"lr {logs['lr']:.3e} samples/s {sps:.3f} max_mem {torch.cuda.max_memory_reserved() / 2 ** 30:.1f} GB")
             if "lr" in logs and every > 0 and trainer.global_step % every == 0 and trainer.global_step != last_ckpt:
                 last_ckpt = trainer.global_step
-                val = validate(trainer, dataset, val_idx, cfg, rank, world) if val_idx else None
+                val = validate(trainer, dataset, val_idx, cfg, rank, world, collate) if val_idx else None
                 ckpt_dir = os.path.join(cfg["output_dir"], "checkpoints", f"step={trainer.global_step}") if cfg.get("output_dir") else None
                 if rank == 0:
                     if val is not None:
