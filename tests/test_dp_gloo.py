@@ -251,3 +251,49 @@ def test_overlapped_optimizer_step_is_bit_identical_to_the_immediate_one(tmp_pat
     for rank in range(world):
         a, b = torch.load(tmp_path / f"ov{rank}.pt"), torch.load(tmp_path / f"im{rank}.pt")
         assert torch.equal(a["param"], b["param"]) and torch.equal(a["synced"], b["synced"]) and torch.equal(a["lrs"], b["lrs"])
+
+
+# ---------------------------------------------------------------- the after_reference hook protocol (single process, overlap forced on)
+class _HookTrainer(_FakeTrainer):
+    """A trainer that CARRIES the `after_reference` attribute (like CogVideoXDPOTrainer / WanDPOTrainer).  mode "calls": training_step calls the
+    hook between its (pretend) reference pass and its policy forward; "never": it never does; "stops": it calls it on the first two micro-steps only."""
+
+    def __init__(self, accumulate, mode):
+        super().__init__(accumulate)
+        self.after_reference = None
+        self.mode, self.calls = mode, 0
+
+    def training_step(self, batch, idx=0):
+        self.calls += 1
+        if self.after_reference is not None and (self.mode == "calls" or (self.mode == "stops" and self.calls <= 2)):
+            self.after_reference()
+        return super().training_step(batch, idx)         # the policy forward reads the parameters only here
+
+
+def _run_engine(mode, overlap, steps=6):
+    import pytest  # noqa: F401
+    from videogpa_amd.trainer import DPOEngine
+    os.environ.pop("RANK", None)
+    tr = _HookTrainer(1, mode) if mode else _FakeTrainer(1)
+    eng = DPOEngine(tr, overlap=overlap)
+    data = _data(8)
+    for i in range(steps):
+        eng.micro_step(data[i:i + 1])
+    eng.flush()
+    return eng.opt.flat.flat.clone(), tr, eng
+
+
+def test_engine_never_steps_between_a_policy_forward_and_its_backward():
+    """with a trainer that has `after_reference` but never calls it, the old engine applied the pending update AFTER the policy forward
+    and BEFORE backward (new A / B against old activations).  Now: a trainer that never calls the hook is detected on the first micro-step (nothing
+    is pending yet) and the engine falls back to stepping BEFORE each forward -- bit-identical to the immediate engine; a trainer that stops calling
+    the hook while a step is pending is an error, not a silent mis-step."""
+    import pytest
+    want, _, _ = _run_engine(None, overlap=False)
+    for mode in ("calls", "never"):
+        got, tr, eng = _run_engine(mode, overlap=True)
+        assert torch.equal(got, want), mode
+        assert eng._hooked == (mode == "calls") and tr.global_step == 6
+        assert (tr.after_reference is None) == (mode == "never")
+    with pytest.raises(RuntimeError, match="after_reference"):
+        _run_engine("stops", overlap=True)

@@ -63,6 +63,7 @@ def test_video_processor_runs_the_vggt_wrapper_on_device():
 
     def net(images):
         seen["images"] = images
+        seen["autocast"] = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16     # utils/model_utils.py:99-102
         T, h, w = images.shape[1], images.shape[3], images.shape[4]
         pe = torch.zeros(1, T, 9, device=images.device)
         pe[..., 6] = 1.0
@@ -74,3 +75,17 @@ def test_video_processor_runs_the_vggt_wrapper_on_device():
     assert np.array_equal(seen["images"].cpu().numpy(), pp.preprocess_images_from_numpy(frames))
     assert preds["images"].shape == (3, 3, 294, 518) and preds["pose_enc"].shape == (3, 9) and preds["depth_conf"].shape == (3, 294, 518)
     assert preds["world_points_from_depth"] is preds["world_points"]
+    assert seen["autocast"] and preds["extrinsic"].shape == (3, 3, 4) and preds["intrinsic"].shape == (3, 3, 3)    # decoded before the squeeze (:104-106)
+
+    class Net(torch.nn.Module):                      # a real module is moved to the device and put in eval mode (:92)
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, images):
+            seen["mode"] = (self.training, self.w.device.type)
+            return net(images)
+
+    m = Net().train()
+    VideoProcessor(metrics={}, backbone="vggt", vggt_model=m).backbone_fn(frames)
+    assert seen["mode"] == (False, "cuda")

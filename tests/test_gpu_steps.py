@@ -162,7 +162,10 @@ class _ToyWan(nn.Module):
         return outs
 
 
-def test_wan_ti2v_step_logic_matches_oracle():
+@pytest.mark.parametrize("latent_dtype", [torch.bfloat16, torch.float32])
+def test_wan_ti2v_step_logic_matches_oracle(latent_dtype):
+    """latents as stored by the dataset: bf16, or fp32 (the reference's encoded Wan latents; every squared error is then formed from fp32
+    values, train/Wan2.2-TI2V-5B/03_train.py:236-242 with train/loss.py:73-77)"""
     from videogpa_amd.wan import WanDPOTrainer, ti2v_timestep_tensor
     from videogpa_amd.lora import LoraConfig, get_peft_model
     B, C, Fr, H, W = 2, 8, 3, 8, 12
@@ -182,8 +185,9 @@ def test_wan_ti2v_step_logic_matches_oracle():
     il = (0.7 * torch.randn(B, C, 1, H, W, generator=g)).to(torch.bfloat16)
     t = torch.tensor([417, 999])
     eps = torch.randn(B, C, Fr, H, W, generator=g).to(torch.bfloat16)
-    out = tr._shared_step({"x_win": xw.cuda(), "x_lose": xl.cuda(), "prompt_emb": txt.cuda(), "image_latent": il.cuda()},
-                          timesteps=t.cuda(), noise=eps.cuda())
+    ld = latent_dtype
+    out = tr._shared_step({"x_win": xw.to(ld).cuda(), "x_lose": xl.to(ld).cuda(), "prompt_emb": txt.cuda(), "image_latent": il.to(ld).cuda()},
+                          timesteps=t.cuda(), noise=eps.to(ld).cuda())
     out.loss.backward()
     # oracle: the same toy model in fp64 on the CPU, adapter on / off, through oracle.steps.wan_pair_step
     import copy

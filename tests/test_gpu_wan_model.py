@@ -106,6 +106,25 @@ def test_wan_model_reference_pass_and_scalar_timestep():
         pm(x, t=t, context=ctx, seq_len=L + 8)
 
 
+def test_wan_from_pretrained_gives_the_identical_forward(tmp_path):
+    """train/Wan2.2-TI2V-5B/03_train.py:140-141: `WanModel.from_pretrained(path)` then `.to(torch.bfloat16)`.  A random model saved in the upstream
+    layout (sharded) and loaded back runs the bit-identical forward on the HIP path."""
+    from videogpa_amd.wan_model import WanModel
+    torch.manual_seed(4)
+    m = WanModel(**CFG)
+    with torch.no_grad():
+        torch.nn.init.normal_(m.head.head.weight, std=0.05)
+    m.to(torch.bfloat16).save_pretrained(str(tmp_path), max_shard_size=300_000)
+    a = m.to("cuda")
+    b = WanModel.from_pretrained(str(tmp_path))
+    b.to(torch.bfloat16)
+    b = b.to("cuda")
+    x, t, ctx, L, _ = _inputs()
+    with torch.no_grad():
+        oa, ob = a(x, t=t, context=ctx, seq_len=L), b(x, t=t, context=ctx, seq_len=L)
+    assert all(torch.equal(u, v) and torch.isfinite(u).all() for u, v in zip(oa, ob)) and oa[0].abs().max() > 0
+
+
 def test_wan_dpo_trainer_step_runs_on_the_hip_model():
     """WanDPOTrainer (train/Wan2.2-TI2V-5B/03_train.py:130-242) driving the HIP WanModel: one pair step, finite loss, every LoRA B gets a gradient"""
     from videogpa_amd.wan import WanDPOTrainer

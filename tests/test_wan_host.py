@@ -91,3 +91,40 @@ def test_oracle_known_answers():
     o_short = ow.forward(P, dict(CFG), x, torch.tensor([500.0]), [c5], 12)[0]
     o_pad = ow.forward(P, dict(CFG), x, torch.tensor([500.0]), [torch.cat([c5, torch.zeros(3, 12, dtype=torch.float64)])], 12)[0]
     assert torch.equal(o_short, o_pad)
+
+
+def test_from_pretrained_reads_the_upstream_checkpoint_layout(tmp_path):
+    """train/Wan2.2-TI2V-5B/03_train.py:140,166 build policy and reference with `WanModel.from_pretrained(config['model_path'])`: config.json +
+    diffusion_pytorch_model.safetensors, or indexed shards.  Round trip of a random model through both layouts: same config, bit-identical parameters,
+    strict names; unknown config keys and a missing directory are errors."""
+    import json
+    import os
+    import pytest
+    from videogpa_amd.wan_model import WanModel
+    m = _model()
+    with torch.no_grad():
+        m.head.head.weight.normal_(std=0.05)
+    m = m.to(torch.bfloat16)
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    m.save_pretrained(one)
+    m.save_pretrained(many, max_shard_size=40_000)
+    assert sorted(os.listdir(one)) == ["config.json", "diffusion_pytorch_model.safetensors"]
+    shards = [f for f in os.listdir(many) if f.endswith(".safetensors")]
+    assert len(shards) > 2 and "diffusion_pytorch_model.safetensors.index.json" in os.listdir(many)
+    cfg = json.load(open(os.path.join(one, "config.json")))
+    assert cfg["_class_name"] == "WanModel" and cfg["dim"] == 128 and cfg["patch_size"] == [1, 2, 2]
+    want = m.state_dict()
+    for path in (one, many):
+        got = WanModel.from_pretrained(path)
+        assert not got.training and dict(got.config) == dict(m.config) and got.config.num_layers == 2
+        sd = got.state_dict()
+        assert sd.keys() == want.keys()
+        assert all(sd[k].dtype == torch.bfloat16 and sd[k].device.type == "cpu" and torch.equal(sd[k], want[k]) for k in want)
+    f32 = WanModel.from_pretrained(one, torch_dtype=torch.float32)
+    assert all(v.dtype == torch.float32 for v in f32.state_dict().values())
+    cfg["rope_scaling"] = 2
+    json.dump(cfg, open(os.path.join(one, "config.json"), "w"))
+    with pytest.raises(ValueError):
+        WanModel.from_pretrained(one)
+    with pytest.raises(FileNotFoundError):
+        WanModel.from_pretrained(str(tmp_path / "nowhere"))

@@ -57,20 +57,40 @@ def load_checkpoint(engine: DPOEngine, path: str) -> Dict[str, int]:
     return {"epoch": int(pos.get("epoch", 0)), "batch": int(pos.get("batch", 0))}
 
 
+def _prune_top_k(kept, k):
+    """ModelCheckpoint(save_top_k=k, monitor='val/loss', mode='min'): keep the k best checkpoints (k < 0: all), delete the others' directories.
+    The most recent one is never deleted by a tie; other ranks' rng files live in the same directory and go with it."""
+    import shutil
+    if k < 0 or len(kept) <= k:
+        return
+    kept.sort(key=lambda e: (e[0], -e[1]))
+    for _, _, d in kept[k:]:
+        shutil.rmtree(d, ignore_errors=True)
+    del kept[k:]
+
+
 @torch.no_grad()
 def validate(trainer, dataset, val_idx, cfg, rank=0, world=1, collate=collate_paired) -> Dict[str, float]:
-    """validation_step over the 2 % split (train/CogVideoX-5B/03_train.py:190-206), mean over pairs and ranks."""
-    local = val_idx[rank::world]
+    """validation_step over the 2 % split, as the reference runs it (train/CogVideoX-5B/03_train.py:190-206,252,261): batch size 1, at most
+    `limit_val_batches` = 50 batches per rank, mean over pairs and ranks.  The (t, eps) draws of validation come from their OWN generator, re-seeded
+    identically at every call (seed 10 007 + rank): the training noise stream is untouched by when / how often validation runs, and the validation
+    loss of successive checkpoints is measured on the same noise, so it is comparable (Lightning's validation consumes the global generator instead)."""
+    local = val_idx[rank::world][: int(cfg.get("limit_val_batches", 50))]
     acc = torch.zeros(4, dtype=torch.float64, device="cuda")
     if local:
-        loader = DataLoader(Subset(dataset, local), batch_size=cfg["batch_size"], shuffle=False, num_workers=0, collate_fn=collate)
+        loader = DataLoader(Subset(dataset, local), batch_size=1, shuffle=False, num_workers=0, collate_fn=collate)
         was = trainer.training
         trainer.eval()
-        for batch in PairedPrefetcher(loader):
-            out = trainer.validation_step(batch)
-            b = (batch["x_pair"] if "x_pair" in batch else batch["x_win"]).shape[0]
-            acc += torch.stack([out["val/loss"].double() * b, out["val/reward_margin"].double() * b,
-                                out["val/reward_accuracy"].double() * b, torch.tensor(float(b), dtype=torch.float64, device="cuda")])
+        keep = getattr(trainer, "_rng", None)
+        trainer._rng = torch.Generator(device=next(trainer.parameters()).device).manual_seed(10007 + rank)   # the device trainer.rng() compares with
+        try:
+            for batch in PairedPrefetcher(loader):
+                out = trainer.validation_step(batch)
+                b = (batch["x_pair"] if "x_pair" in batch else batch["x_win"]).shape[0]
+                acc += torch.stack([out["val/loss"].double() * b, out["val/reward_margin"].double() * b,
+                                    out["val/reward_accuracy"].double() * b, torch.tensor(float(b), dtype=torch.float64, device="cuda")])
+        finally:
+            trainer._rng = keep
         trainer.train(was)
     if dist.is_initialized() and world > 1:
         dist.all_reduce(acc)
@@ -119,6 +139,7 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
     epoch, skip = pos["epoch"], pos["batch"]
     t0, start_step = time.time(), trainer.global_step
     last_ckpt = trainer.global_step
+    kept = []           # (val/loss, step, dir) of the checkpoints on disk: ModelCheckpoint(monitor="val/loss", mode="min", save_top_k), 03_train.py:268-275
     while trainer.global_step < step_target:
         local = [train_idx[i] for i in shard_indices(len(train_idx), rank, world, epoch=epoch)]
         local = local[skip * cfg["batch_size"]:]                    # a resumed run continues inside the epoch it was in
@@ -147,6 +168,8 @@ def fit(config: Dict[str, Any], transformer=None, dataset: Optional[DPODataset] 
                         log(f"step {trainer.global_step}: " + " ".join(f"{k} {v:.6f}" for k, v in val.items()))
                     if ckpt_dir:
                         save_checkpoint(engine, ckpt_dir, val, position={"epoch": epoch, "batch": batch_in_epoch})
+                        kept.append((val["val/loss"] if val is not None else float("inf"), trainer.global_step, ckpt_dir))
+                        _prune_top_k(kept, int(cfg.get("save_top_k", 10)))
                 elif ckpt_dir:
                     save_rng_state(engine, ckpt_dir)
             if trainer.global_step >= step_target:

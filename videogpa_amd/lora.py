@@ -128,7 +128,7 @@ class LoraLinear(nn.Module):
         """peft.tuners.lora.layer.Linear.forward.  On the GPU in bf16 (the training path, e.g. the q/k/v/o linears of a Wan
         model wrapped by get_peft_model) the base product goes to hipBLASLt and the A / B contractions to the MFMA kernels of
         csrc/lora.hip through ops.linear_lora; the torch expression below only serves host-side use (CPU adapter-format and
-        merge checks, fp32 tensors)."""
+        merge checks on CPU tensors).  A GPU tensor that is not bf16 raises: nothing on the device runs through torch eager."""
         lora = self.active_lora()
         if x.is_cuda and x.dtype == torch.bfloat16 and self.base_layer.weight.dtype == torch.bfloat16:
             from . import ops
@@ -142,6 +142,9 @@ class LoraLinear(nn.Module):
             # share the base partial sums bit for bit (ops.LoraExt)
             return ops.linear_lora_ext(x, W, b, self._ext, [(self.lora_A[n].weight, self.lora_B[n].weight, self.scaling[n])],
                                        enabled=not self.disable_adapters)
+        if x.is_cuda:
+            raise RuntimeError(f"videogpa_amd LoraLinear: the GPU path computes in bf16 (got activations {x.dtype}, base weight "
+                               f"{self.base_layer.weight.dtype}); cast the model and its inputs to torch.bfloat16 -- there is no eager GPU fallback")
         y = F.linear(x, self.base_layer.weight, self.base_layer.bias)
         if lora is not None:
             A, B, s = lora

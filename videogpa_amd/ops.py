@@ -667,7 +667,7 @@ def frozen_linear_fp8(x, W, bias):
 class _LinearLoraExtFn(torch.autograd.Function):
     """y = x W^T + b (+ LoRA when `enabled`), W / b frozen; see LoraExt.  x / dy are used in place when they are the heads of
     padded buffers (produced by ops.residual_ln / qknorm_attention with n_pad / o_pad / grad pads), copied into one otherwise.
-    x_recompute: a callable that returns x [M, K] again (bit-identical) in the backward; the forward then keeps only the [M, R] LoRA
+    x_recompute: (fn, tensors) with fn(*tensors) returning x [M, K] again (bit-identical) in the backward; the forward then keeps only the [M, R] LoRA
     down-projections instead of the whole [M, K + R] operand ("lean activations": x is a cheap function of a tensor that is saved anyway)."""
 
     @staticmethod
@@ -685,8 +685,9 @@ class _LinearLoraExtFn(torch.autograd.Function):
         # disabled (reference pass): the tail of a `_padded_empty` buffer is zero since its allocation
         y = _gemm(x_ext, ext.W_ext, bias)
         if x_recompute is not None and enabled:
-            ctx.save_for_backward(tv.contiguous())
-            ctx.x_fn = x_recompute
+            fn, srcs = x_recompute
+            ctx.save_for_backward(tv.contiguous(), *srcs)     # the recompute sources go through autograd's saved-tensor checks (in-place version, lifetime)
+            ctx.x_fn = fn
         else:
             ctx.save_for_backward(x_ext)
             ctx.x_fn = None
@@ -696,7 +697,7 @@ class _LinearLoraExtFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         ext, enabled = ctx.ext, ctx.enabled
-        (saved,) = ctx.saved_tensors
+        saved, *srcs = ctx.saved_tensors
         K, R, N, Dn, rp, r, act = ext.K, ext.R, ext.N, ext.Dn, ext.rp, ext.r, ext.act
         dy2 = dy.reshape(-1, N)
         M = dy2.shape[0]
@@ -711,7 +712,7 @@ class _LinearLoraExtFn(torch.autograd.Function):
         out_grads = [None] * len(ctx.needs_input_grad[6:])
         if enabled:
             if ctx.x_fn is not None:
-                t_all, xh = saved, ctx.x_fn().reshape(M, K)          # [M, R] kept, x made again
+                t_all, xh = saved, ctx.x_fn(*srcs).reshape(M, K)     # [M, R] kept, x made again
             else:
                 t_all, xh = saved[:, K:], saved[:, :K]
             for j, i in enumerate(act):

@@ -68,12 +68,20 @@ class VideoProcessor:
         return self.frame_sampler(video_path, num_frames)
 
     def _run_vggt(self, model, frames):
-        """utils/model_utils.py:89-122 around the external network: preprocess on the device (:98), forward, drop the batch axis (:111-116)"""
+        """utils/model_utils.py:86-122 around the external network, step for step: the model is moved to the device and put in eval mode (:92),
+        frames are preprocessed on the device (:94), the forward runs under no_grad + bf16 autocast (:99-102), the camera head's `pose_enc` is decoded
+        into extrinsic / intrinsic BEFORE the batch axis is dropped (:104-106, on the device: scorer.pose_encoding_to_extri_intri), then every
+        [1, ...] tensor is squeezed (:108-111)"""
         from .model_utils import prepare_inputs
+        dev = torch.device(self.device)
+        if hasattr(model, "to") and hasattr(model, "eval"):
+            model = model.to(dev).eval()
         images = prepare_inputs(np.asarray(frames) if not torch.is_tensor(frames) else frames, device=self.device)
-        with torch.no_grad():
+        with torch.no_grad(), torch.autocast(dev.type, dtype=torch.bfloat16, enabled=dev.type == "cuda"):
             preds = dict(model(images))
         preds["images"] = images
+        if "pose_enc" in preds and "extrinsic" not in preds:
+            preds["extrinsic"], preds["intrinsic"] = scorer.pose_encoding_to_extri_intri(preds["pose_enc"].float(), tuple(images.shape[-2:]))
         preds = {k: (v.squeeze(0) if torch.is_tensor(v) and v.ndim > 0 and v.shape[0] == 1 else v) for k, v in preds.items()}
         if "world_points" in preds:       # :116-117
             preds["world_points_from_depth"] = preds["world_points"]

@@ -293,8 +293,13 @@ class DPOEngine:
         self.last = {}                    # lr / rank-mean scalars of the most recently applied optimizer step
         self._fresh = False
         self._hooked = self.overlap and hasattr(trainer, "after_reference")
+        self._hook_seen = False
         if self._hooked:
-            trainer.after_reference = self._finish
+            trainer.after_reference = self._from_hook
+
+    def _from_hook(self):
+        self._hook_seen = True
+        self._finish()
 
     def _finish(self):
         if self._pending is None:
@@ -317,8 +322,19 @@ class DPOEngine:
     def micro_step(self, batch) -> Dict[str, Any]:
         if not self._hooked:
             self._finish()                                               # a trainer without the hook: the step lands before its forward
+        self._hook_seen = False
         loss, logs = self.trainer.training_step(batch, self.micro)      # hooked: a pending step is applied after the reference pass
-        self._finish()                                                   # (a training_step that never reached the hook)
+        if self._hooked and not self._hook_seen:
+            # The trainer carries `after_reference` but its training_step never called it.  The policy forward above has then run on the
+            # adapters as they are; applying a pending update NOW (between that forward and its backward) would pair new A / B with old
+            # activations -- silently wrong gradients.  So: never step here.  With nothing pending this is harmless and the engine simply
+            # stops relying on the hook; with a step pending the forward already used stale adapters, which cannot be repaired.
+            if self._pending is not None:
+                raise RuntimeError("DPOEngine: an optimizer step is pending but trainer.training_step() did not call "
+                                   "trainer.after_reference() between its reference and policy passes; construct the engine with "
+                                   "overlap=False for this trainer (or call the hook)")
+            self._hooked = False
+            self.trainer.after_reference = None
         (loss / self.accum).backward()
         # the three scalars the reference logs with sync_dist=True (train/CogVideoX-5B/03_train.py:164-173) go into the tail
         # of the gradient buffer and are reduced by the SAME all-reduce: no extra collective, no host sync

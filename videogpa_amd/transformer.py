@@ -224,7 +224,7 @@ class AttentionCore:
             fn = None
             if lean_src is not None:
                 xs, lw, lb, lmod, leps = lean_src
-                fn = lambda: ops.ln_modulate_recompute(xs, lw, lb, lmod, text_len, leps)
+                fn = (lambda xs_, lw_, lb_, lmod_: ops.ln_modulate_recompute(xs_, lw_, lb_, lmod_, text_len, leps), (xs, lw, lb, lmod))
             qkv = ops.linear_lora_ext(n, W, b, self._qkv_ext, qa, enabled=on, x_recompute=fn)
         else:
             qkv = ops.frozen_linear(n, W, b)

@@ -124,11 +124,14 @@ class WanDPOTrainer(nn.Module):
             if self.after_reference is not None:
                 self.after_reference()
             v_w, v_l = torch.stack(self.transformer(xw_in, **kw)), torch.stack(self.transformer(xl_in, **kw))
-        v_pol = torch.stack([v_w, v_l], dim=1).to(x_win.dtype).contiguous()
-        v_ref = torch.stack([v_wr, v_lr], dim=1).to(x_win.dtype).contiguous()
+        # WanModel returns fp32 (`[u.float() for u in x]` upstream) and the reference forms (pred - target) with an fp32 pred, so every squared error of
+        # train/loss.py:73-77 is an fp32 quantity whatever the latents' stored dtype (a bf16 target promotes exactly): predictions stay fp32 here, the
+        # velocity target is widened, and nothing is rounded before the square (round_diff is the CogVideoX bf16-prediction rule only)
+        v_pol = torch.stack([v_w, v_l], dim=1).float().contiguous()
+        v_ref = torch.stack([v_wr, v_lr], dim=1).float().contiguous()
         lf = self.loss_fn
-        loss, margin, wr, lr, acc, _ = ops.dpo_loss_paired(v_pol, v_ref, vt_pair, beta=lf.beta, label_smoothing=lf.label_smoothing,
-                                                            loss_type=lf.loss_type, round_diff=(v_pol.dtype == torch.bfloat16))
+        loss, margin, wr, lr, acc, _ = ops.dpo_loss_paired(v_pol, v_ref, vt_pair.float(), beta=lf.beta, label_smoothing=lf.label_smoothing,
+                                                            loss_type=lf.loss_type, round_diff=False)
         return LossOutput(loss=loss, reward_margin=margin.detach(), winner_reward=wr.detach(), loser_reward=lr.detach(), accuracy=acc.detach())
 
     def training_step(self, batch, batch_idx=0):

@@ -23,7 +23,9 @@ MI355X-first choices (everything else is the upstream arithmetic):
 Call convention as upstream:  model(list of [C,F,H,W], t=[B] or [B, seq_len], context=list of [n, text_dim], seq_len=int) -> list of
 [C_out,F,H,W] fp32.  All samples of a call must share one latent shape (the reference's batches do), and seq_len must equal the token
 count (it does: 03_train.py:176-179 computes it from the latent)."""
+import json
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -455,6 +457,11 @@ class WanModel(nn.Module):
         assert model_type in ("t2v", "i2v", "ti2v", "s2v")
         self.model_type, self.patch_size, self.text_len, self.in_dim, self.dim, self.ffn_dim = model_type, tuple(patch_size), text_len, in_dim, dim, ffn_dim
         self.freq_dim, self.text_dim, self.out_dim, self.num_heads, self.num_layers, self.eps = freq_dim, text_dim, out_dim, num_heads, num_layers, eps
+        # ConfigMixin's `model.config`: the registered constructor arguments (attribute and item access)
+        from .transformer import _Config
+        self.config = _Config(model_type=model_type, patch_size=list(patch_size), text_len=text_len, in_dim=in_dim, dim=dim, ffn_dim=ffn_dim, freq_dim=freq_dim,
+                              text_dim=text_dim, out_dim=out_dim, num_heads=num_heads, num_layers=num_layers, window_size=list(window_size), qk_norm=qk_norm,
+                              cross_attn_norm=cross_attn_norm, eps=eps)
         self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=self.patch_size, stride=self.patch_size)
         self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
         self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
@@ -465,6 +472,96 @@ class WanModel(nn.Module):
         self.checkpoint_stride = 1
         self._rope = {}
         self.init_weights()
+
+    # ------------------------------------------------------------------ upstream (diffusers ModelMixin / ConfigMixin) loading protocol
+    config_name = "config.json"
+    weights_name = "diffusion_pytorch_model.safetensors"
+    _CONFIG_KEYS = ("model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "text_dim", "out_dim", "num_heads",
+                    "num_layers", "window_size", "qk_norm", "cross_attn_norm", "eps")
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        cfg = {k: v for k, v in dict(config).items() if k in cls._CONFIG_KEYS}
+        cfg.update(kw)
+        for k in ("patch_size", "window_size"):
+            if k in cfg:
+                cfg[k] = tuple(cfg[k])
+        return cls(**cfg)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **kw):
+        """`WanModel.from_pretrained(config['model_path'])` -- how the reference builds policy AND reference model
+        (train/Wan2.2-TI2V-5B/03_train.py:140,166; generate/Wan2.2-TI2V-5B.py).  Upstream WanModel is a diffusers ModelMixin with
+        @register_to_config, so a checkpoint directory holds `config.json` (the constructor arguments + `_class_name` / `_diffusers_version`)
+        and the weights as `diffusion_pytorch_model.safetensors` or as shards `diffusion_pytorch_model-0000i-of-0000n.safetensors` listed by
+        `diffusion_pytorch_model.safetensors.index.json` (`weight_map`: parameter name -> shard file).  Parameter names are the upstream ones
+        (module docstring), loaded strictly; like diffusers the weights keep their stored dtype unless `torch_dtype` is given.  No hub access:
+        `path` must be a local directory."""
+        from safetensors.torch import load_file
+        root = os.path.join(path, subfolder) if subfolder else path
+        if not os.path.isdir(root):
+            raise FileNotFoundError(f"WanModel.from_pretrained: {root!r} is not a local directory (there is no hub access on this path)")
+        with open(os.path.join(root, cls.config_name)) as f:
+            cfg = json.load(f)
+        unknown = sorted(k for k in cfg if k not in cls._CONFIG_KEYS and not k.startswith("_"))
+        if unknown:
+            raise ValueError(f"WanModel.from_pretrained: config keys this model does not implement: {unknown}")
+        index = os.path.join(root, cls.weights_name + ".index.json")
+        if os.path.isfile(index):
+            with open(index) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+        elif os.path.isfile(os.path.join(root, cls.weights_name)):
+            files = [cls.weights_name]
+        else:
+            files = sorted(f for f in os.listdir(root) if f.endswith(".safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no .safetensors weights under {root}")
+        sd = {}
+        for fn in files:
+            sd.update(load_file(os.path.join(root, fn)))
+        with torch.device("meta"):
+            model = cls.from_config(cfg, **kw)
+        dtypes = {v.dtype for v in sd.values() if v.is_floating_point()}
+        model.load_state_dict(sd, strict=True, assign=True)          # meta skeleton + assign: no second copy of a 5 B-parameter model, no random init
+        model._rope = {}
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        elif len(dtypes) > 1:
+            raise ValueError(f"checkpoint mixes dtypes {sorted(map(str, dtypes))}: pass torch_dtype=")
+        model.eval()                                                  # diffusers' from_pretrained returns the model in eval mode
+        return model
+
+    def save_pretrained(self, path, max_shard_size=None, safe_serialization=True):
+        """the upstream on-disk layout (see from_pretrained); `max_shard_size` bytes (int) splits the weights into indexed shards"""
+        from safetensors.torch import save_file
+        if not safe_serialization:
+            raise NotImplementedError("safetensors only")
+        os.makedirs(path, exist_ok=True)
+        cfg = dict(self.config)
+        cfg["_class_name"] = "WanModel"
+        with open(os.path.join(path, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if max_shard_size is None:
+            save_file(sd, os.path.join(path, self.weights_name))
+            return
+        shards, cur, size = [], {}, 0
+        for k, v in sd.items():
+            b = v.numel() * v.element_size()
+            if cur and size + b > int(max_shard_size):
+                shards.append(cur)
+                cur, size = {}, 0
+            cur[k] = v
+            size += b
+        shards.append(cur)
+        stem = self.weights_name[:-len(".safetensors")]
+        wmap = {}
+        for i, sh in enumerate(shards):
+            fn = f"{stem}-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file(sh, os.path.join(path, fn))
+            wmap.update({k: fn for k in sh})
+        with open(os.path.join(path, self.weights_name + ".index.json"), "w") as f:
+            json.dump({"metadata": {"total_size": sum(v.numel() * v.element_size() for v in sd.values())}, "weight_map": wmap}, f, indent=2)
 
     def init_weights(self):
         """upstream init_weights: xavier on linears, patch embedding, normal(0.02) on the two embedding MLPs, zero output head"""
@@ -502,7 +599,7 @@ class WanModel(nn.Module):
             self._rope = {key: rope_tables(grid, self.dim // self.num_heads, device)}
         return self._rope[key]
 
-    def forward(self, x, t, context, seq_len, y=None):
+    def forward(self, x, t, context, seq_len, y=None, timestep_groups=None):
         if y is not None:
             x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
         xb = torch.stack(list(x))
@@ -517,11 +614,25 @@ class WanModel(nn.Module):
         # patch embedding: Conv3d with kernel = stride = patch  ==  one GEMM over the (c, pt, ph, pw) patch vectors
         patches = xb.view(B, C, f, pt, h, ph, w, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * L, C * pt * ph * pw).to(wdt)
         tok = F.linear(patches, self.patch_embedding.weight.view(self.dim, -1), self.patch_embedding.bias)           # [B*L, dim]
-        # time embedding on the distinct timesteps only
-        if t.dim() == 1:
-            t = t[:, None].expand(B, L)
-        tvals, inv = torch.unique(t.reshape(-1).float(), return_inverse=True)
-        gid = inv.to(torch.int32).contiguous()
+        # time embedding on the distinct timesteps only -- grouped WITHOUT a host round trip (torch.unique would sort and synchronise in every forward):
+        #   t [B]     one group per sample;
+        #   t [B, L]  the TI2V form (03_train.py:119-125,181-187): a sample's tokens carry its first token's value (the clean first latent frame: 0) or
+        #             ONE other value -> groups (2b, 2b + 1), table values (t[b, 0], that other value); checked on the device, asynchronously.
+        #   anything richer: pass timestep_groups=(values [G], gid [B*L] int32).
+        if timestep_groups is not None:
+            tvals, gid = timestep_groups[0].reshape(-1).float(), timestep_groups[1].reshape(-1).to(torch.int32).contiguous()
+        elif t.dim() == 1:
+            tvals = t.reshape(B).float()
+            gid = torch.arange(B, device=dev, dtype=torch.int32)[:, None].expand(B, L).reshape(-1).contiguous()
+        else:
+            tf = t.reshape(B, L).float()
+            first = tf[:, :1]
+            is_other = tf != first
+            other = torch.where(is_other, tf, tf.new_full((), float("-inf"))).amax(dim=1, keepdim=True)
+            other = torch.where(torch.isinf(other), first, other)         # a sample whose tokens all share one value
+            torch._assert_async((~is_other | (tf == other)).all())      # at most two distinct values per sample
+            tvals = torch.cat([first, other], dim=1).reshape(-1)
+            gid = (2 * torch.arange(B, device=dev, dtype=torch.int32)[:, None] + is_other.to(torch.int32)).reshape(-1).contiguous()
         te = self.time_embedding
         e = F.linear(sinusoidal_embedding_1d(self.freq_dim, tvals).float(), te[0].weight.float(), te[0].bias.float())
         e = F.linear(F.silu(e), te[2].weight.float(), te[2].bias.float())                                             # [G, dim]
