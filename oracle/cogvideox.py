@@ -163,7 +163,55 @@ def apply_rotary_emb(x, cos, sin):
     return (x.float() * cos.float() + x_rot * sin.float()).to(x.dtype)
 
 
-def _lora_linear(x, sd, lora, name, lora_scale):
+# ---------------------------------------------------------------------------------------------------------------- activation-rounded mode
+# `round_activations=True` ("rnd" below): the oracle keeps computing in its own precision (fp32 / fp64) but rounds to bf16 EXACTLY the tensors the
+# HIP path stores in bf16, in the forward and -- for their incoming gradients -- in the backward; everything between two such points (GEMM
+# accumulation, LayerNorm statistics, softmax, the loss) stays unrounded, as in the kernels (fp32 accumulators).  The rounding points follow
+# videogpa_amd/transformer.py + ops.py + csrc/{residual_ln,qknorm,lora,attention_w1}.hip:
+#   forward : time / text / patch embeddings and the modulation vectors as torch bf16 makes them (each linear / silu / `1 + scale` result rounded);
+#             LN+modulate output n; LoRA down-projection T = n A^T (A, and s*B, cast to bf16 first); the fused projection output (base + adapter in ONE
+#             fp32 accumulation, one rounding); normalised q (rounded AFTER the scale * log2(e) fold) and k; P where it multiplies V; the attention
+#             output; gate * y and the residual sum (two roundings, csrc/residual_ln.hip); FF pre-activation, GELU output, FF output; norm_final /
+#             norm_out / proj_out outputs; (pred - target) before the square (train/loss.py:73-77 under bf16 autocast).
+#   backward: the gradient of every tensor above is rounded where the HIP path stores it (dy of each GEMM, dT, dq / dk / dv, dS inside attention,
+#             d(qkv) behind the QK-norm backward, dx' of the fused residual+LN backward and gate * dx', dGELU); adapter gradients dA, dB are fp32
+#             results of bf16 operands and are NOT rounded.
+# What such an oracle can and cannot pin is measured in tests/test_gpu_cfg1.py (see its header).
+class _RoundGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+def _rv(x):
+    """value rounded to bf16, gradient passed straight through (weights cast to the activation dtype: their fp32 gradients are not rounded)"""
+    return x + (x.detach().bfloat16().to(x.dtype) - x.detach())
+
+
+def _rg(x):
+    """identity whose incoming gradient is rounded to bf16"""
+    return _RoundGrad.apply(x) if x.requires_grad else x
+
+
+def _r(x, on=True):
+    """a tensor the HIP path stores in bf16: value and incoming gradient rounded"""
+    return _rg(_rv(x)) if on else x
+
+
+def _lora_linear(x, sd, lora, name, lora_scale, rnd=False):
+    if rnd:
+        # ops.LoraExt: y = [x | T] [W | s B]^T + b in one fp32 accumulation, T = bf16(x A^T), A and s*B as bf16 copies of the fp32 adapters
+        y = F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+        ka = "base_model.model." + name + ".lora_A.weight"
+        if lora is not None and ka in lora:
+            A = _rv(lora[ka].to(x.dtype))
+            sB = _rv(_rv(lora["base_model.model." + name + ".lora_B.weight"].to(x.dtype)) * lora_scale)
+            y = y + F.linear(_r(F.linear(x, A)), sB)
+        return _r(y)
     y = F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
     if lora is not None:
         ka = "base_model.model." + name + ".lora_A.weight"
@@ -178,7 +226,13 @@ def layer_norm(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def patch_embed(sd, cfg, text, video):
+def patch_embed(sd, cfg, text, video, rnd=False):
+    if rnd:
+        emb = patch_embed(sd, cfg, text, video)          # each of the two projections is one bf16 GEMM; the positional table is added in bf16
+        if cfg.use_learned_positional_embeddings:
+            pos = sd["patch_embed.pos_embedding"][:, : emb.shape[1]].to(emb.dtype)
+            return _r(_r(emb - pos) + pos)
+        return _r(emb)
     B, Fr, C, H, W = video.shape
     p = cfg.patch_size
     text = F.linear(text, sd["patch_embed.text_proj.weight"], sd["patch_embed.text_proj.bias"])
@@ -233,25 +287,29 @@ class _RoundedSDPA(torch.autograd.Function):
         return dq, dk, dv
 
 
-def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_rotary_emb=None, capture=None, round_p_ds=False):
+def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_rotary_emb=None, capture=None, round_p_ds=False, rnd=False):
     b = f"transformer_blocks.{i}."
     Lt = enc.shape[1]
     H, hd = cfg.num_attention_heads, cfg.attention_head_dim
     B = hid.shape[0]
 
     def ln_zero(name, hid, enc):
-        m = F.linear(F.silu(temb), sd[b + name + ".linear.weight"], sd[b + name + ".linear.bias"])
+        m = _r(F.linear(_r(F.silu(temb), rnd), sd[b + name + ".linear.weight"], sd[b + name + ".linear.bias"]), rnd)
         shift, scale, gate, e_shift, e_scale, e_gate = m.chunk(6, dim=1)
         nw, nb = sd[b + name + ".norm.weight"], sd[b + name + ".norm.bias"]
-        n_h = layer_norm(hid, nw, nb, cfg.norm_eps) * (1 + scale)[:, None] + shift[:, None]
-        n_e = layer_norm(enc, nw, nb, cfg.norm_eps) * (1 + e_scale)[:, None] + e_shift[:, None]
-        return n_h, n_e, gate[:, None], e_gate[:, None]
+        n_h = layer_norm(hid, nw, nb, cfg.norm_eps) * _r(1 + scale, rnd)[:, None] + shift[:, None]      # `1 + scale` is formed in the model dtype
+        n_e = layer_norm(enc, nw, nb, cfg.norm_eps) * _r(1 + e_scale, rnd)[:, None] + e_shift[:, None]
+        return _r(n_h, rnd), _r(n_e, rnd), gate[:, None], e_gate[:, None]
+
+    def add(x, g, y):
+        # csrc/residual_ln.hip: x' = bf16(x + bf16(gate * y)); backward dx' rounded once, dy = bf16(gate * bf16(dx'))
+        return _r(x + _r(g * y)) if rnd else x + g * y
 
     n_h, n_e, gate, e_gate = ln_zero("norm1", hid, enc)
     x = torch.cat([n_e, n_h], dim=1)
-    q = _lora_linear(x, sd, lora, b + "attn1.to_q", lora_scale)
-    k = _lora_linear(x, sd, lora, b + "attn1.to_k", lora_scale)
-    v = _lora_linear(x, sd, lora, b + "attn1.to_v", lora_scale)
+    q = _lora_linear(x, sd, lora, b + "attn1.to_q", lora_scale, rnd)
+    k = _lora_linear(x, sd, lora, b + "attn1.to_k", lora_scale, rnd)
+    v = _lora_linear(x, sd, lora, b + "attn1.to_v", lora_scale, rnd)
     q, k, v = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
     q = layer_norm(q, sd[b + "attn1.norm_q.weight"], sd[b + "attn1.norm_q.bias"], cfg.qk_norm_eps)
     k = layer_norm(k, sd[b + "attn1.norm_k.weight"], sd[b + "attn1.norm_k.bias"], cfg.qk_norm_eps)
@@ -259,45 +317,51 @@ def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_r
         cos, sin = image_rotary_emb
         q = torch.cat([q[:, :, :Lt], apply_rotary_emb(q[:, :, Lt:], cos, sin)], dim=2)
         k = torch.cat([k[:, :, :Lt], apply_rotary_emb(k[:, :, Lt:], cos, sin)], dim=2)
-    o = _RoundedSDPA.apply(q, k, v) if round_p_ds else F.scaled_dot_product_attention(q, k, v)
-    o = o.transpose(1, 2).reshape(B, -1, H * hd)
+    if rnd:
+        # csrc/qknorm.hip folds scale * log2(e) into q before its one rounding; the attention kernels return dq for the UNSCALED q, as bf16
+        c = hd ** -0.5 * 1.4426950408889634
+        q, k = _rg(_rv(q * c) / c), _r(k)
+    o = _RoundedSDPA.apply(q, k, v) if (round_p_ds or rnd) else F.scaled_dot_product_attention(q, k, v)
+    o = _r(o.transpose(1, 2).reshape(B, -1, H * hd), rnd)
     if capture is not None:
         capture.update(q=q, k=k, v=v, attn=o)
-    o = _lora_linear(o, sd, lora, b + "attn1.to_out.0", lora_scale)
-    hid = hid + gate * o[:, Lt:]
-    enc = enc + e_gate * o[:, :Lt]
+    o = _lora_linear(o, sd, lora, b + "attn1.to_out.0", lora_scale, rnd)
+    hid = add(hid, gate, o[:, Lt:])
+    enc = add(enc, e_gate, o[:, :Lt])
 
     n_h, n_e, gate, e_gate = ln_zero("norm2", hid, enc)
     x = torch.cat([n_e, n_h], dim=1)
-    x = F.gelu(F.linear(x, sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"]), approximate="tanh")
-    x = F.linear(x, sd[b + "ff.net.2.weight"], sd[b + "ff.net.2.bias"])
-    hid = hid + gate * x[:, Lt:]
-    enc = enc + e_gate * x[:, :Lt]
+    x = _r(F.gelu(_r(F.linear(x, sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"]), rnd), approximate="tanh"), rnd)
+    x = _r(F.linear(x, sd[b + "ff.net.2.weight"], sd[b + "ff.net.2.bias"]), rnd)
+    hid = add(hid, gate, x[:, Lt:])
+    enc = add(enc, e_gate, x[:, :Lt])
     return hid, enc
 
 
 def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, lora_scale=2.0,
-            image_rotary_emb=None, round_p_ds=False):
-    """hidden_states [B,F,C,H,W], encoder_hidden_states [B,L,4096], timestep [B] -> sample [B,F,C_out,H,W]."""
+            image_rotary_emb=None, round_p_ds=False, round_activations=False):
+    """hidden_states [B,F,C,H,W], encoder_hidden_states [B,L,4096], timestep [B] -> sample [B,F,C_out,H,W].
+    round_activations: see "activation-rounded mode" above (implies round_p_ds)."""
     B, Fr, C, H, W = hidden_states.shape
     p = cfg.patch_size
     D = cfg.inner_dim
     dt = hidden_states.dtype
-    t_emb = timestep_embedding(timestep, D, cfg.flip_sin_to_cos, cfg.freq_shift).to(dt)
-    emb = F.linear(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
-    emb = F.linear(F.silu(emb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    rnd = bool(round_activations)
+    t_emb = _r(timestep_embedding(timestep, D, cfg.flip_sin_to_cos, cfg.freq_shift).to(dt), rnd)
+    emb = _r(F.linear(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"]), rnd)
+    emb = _r(F.linear(_r(F.silu(emb), rnd), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"]), rnd)
 
-    x = patch_embed(sd, cfg, encoder_hidden_states, hidden_states)
+    x = patch_embed(sd, cfg, encoder_hidden_states, hidden_states, rnd)
     Lt = encoder_hidden_states.shape[1]
     enc, hid = x[:, :Lt], x[:, Lt:]
     for i in range(cfg.num_layers):
-        hid, enc = block_forward(sd, cfg, i, hid, enc, emb, lora, lora_scale, image_rotary_emb, round_p_ds=round_p_ds)
+        hid, enc = block_forward(sd, cfg, i, hid, enc, emb, lora, lora_scale, image_rotary_emb, round_p_ds=round_p_ds, rnd=rnd)
 
-    hid = layer_norm(torch.cat([enc, hid], dim=1), sd["norm_final.weight"], sd["norm_final.bias"], cfg.norm_eps)[:, Lt:]
-    m = F.linear(F.silu(emb), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
+    hid = _r(layer_norm(torch.cat([enc, hid], dim=1), sd["norm_final.weight"], sd["norm_final.bias"], cfg.norm_eps), rnd)[:, Lt:]
+    m = _r(F.linear(_r(F.silu(emb), rnd), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"]), rnd)
     shift, scale = m.chunk(2, dim=1)
-    hid = layer_norm(hid, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], cfg.norm_eps) * (1 + scale)[:, None] + shift[:, None]
-    hid = F.linear(hid, sd["proj_out.weight"], sd["proj_out.bias"])
+    hid = _r(layer_norm(hid, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], cfg.norm_eps) * _r(1 + scale, rnd)[:, None] + shift[:, None], rnd)
+    hid = _r(F.linear(hid, sd["proj_out.weight"], sd["proj_out.bias"]), rnd)
     if cfg.patch_size_t is None:
         out = hid.reshape(B, Fr, H // p, W // p, -1, p, p).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
     else:
@@ -307,7 +371,7 @@ def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, 
     return out
 
 
-def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta=1.0, lora_scale=2.0, round_p_ds=False):
+def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta=1.0, lora_scale=2.0, round_p_ds=False, round_activations=False):
     """One preference-pair step as train/CogVideoX-5B/03_train.py:116-157 does it.
 
     x_win/x_lose arrive as the dataset stores them, [B,C,F,H,W] (train/dataset.py:228-229), and are
@@ -318,13 +382,23 @@ def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta
     xl = x_lose.permute(0, 2, 1, 3, 4)
     xw_n = scheduler.add_noise(abar, xw, noise, t)
     xl_n = scheduler.add_noise(abar, xl, noise, t)
-    v_w = forward(sd, cfg, xw_n, prompt_emb, t, lora, lora_scale, round_p_ds=round_p_ds)
-    v_l = forward(sd, cfg, xl_n, prompt_emb, t, lora, lora_scale, round_p_ds=round_p_ds)
+    kw = dict(round_p_ds=round_p_ds, round_activations=round_activations)
+    if round_activations:       # csrc/noise.hip: x_t and the v-target are bf16 tensors
+        xw_n, xl_n = _rv(xw_n), _rv(xl_n)
+    v_w = forward(sd, cfg, xw_n, prompt_emb, t, lora, lora_scale, **kw)
+    v_l = forward(sd, cfg, xl_n, prompt_emb, t, lora, lora_scale, **kw)
     with torch.no_grad():
-        v_wr = forward(sd, cfg, xw_n, prompt_emb, t, None, round_p_ds=round_p_ds)
-        v_lr = forward(sd, cfg, xl_n, prompt_emb, t, None, round_p_ds=round_p_ds)
+        v_wr = forward(sd, cfg, xw_n, prompt_emb, t, None, **kw)
+        v_lr = forward(sd, cfg, xl_n, prompt_emb, t, None, **kw)
     tw = scheduler.get_velocity(abar, xw, noise, t)
     tl = scheduler.get_velocity(abar, xl, noise, t)
-    out = dpo.dpo_loss(v_w, v_l, v_wr, v_lr, tw, tl, beta=beta)
+    if round_activations:
+        # bf16 predictions and targets; (pred - target) is formed in bf16 before the fp32 square (train/loss.py:73-77 under bf16 autocast): the
+        # rounded difference replaces the prediction, the target becomes zero
+        tw, tl = _rv(tw), _rv(tl)
+        v_w_, v_l_, v_wr_, v_lr_ = (_r(a - b) for a, b in ((v_w, tw), (v_l, tl), (v_wr, tw), (v_lr, tl)))
+        out = dpo.dpo_loss(v_w_, v_l_, v_wr_, v_lr_, torch.zeros_like(tw), torch.zeros_like(tl), beta=beta)
+    else:
+        out = dpo.dpo_loss(v_w, v_l, v_wr, v_lr, tw, tl, beta=beta)
     out.update(v_win=v_w, v_lose=v_l, v_win_ref=v_wr, v_lose_ref=v_lr)
     return out

@@ -2,7 +2,8 @@
 engine, checked by what holds regardless of the random weights (SURVEY 8c known answers): with the adapters' B = 0 (the PEFT
 initialisation) policy == reference bit for bit, so the Diffusion-DPO loss is ln 2 to 1e-6 after 42 layers, the gradient reaches only
 lora_B, everything is finite -- plus the memory the reference's I2V batch size needs, and one engine step through a real RCCL
-communicator.  -m gpu only; these three tests take the whole GPU (up to ~270 GB)."""
+communicator; and BASELINE configs[3] (CogVideoX1.5-5B, S = 41 026) at full depth with lean activations.  -m gpu only; these tests take the whole
+GPU (up to ~270 GB)."""
 import math
 import os
 
@@ -81,6 +82,38 @@ def test_cfg3_i2v_batch_2_fits_and_is_ln2_at_b0():
     gb = _ln2_step(tr, batch, n_lora=42 * 8)
     assert gb < 280.0, gb
     print(f"cfg3 batch-2 pair-step peak memory {gb:.1f} GB")
+
+
+def test_cfg4_full_depth_lean_step_is_ln2_at_b0():
+    """BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t = 2, no patch bias), 81f x 768x1360 -> paired latents [1,2,21,16,96,170], even-cropped to
+    20 frames by the 1.5 step (train/CogVideoX1.5-5B/03_train.py:118-186) -> S = 226 + 10 x 48 x 85 = 41 026 tokens, ALL 42 blocks, LoRA r = 64, lean
+    activations and NO recompute -- exactly what `bench.py --config cfg4` times (230 GB of the 288).  B = 0: policy == reference through 42 layers at
+    S = 41 026, so the loss is ln 2 to 1e-6, gradients reach only lora_B and are finite."""
+    import gc
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    gc.collect(); torch.cuda.empty_cache()
+    model = _build("COGVIDEOX_1_5_5B")
+    tr = CogVideoXDPOTrainer({"lora_rank": 64, "lora_alpha": 128, "beta": 1.0, "seed": 7, "weight_decay": 1e-3, "lean_activations": True,
+                              "enable_gradient_checkpointing": False}, transformer=model)
+    assert model.lean_activations and not model.gradient_checkpointing
+    tr.train()
+    g = torch.Generator(device="cuda").manual_seed(2468)
+    batch = {"x_pair": (0.7 * torch.randn(1, 2, 21, 16, 96, 170, generator=g, device="cuda")).to(torch.bfloat16),
+             "prompt_emb": (0.2 * torch.randn(1, 226, 4096, generator=g, device="cuda")).to(torch.bfloat16)}
+    seen = {}
+    orig = model.forward
+
+    def spy(hs, *a, **k):
+        seen["tokens"] = 226 + (hs.shape[1] // 2) * (hs.shape[3] // 2) * (hs.shape[4] // 2)
+        return orig(hs, *a, **k)
+    model.forward = spy
+    gb = _ln2_step(tr, batch, n_lora=42 * 8)
+    model.forward = orig
+    assert seen["tokens"] == 41026, seen
+    assert gb < 260.0, gb
+    print(f"cfg4 full-depth lean pair-step peak memory {gb:.1f} GB")
+    del tr, model, batch
+    gc.collect(); torch.cuda.empty_cache()
 
 
 def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):

@@ -63,7 +63,7 @@ def test_video_processor_runs_the_vggt_wrapper_on_device():
 
     def net(images):
         seen["images"] = images
-        seen["autocast"] = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16     # utils/model_utils.py:99-102
+        seen["autocast"] = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16     # utils/model_utils.py:99-102
         T, h, w = images.shape[1], images.shape[3], images.shape[4]
         pe = torch.zeros(1, T, 9, device=images.device)
         pe[..., 6] = 1.0

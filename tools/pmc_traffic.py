@@ -74,6 +74,7 @@ if len(parts) == 2:
                 e[key] = sum(p[key] * wi for p, wi in zip(parts, w)) / sum(w)
         e["avg_ns_under_rocprof"] = sum(w)
     out["attn128_bwd"] = e
+out["__source__"] = {"profile_round": tag, "made_by": "tools/profile_round.sh -> tools/pmc_traffic.py", "files": f"profiles/{tag}_pmc_traffic.json"}
 json.dump(out, open(f"{root}/pmc_traffic_{tag}.json", "w"), indent=1)
 for k, v in out.items():
     print(f"{k:48s} hbm {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  mfma_busy {v.get('mfma_busy', float('nan')):.3f}  clock {v.get('clock_mhz', float('nan')):7.0f} MHz")
