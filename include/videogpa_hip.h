@@ -122,6 +122,12 @@ int32_t vgpa_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, f
 size_t vgpa_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t S);
 int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_strides, const int64_t* do_strides, float* delta,
                             int64_t B, int64_t H, int64_t S, int64_t head_dim, vgpa_stream_t stream);
+/* The same with the forward's rounding residual o_res = O_fp32 - bf16(O) (vgpa_attn_fwd_w1_res; bf16 view with its own strides, may be
+ * NULL): delta = rowsum(dO o (O + O_res)).  delta stands for rowsum(P o dP), which equals rowsum(dO o O) for the UNROUNDED O only; from the
+ * bf16 O alone (what flash-attention backwards, torch's included, do) every row's dS stops summing to zero and dQ picks up a coherent error. */
+int32_t vgpa_attn_bwd_delta_res(const void* o, const void* o_res, const void* d_o, const int64_t* o_strides, const int64_t* ores_strides,
+                                const int64_t* do_strides, float* delta, int64_t B, int64_t H, int64_t S, int64_t head_dim,
+                                vgpa_stream_t stream);
 int32_t vgpa_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
                           void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                           const int64_t* do_strides, const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H,
@@ -145,10 +151,19 @@ size_t vgpa_attn_fwd_w1_workspace_bytes(int64_t B, int64_t H, int64_t S);
 int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
                          const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
                          int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* vgpa_attn_fwd_w1 that also writes o_res = O_fp32 - bf16(O) as bf16 ([B,H,S,64] view, own strides; NULL = plain vgpa_attn_fwd_w1): with it the
+ * pair (o, o_res) carries the attention output to ~2^-17 for the backward's delta (vgpa_attn_bwd_prep_w1_res / vgpa_attn_bwd_delta_res). */
+int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* o, void* o_res, float* lse2, const int64_t* q_strides,
+                             const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* ores_strides,
+                             int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace,
+                             size_t ws_bytes, vgpa_stream_t stream);
 /* w1 backward, step 1 and step 2: vgpa_attn_bwd_prep_w1 writes delta (fp32 [B,H,S], as vgpa_attn_bwd_delta) and the statistics
  * planes stats = fp32 [B,H,2,S] = {-lse2, -delta}; vgpa_attn_bwd_dkv_w1 = vgpa_attn_bwd_dkv_ws on the w1 structure, reading `stats`. */
 int32_t vgpa_attn_bwd_prep_w1(const void* o, const void* d_o, const float* lse2, const int64_t* o_strides, const int64_t* do_strides,
                               float* delta, float* stats, int64_t B, int64_t H, int64_t S, int64_t head_dim, vgpa_stream_t stream);
+int32_t vgpa_attn_bwd_prep_w1_res(const void* o, const void* o_res, const void* d_o, const float* lse2, const int64_t* o_strides,
+                                  const int64_t* ores_strides, const int64_t* do_strides, float* delta, float* stats, int64_t B, int64_t H,
+                                  int64_t S, int64_t head_dim, vgpa_stream_t stream);
 int32_t vgpa_attn_bwd_dkv_w1(const void* q, const void* k, const void* v, const void* d_o, const float* stats, void* dk, void* dv,
                              const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* do_strides,
                              const int64_t* dk_strides, const int64_t* dv_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,

@@ -10,22 +10,27 @@ Tolerances (the HIP path computes in bf16, the oracle in fp32 on the same bf16-r
   loss                  |d| <= 1e-3 (north_star) -- measured ~3e-4
   rewards (= -mean err) |d| <= 2e-4 + 1 % relative; reward_margin (their difference, 1e-3 of the rewards) |d| <= 1e-3
   v_pred samples        |d| <= 3 % of the prediction range (bf16 activations through 2 blocks)
-  LoRA grads, EVERY tensor, both variants: relative error e = |g - g_fp32| / |g_fp32| (whole tensor)
-                            e_hip <= max(REL_FIXED, FLOOR_FACTOR * e_torch_bf16)
-                        where e_torch_bf16 is the error of the oracle's own code run with bf16 weights / activations on the same GPU
-                        (plain torch autograd: what the reference's bf16-mixed training computes).  REL_FIXED = 0.08 (cosine 0.997)
-                        covers every well-conditioned tensor with room; the floor term exists for ONE family, the to_q / to_k adapters
-                        of the LAST block, whose gradient is a heavily cancelling sum (|dQ| 20x below |dK|) that amplifies ANY bf16
-                        perturbation of its inputs -- torch bf16 itself is 30-70 % off there.  The statement tested is therefore: the
-                        HIP path is never further from fp32 than 1.25 x plain torch bf16, and within 8 % wherever that is achievable.
-                        (Round 2 tested cosines against 3 x the floor with a "noise-dominated" escape; that escape is gone.)
+  LoRA grads, EVERY tensor, both variants, against TWO references:
+    (a) the ACTIVATION-ROUNDED oracle (oracle/cogvideox.py round_activations=True): fp32 arithmetic with every tensor the HIP path stores in bf16
+        rounded to bf16 in the forward and its gradient rounded in the backward -- the same arithmetic TYPE at the same places, so what is left is
+        arithmetic ORDER and the independent realisation of the rounding noise.  Bound: relative error <= 10 % AND cosine >= 0.995 on every tensor,
+        the last block's to_q / to_k included (measured 1.2-6 %; two runs of the rounded oracle itself that differ by ONE bf16 ulp in ONE input
+        element drift 0.3-2.8 % apart: tools/cfg1_round_diag.py, profiles/r04_cfg1_round_diag_*.json).
+    (b) the fp32 oracle: e_hip <= min(max(0.08, 1.25 x e_torch_bf16), 0.12), where e_torch_bf16 is the error of the oracle's own code run in plain
+        torch bf16 on the same GPU (what the reference's bf16-mixed training computes; 0.04-0.86 per tensor).  The 12 % cap holds for EVERY tensor
+        since round 4 (measured 1.7-10.4 %; the activation-rounded oracle itself is 1.8-9.7 % from fp32 on the same tensors).
+  What round 4 found with (a): the 37-87 % the last block's to_q / to_k adapters were off (in this path AND in torch bf16) is not diffuse
+  "noise amplified by cancellation" but ONE mechanism: the flash-attention backward forms delta = rowsum(dO o O) from the STORED bf16 output, while
+  the identity delta = rowsum(P o dP) holds for the unrounded O = P V only; each row's dS then stops summing to zero and dQ_i picks up
+  -d(delta_i) sum_j P_ij K_j, a coherent term.  The rounded oracle reproduces the HIP gradients to 4-9 % once it does the same
+  (test_cfg1_plain_delta_path_matches_the_oracle_that_rounds_the_output_in_delta), and is within 3-4 % of fp32 when delta comes from the
+  unrounded output.  The HIP path therefore now stores the output's rounding residual next to it (ops.PRECISE_DELTA, csrc/attention_w1.hip
+  w1_residual4; + S D 2 bytes per layer) and forms delta from O + O_res: reference (a) is the oracle with exact_delta=True, and the fp32 errors of that
+  family drop from 0.37-0.87 to the level of every other tensor.
   attention backward, kernel level (test_cfg1_attention_backward_matches_rounding_injected_recompute): every attention-backward
                         launch of the step is recorded and dQ / dK / dV of six (batch, head) slices each are recomputed in fp32 from
                         the SAME inputs with only the two roundings every bf16 flash attention makes (P -> bf16 for dV, dS -> bf16 for
                         dQ / dK): cosine >= 0.999, norm within 1 % -- the tight statement about the kernels themselves.
-  Reported, not asserted: the gradients against the rounding-injected oracle at MODEL level (oracle/cogvideox.py::_RoundedSDPA);
-                        measured, it does not explain the last block's q / k family (cos 0.79-0.95): that error comes from the bf16
-                        rounding of the attention's INPUTS, not of P / dS.
 """
 import json
 import math
@@ -48,11 +53,13 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-REL_FIXED, FLOOR_FACTOR = 0.08, 1.25
+REL_FIXED, FLOOR_FACTOR, ABS_CAP = 0.08, 1.25, 0.12    # against fp32: never further than 1.25 x torch bf16, within 8 % where that is achievable, within 12 % EVERYWHERE
+ROUNDED_REL, ROUNDED_COS = 0.10, 0.995          # against the activation-rounded oracle
 
 
-def _oracle_on_gpu(variant, dtype, round_p_ds=False):
-    """The oracle's own code on the GPU: fp32 (the reference for whole gradient tensors), fp32 with the P / dS roundings injected, or
+def _oracle_on_gpu(variant, dtype, round_p_ds=False, **kw):
+    """The oracle's own code on the GPU: fp32 (the reference for whole gradient tensors), fp32 with the P / dS roundings injected, fp32 with EVERY
+    bf16-stored tensor rounded (round_activations=True; exact_delta=True forms the attention backward's delta from the unrounded output), or
     bf16 weights / activations (plain torch bf16: the floor)  -> (loss, {name: grad fp32 on the CPU})."""
     from oracle import scheduler as osch
     cfg = c1.config()
@@ -61,7 +68,7 @@ def _oracle_on_gpu(variant, dtype, round_p_ds=False):
     lora = {k: v.cuda().requires_grad_(True) for k, v in lora.items()}
     xw, xl, prompt, t, noise = (v.to(dtype) if v.is_floating_point() else v for v in c1.inputs())
     abar = osch.alphas_cumprod().cuda()
-    out = ocv.dpo_pair_step(sd, cfg, lora, abar, xw.cuda(), xl.cuda(), prompt.cuda(), t.cuda(), noise.cuda(), beta=1.0, round_p_ds=round_p_ds)
+    out = ocv.dpo_pair_step(sd, cfg, lora, abar, xw.cuda(), xl.cuda(), prompt.cuda(), t.cuda(), noise.cuda(), beta=1.0, round_p_ds=round_p_ds, **kw)
     out["loss"].backward()
     loss = float(out["loss"].detach())
     grads = {k: p.grad.float().cpu() for k, p in lora.items()}
@@ -70,7 +77,8 @@ def _oracle_on_gpu(variant, dtype, round_p_ds=False):
     return loss, grads
 
 
-def _hip_step(variant):
+def _hip_step(variant, precise_delta=True):
+    from videogpa_amd import ops as _ops
     from videogpa_amd.lora import LoraConfig, get_peft_model
     from videogpa_amd.trainer import CogVideoXDPOTrainer
     from videogpa_amd.transformer import COGVIDEOX_5B, CogVideoXTransformer3DModel
@@ -96,11 +104,16 @@ def _hip_step(variant):
         captured.setdefault("preds", []).append(out.sample.detach())
         return out
     tr.transformer.forward = spy
-    out = tr._shared_step({"x_win": x_win.cuda(), "x_lose": x_lose.cuda(), "prompt_emb": prompt.cuda()},
-                          timesteps=t.cuda(), noise=noise.cuda())
-    tr.transformer.forward = orig
-    out.loss.backward()
-    torch.cuda.synchronize()
+    keep = _ops.PRECISE_DELTA
+    _ops.PRECISE_DELTA = bool(precise_delta)
+    try:
+        out = tr._shared_step({"x_win": x_win.cuda(), "x_lose": x_lose.cuda(), "prompt_emb": prompt.cuda()},
+                              timesteps=t.cuda(), noise=noise.cuda())
+        tr.transformer.forward = orig
+        out.loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        _ops.PRECISE_DELTA = keep
     v_ref, v_pol = captured["preds"]            # reference pass first (adapter off), then the policy pass; batch = (win, lose)
     grads = {}
     named = dict(pm.named_parameters())
@@ -143,10 +156,11 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
     torch.cuda.empty_cache()
     ref_loss, ref_grads = _oracle_on_gpu(variant, torch.float32)
     floor_loss, floor_grads = _oracle_on_gpu(variant, torch.bfloat16)
-    ro_loss, ro_grads = _oracle_on_gpu(variant, torch.float32, round_p_ds=True)
-    report.update(loss_oracle_fp32_here=ref_loss, loss_torch_bf16=floor_loss, loss_rounded_oracle=ro_loss)
+    ro_loss, ro_grads = _oracle_on_gpu(variant, torch.float32, round_activations=True, exact_delta=True)
+    report.update(loss_oracle_fp32_here=ref_loss, loss_torch_bf16=floor_loss, loss_activation_rounded_oracle=ro_loss)
     check(abs(ref_loss - float(gold["loss"])) < 1e-5, ("in-process fp32 oracle vs golden loss", ref_loss, float(gold["loss"])))
-    check(abs(ro_loss - float(gold["loss"])) < 2e-4, ("rounding-injected oracle drifted from the golden", ro_loss, float(gold["loss"])))
+    check(abs(ro_loss - float(gold["loss"])) < 5e-4, ("activation-rounded oracle drifted from the golden", ro_loss, float(gold["loss"])))
+    check(abs(out.loss.item() - ro_loss) < 5e-4, ("loss vs the activation-rounded oracle", out.loss.item(), ro_loss))
     worst = {"rel_err_hip": 0.0, "rel_err_over_bound": 0.0}
     per_tensor = {}
     assert set(grads) == set(gold["lora_grads"]) == set(ref_grads)
@@ -166,13 +180,18 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
         check(cosine(r.flatten()[idx], gs["samples"]) > 0.99999 and abs(r.double().norm().item() / float(gs["norm"]) - 1) < 1e-4,
               (k, "in-process fp32 oracle vs golden samples", cosine(r.flatten()[idx], gs["samples"])))
         e_hip, e_floor = rel(g, r), rel(floor_grads[k], r)
-        bound = max(REL_FIXED, FLOOR_FACTOR * e_floor)
+        bound = min(max(REL_FIXED, FLOOR_FACTOR * e_floor), ABS_CAP)
+        e_ro, c_ro = rel(g, ro_grads[k]), cosine(g, ro_grads[k])
         per_tensor[k.replace("base_model.model.transformer_blocks.", "")] = {
             "rel_err_hip": round(e_hip, 5), "rel_err_torch_bf16": round(e_floor, 5), "bound": round(bound, 5), "cos_hip": round(cosine(g, r), 6),
-            "cos_torch_bf16": round(cosine(floor_grads[k], r), 6), "cos_hip_vs_rounding_injected_oracle": round(cosine(g, ro_grads[k]), 6)}
+            "cos_torch_bf16": round(cosine(floor_grads[k], r), 6), "rel_err_hip_vs_activation_rounded_oracle": round(e_ro, 5),
+            "cos_hip_vs_activation_rounded_oracle": round(c_ro, 6), "rel_err_activation_rounded_oracle_vs_fp32": round(rel(ro_grads[k], r), 5)}
         worst["rel_err_hip"] = max(worst["rel_err_hip"], e_hip)
         worst["rel_err_over_bound"] = max(worst["rel_err_over_bound"], e_hip / bound)
+        worst["rel_err_vs_rounded_oracle"] = max(worst.get("rel_err_vs_rounded_oracle", 0.0), e_ro)
+        worst["cos_vs_rounded_oracle"] = min(worst.get("cos_vs_rounded_oracle", 1.0), c_ro)
         check(math.isfinite(e_hip) and e_hip <= bound, (k, "relative error vs fp32 oracle", e_hip, "bound", bound, "torch bf16", e_floor))
+        check(e_ro <= ROUNDED_REL and c_ro >= ROUNDED_COS, (k, "vs the activation-rounded oracle: relative error", e_ro, "cosine", c_ro))
     report["lora_grads_worst"] = worst
     report["lora_grads_per_tensor"] = per_tensor
     report["failed_checks"] = [str(f) for f in fails]
@@ -181,6 +200,33 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
         json.dump(report, f, indent=1)
     print(json.dumps(report))
     assert not fails, fails
+
+
+@pytest.mark.parametrize("variant", ["r8", "r64"])
+def test_cfg1_plain_delta_path_matches_the_oracle_that_rounds_the_output_in_delta(variant):
+    """ops.PRECISE_DELTA off = the textbook flash-attention backward (delta from the stored bf16 output; what torch's bf16 kernels do): the HIP gradients
+    must then follow the activation-rounded oracle that ALSO forms delta from the rounded output -- every tensor within 12 % / cosine 0.993 (measured
+    1.3-9.2 %, cosine >= 0.9958; the last block's to_q / to_k are 35-83 % away from fp32 in BOTH, which is the point: the mechanism is modelled, not
+    tolerated) -- and the default path must be at least 3x closer to fp32 than this one on the tensors it was introduced for."""
+    _, _, g_plain = _hip_step(variant, precise_delta=False)
+    _, _, g_prec = _hip_step(variant, precise_delta=True)
+    _, ro = _oracle_on_gpu(variant, torch.float32, round_activations=True, exact_delta=False)
+    _, ref = _oracle_on_gpu(variant, torch.float32)
+
+    def rel(a, r):
+        return float((a.double() - r.double()).norm() / r.double().norm())
+
+    worst, gains = 0.0, {}
+    for k, g in g_plain.items():
+        a, r = g.double().flatten(), ro[k].double().flatten()
+        cos = float((a * r).sum() / (a.norm() * r.norm()))
+        worst = max(worst, rel(g, ro[k]))
+        assert rel(g, ro[k]) <= 0.12 and cos >= 0.993, (k, rel(g, ro[k]), cos)
+        if ".transformer_blocks.1.attn1.to_q." in k or ".transformer_blocks.1.attn1.to_k." in k:
+            gains[k] = (rel(g, ref[k]), rel(g_prec[k], ref[k]))
+            assert gains[k][1] < gains[k][0] / 3 and gains[k][1] < 0.12, (k, gains[k])
+    print(json.dumps({"variant": variant, "plain_delta_worst_rel_err_vs_matching_oracle": worst,
+                      "last_block_qk_rel_err_vs_fp32_plain_then_precise": {k.split("blocks.")[1]: v for k, v in gains.items()}}))
 
 
 def test_cfg1_attention_backward_matches_rounding_injected_recompute():
@@ -193,7 +239,8 @@ def test_cfg1_attention_backward_matches_rounding_injected_recompute():
 
     def spy(q, k, v, o, do, lse, dq, dk, dv, **kw):
         orig(q, k, v, o, do, lse, dq, dk, dv, **kw)
-        rec.append(tuple(t.clone() for t in (q, k, v, o, do, dq, dk, dv)))
+        o_full = o.float() if kw.get("o_res") is None else o.float() + kw["o_res"].float()     # what the kernels' delta is formed from (ops.PRECISE_DELTA)
+        rec.append(tuple(t.clone() for t in (q, k, v, o_full, do, dq, dk, dv)))
     ops.attention_bwd_raw = spy
     try:
         _hip_step("r64")

@@ -1,7 +1,7 @@
 """What can an activation-rounded oracle pin at BASELINE configs[0] width?  
 
 Runs on the GPU box.  For r8 and r64: the HIP pair-step's LoRA gradients (h), the fp32 oracle (f), plain torch bf16 (b), the oracle with P / dS rounded
-(p), the ACTIVATION-ROUNDED oracle (a: oracle/cogvideox.py round_activations=True) and the same oracle on an input that differs by ONE bf16 ulp in
+(p), the ACTIVATION-ROUNDED oracle (a: oracle/cogvideox.py round_activations=True; x: the same with the attention backward's delta formed from the UNROUNDED output) and the same oracle on an input that differs by ONE bf16 ulp in
 ONE prompt-embedding element (a').  Prints, per adapter tensor, relative errors and cosines between the pairs that matter:
 
     h|f  b|f  a|f     distance of each bf16-class computation from fp32
@@ -65,6 +65,7 @@ def main():
         lb, b = oracle(variant, torch.bfloat16)
         lp, p = oracle(variant, round_p_ds=True)
         la, a = oracle(variant, round_activations=True)
+        lx, x = oracle(variant, round_activations=True, exact_delta=True)
         la2, a2 = oracle(variant, round_activations=True, perturb=True)
         lf2, f2 = oracle(variant, perturb=True)
         rep = {"variant": variant, "loss": {"hip": lh, "fp32": lf, "torch_bf16": lb, "p_ds_rounded": lp, "act_rounded": la, "act_rounded_perturbed": la2,
@@ -75,10 +76,10 @@ def main():
             name = k.replace("base_model.model.transformer_blocks.", "").replace(".weight", "").replace("attn1.", "")
             r = {"h|f": rel(h[k], f[k]), "b|f": rel(b[k], f[k]), "a|f": rel(a[k], f[k]), "p|f": rel(p[k], f[k]), "h|a": rel(h[k], a[k]), "a'|a": rel(a2[k], a[k]),
                  "f'|f": rel(f2[k], f[k]), "cos h,f": cos(h[k], f[k]), "cos h,a": cos(h[k], a[k]), "cos a',a": cos(a2[k], a[k]), "cos b,f": cos(b[k], f[k]),
-                 "cos a,f": cos(a[k], f[k]), "norm f": float(f[k].norm()), "norm h": float(h[k].norm()), "norm a": float(a[k].norm())}
+                 "cos a,f": cos(a[k], f[k]), "x|f": rel(x[k], f[k]), "h|x": rel(h[k], x[k]), "h|b": rel(h[k], b[k]), "cos h,b": cos(h[k], b[k]), "norm f": float(f[k].norm()), "norm h": float(h[k].norm()), "norm a": float(a[k].norm())}
             rep["tensors"][name] = r
             print(f"{name:34s} {r['h|f']:7.4f} {r['b|f']:7.4f} {r['a|f']:7.4f} {r['h|a']:7.4f} {r[chr(97)+chr(39)+'|a']:7.4f} {r[chr(102)+chr(39)+'|f']:8.5f} |     "
-                  f"{r['cos h,f']:7.4f} {r['cos h,a']:7.4f} {r['cos a'+chr(39)+',a']:7.4f} {r['cos b,f']:7.4f}")
+                  f"{r['cos h,f']:7.4f} {r['cos h,a']:7.4f} {r['cos a'+chr(39)+',a']:7.4f} {r['cos b,f']:7.4f}  | x|f {r['x|f']:7.4f} h|x {r['h|x']:7.4f} h|b {r['h|b']:7.4f}")
         with open(os.path.join(ROOT, "gpurun_out", f"cfg1_round_diag_{variant}.json"), "w") as fh:
             json.dump(rep, fh, indent=1)
 

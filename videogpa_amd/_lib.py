@@ -41,12 +41,15 @@ SIGNATURES = {
     "vgpa_grad_norm": (I32, [P, I64, F32, P, P, SZ, P]),
     "vgpa_adamw_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P, P]),
     "vgpa_attn_bwd_delta": (I32, [P, P, P, P, P, I64, I64, I64, I64, P]),
+    "vgpa_attn_bwd_delta_res": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
     "vgpa_attn_bwd_dkv": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd_dq": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd_dq_w1": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_fwd_w1_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn_fwd_w1": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_prep_w1": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
+    "vgpa_attn_bwd_prep_w1_res": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
+    "vgpa_attn_fwd_w1_res": (I32, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_dkv_w1": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_split_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn_bwd_dkv_ws": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),

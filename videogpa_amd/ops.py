@@ -767,6 +767,12 @@ ATTN_SPLIT_MODE = int(_os.environ.get("VGPA_ATTN_SPLIT", "-1"))
 # main loops).  VGPA_ATTN_W1 = comma list out of {fwd, dq, dkv} selects which (default all three; "none" = the 2-waves-per-SIMD
 # kernels of attention.hip, which stay in the library as the redo path of the forward and for A/B runs).
 ATTN_W1 = set(x for x in _os.environ.get("VGPA_ATTN_W1", "fwd,dq,dkv").split(",") if x and x != "none")
+# "Precise delta": the forward also stores the rounding residual of its output, o_res = O_fp32 - bf16(O) (bf16, + S*D*2 bytes per sequence and layer), and
+# the backward forms delta = rowsum(dO o (O + O_res)).  delta stands for rowsum(P o dP); formed from the bf16 O alone (what every flash-attention backward,
+# torch's included, does) each row's dS stops summing to zero and dQ picks up a coherent error -d(delta_i) sum_j P_ij K_j that swamps q / k gradients
+# which are small by cancellation (37-87 % of the last block's to_q / to_k adapter gradients at BASELINE configs[0] width: profiles/r04_cfg1_round_diag_*.json).
+# On by default (+0.1 ms per layer); off under lean activations (S = 41 026 has no room for it) and with VGPA_PRECISE_DELTA=0.
+PRECISE_DELTA = _os.environ.get("VGPA_PRECISE_DELTA", "1") == "1"
 
 
 def prescale_q(q, scale=None):
@@ -776,8 +782,9 @@ def prescale_q(q, scale=None):
     return (q.float() * (scale * LOG2E)).to(q.dtype)
 
 
-def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o_pad=0):
+def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o_pad=0, o_res=None):
     """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32.
+    o_res: optional bf16 [B,S,H*64] buffer that receives the output's rounding residual (w1 forward only; see PRECISE_DELTA).
     split_mode: -1 lets the launcher cut the tasks of a mostly empty last scheduling round into key-range chunks,
     0 forbids it, k >= 2 forces k chunks for every task (tests).  o_pad: o is the head of a [B,S,H*64+o_pad] buffer (the
     output projection's LoRA tail, see LoraExt)."""
@@ -792,10 +799,18 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
     if "fwd" in ATTN_W1:
         ws_bytes = _lib.query("vgpa_attn_fwd_w1_workspace_bytes", B, H, S)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        if o_res is not None:
+            rv = o_res.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
+            _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
+                "vgpa_attn_fwd_w1_res", q, k, v, o, o_res, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), _bhs_strides(rv),
+                B, H, S, Dh, float(scale), int(split_mode), ws, ws_bytes, _stream()))
+            return o, lse
         _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
             "vgpa_attn_fwd_w1", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
             float(scale), int(split_mode), ws, ws_bytes, _stream()))
         return o, lse
+    if o_res is not None:
+        raise RuntimeError("attention_fwd_raw: o_res needs the w1 forward (VGPA_ATTN_W1 includes fwd)")
     ws_bytes = _lib.query("vgpa_attn_fwd_workspace_bytes", B, H, S) if split_mode != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
     _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
@@ -804,8 +819,9 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
     return o, lse
 
 
-def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False, split_mode=None):
-    """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.
+def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False, split_mode=None, o_res=None):
+    """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.  o_res ([B,H,S,64] view): the forward's rounding
+    residual, delta = rowsum(dO o (O + O_res)) (PRECISE_DELTA).
     Algorithmic FLOPs (backward = 2 x forward): dK/dV kernel carries dV, dP, dK = 6 S^2 d; dQ kernel 2 S^2 d
     (the S = QK^T recomputes in both kernels and the second dP are overhead, not counted)."""
     B, H, S, Dh = q.shape
@@ -817,11 +833,13 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
     w1_dkv = "dkv" in ATTN_W1 and not ATTN_BWD_FUSED
     if w1_dkv:     # one pass: delta + the {-lse2, -delta} planes the w1 dK/dV kernel streams
         stats = torch.empty(B, H, 2, S, dtype=torch.float32, device=q.device)
-        _timed("attn_delta_kernel", 4.0 * B * H * S * Dh, lambda: _lib.call(
-            "vgpa_attn_bwd_prep_w1", o, do, lse, _bhs_strides(o), _bhs_strides(do), delta, stats, B, H, S, Dh, st), "byte")
+        _timed("attn_delta_kernel", (4.0 if o_res is None else 6.0) * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_attn_bwd_prep_w1_res", o, o_res, do, lse, _bhs_strides(o), None if o_res is None else _bhs_strides(o_res), _bhs_strides(do), delta, stats,
+            B, H, S, Dh, st), "byte")
     else:
-        _timed("attn_delta_kernel", 4.0 * B * H * S * Dh, lambda: _lib.call(
-            "vgpa_attn_bwd_delta", o, do, _bhs_strides(o), _bhs_strides(do), delta, B, H, S, Dh, st), "byte")
+        _timed("attn_delta_kernel", (4.0 if o_res is None else 6.0) * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_attn_bwd_delta_res", o, o_res, do, _bhs_strides(o), None if o_res is None else _bhs_strides(o_res), _bhs_strides(do), delta,
+            B, H, S, Dh, st), "byte")
     if ATTN_BWD_FUSED:
         dq32 = torch.zeros(B, H, S, Dh, dtype=torch.float32, device=q.device)
         _timed("attn_bwd_fused_kernel", 8.0 * S * S * Dh * B * H, lambda: _lib.call(
@@ -927,11 +945,15 @@ class _QKNormAttentionFn(torch.autograd.Function):
         _timed("qknorm_rope_fwd", 8.0 * B * H * S * Dh, lambda: _lib.call(
             "vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
             wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), int(rope_mode), _stream()), "byte")
-        o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad)
+        # the output's rounding residual for the backward's delta -- only where a backward will run, on the w1 forward, and not under lean activations
+        o_res = None
+        if PRECISE_DELTA and "fwd" in ATTN_W1 and not recompute_qk and ctx.needs_input_grad[0]:
+            o_res = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=qkv.device)
+        o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad, o_res=o_res)
         if recompute_qk:
             ctx.save_for_backward(qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk)
         else:
-            ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin)
+            ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin, o_res)
         ctx.meta = (text_len, H, eps, grad_pad, int(rope_mode), bool(recompute_qk))
         return o
 
@@ -940,8 +962,9 @@ class _QKNormAttentionFn(torch.autograd.Function):
         text_len, H, eps, grad_pad, rope_mode, recompute_qk = ctx.meta
         if recompute_qk:
             qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk = ctx.saved_tensors
+            o_res = None
         else:
-            qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin = ctx.saved_tensors
+            qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin, o_res = ctx.saved_tensors
         B, S, W = qkv.shape
         Dh = W // (3 * H)
         do = do.contiguous()
@@ -960,7 +983,8 @@ class _QKNormAttentionFn(torch.autograd.Function):
         dkn = torch.empty_like(kn)
         ov = o.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
         dov = do.view(B, S, H, Dh).permute(0, 2, 1, 3)
-        attention_bwd_raw(qn, kn, v, ov, dov, lse, dqn, dkn, dv, q_prescaled=True)
+        attention_bwd_raw(qn, kn, v, ov, dov, lse, dqn, dkn, dv, q_prescaled=True,
+                          o_res=None if o_res is None else o_res.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3))
         _timed("qknorm_rope_bwd", 12.0 * B * H * S * Dh, lambda: _lib.call(
             "vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
             _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
