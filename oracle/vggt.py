@@ -6,9 +6,12 @@
                                                  softmax(q k^T / sqrt(d)) v, proj
   block             vggt/layers/block.py:30-108  x + ls1(attn(norm1(x))) ; x + ls2(mlp(norm2(x))), Mlp = fc1 -> GELU (erf) -> fc2
   frame_global_pair vggt/models/aggregator.py:260-306  frame attention on (B*S, P, C), global attention on (B, S*P, C)
+  aggregator        vggt/models/aggregator.py:184-258  ImageNet normalisation, patch embedding (the "conv" form), camera / register tokens (entry 0 for
+                                                 a sequence's first frame, entry 1 for the others), positions (0 for special tokens, grid + 1 for
+                                                 patches), aa_block_num x aa_order x aa_block_size blocks, per-depth [frame | global] intermediates
 
-Pinned: tests/test_oracle_golden.py::test_vggt_attention_* checks every function against tests/golden/vggt_attention.pt, which
-tests/golden/make_golden.py::golden_vggt_attention made by importing the reference modules."""
+Pinned: tests/test_oracle_golden.py::test_vggt_* checks every function against tests/golden/vggt_attention.pt / vggt_aggregator.pt, which
+tests/golden/make_golden.py::golden_vggt_attention / golden_vggt_aggregator made by importing the reference modules."""
 import torch
 import torch.nn.functional as F
 
@@ -55,3 +58,39 @@ def frame_global_pair(tokens, p_frame, p_global, heads, B, S, pos):
     t1 = block(tokens, p_frame, heads, pos)
     t2 = block(t1.view(B, S * P, C), p_global, heads, pos.view(B, S * P, 2))
     return t1, t2
+
+
+def aggregator(images, p, heads, depth, patch_size, n_register=4, aa_order=("frame", "global"), aa_block_size=1, rope=True):
+    """images [B, S, 3, H, W] in [0, 1]; p: the reference aggregator's state dict (patch_embed = "conv") -> (list of [B, S, P, 2C], patch_start_idx)"""
+    B, S, _, H, W = images.shape
+    mean = torch.tensor([0.485, 0.456, 0.406], dtype=images.dtype).view(1, 1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], dtype=images.dtype).view(1, 1, 3, 1, 1)
+    x = ((images - mean) / std).view(B * S, 3, H, W)
+    patches = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=patch_size).flatten(2).transpose(1, 2)
+
+    def special(t):          # [1, 2, X, C] -> [B*S, X, C]
+        return torch.cat([t[:, 0:1].expand(B, 1, -1, -1), t[:, 1:2].expand(B, S - 1, -1, -1)], dim=1).reshape(B * S, t.shape[2], t.shape[3])
+    tokens = torch.cat([special(p["camera_token"]), special(p["register_token"]), patches], dim=1)
+    start = 1 + n_register
+    pos = None
+    if rope:
+        gh, gw = H // patch_size, W // patch_size
+        grid = torch.cartesian_prod(torch.arange(gh), torch.arange(gw)) + 1
+        pos = torch.cat([torch.zeros(start, 2, dtype=torch.long), grid], dim=0)[None].expand(B * S, -1, -1)
+    P, C = tokens.shape[1], tokens.shape[2]
+    sub = lambda prefix: {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+    fi = gi = 0
+    out = []
+    for _ in range(depth // aa_block_size):
+        inter = {"frame": [], "global": []}
+        for kind in aa_order:
+            for _ in range(aa_block_size):
+                if kind == "frame":
+                    tokens = block(tokens.reshape(B * S, P, C), sub(f"frame_blocks.{fi}."), heads, None if pos is None else pos.reshape(B * S, P, 2))
+                    fi += 1
+                else:
+                    tokens = block(tokens.reshape(B, S * P, C), sub(f"global_blocks.{gi}."), heads, None if pos is None else pos.reshape(B, S * P, 2))
+                    gi += 1
+                inter[kind].append(tokens.reshape(B, S, P, C))
+        out += [torch.cat([f, g], dim=-1) for f, g in zip(inter["frame"], inter["global"])]
+    return out, start

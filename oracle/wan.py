@@ -52,13 +52,55 @@ def layer_norm(x, eps, weight=None, bias=None):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
-class Params:
-    """state dict + LoRA lookup"""
+def _q8_rows(x):
+    """per-row dynamic OCP e4m3 quantisation as csrc/fp8.hip does it (scale = amax / 448, round to nearest even, saturating), returned DEquantised in
+    x's dtype: the value the e4m3 GEMM operand stands for"""
+    fmax = 448.0
+    amax = x.abs().amax(dim=-1, keepdim=True)
+    sc = torch.where(amax > 0, amax / fmax, torch.ones_like(amax))
+    return (x / sc).clamp(-fmax, fmax).to(torch.float32).to(torch.float8_e4m3fn).to(x.dtype) * sc
 
-    def __init__(self, state, lora=None, dtype=torch.float32):
+
+def _bf(x):
+    return x.bfloat16().to(x.dtype)
+
+
+class _Fp8Ffn(torch.autograd.Function):
+    """The feed-forward branch y = W2 gelu(W1 h + b1) + b2 with the roundings of videogpa_amd/wan_model.py::_FfnFp8Fn INJECTED into the oracle's own
+    precision (the "fp8 MFMA path" of BASELINE configs[4]; frozen weights, so the backward is dX only):
+      forward : h -> bf16 -> e4m3 rows; W1, W2 e4m3 per output row; u = bf16(h8 W1_8^T + b1); g = bf16(gelu(u)) -> e4m3 rows; y = bf16(g8 W2_8^T + b2)
+      backward: dy -> bf16 -> e4m3 rows; dg = bf16(dy8 (W2^T)_8^T) with W2^T quantised per ITS rows; du = bf16(dg gelu'(u)) -> e4m3 rows; dh = bf16(du8 (W1^T)_8^T)
+    GEMM accumulation itself stays in the oracle's precision (the fp8 MFMAs accumulate in fp32)."""
+
+    @staticmethod
+    def forward(ctx, h, W1, b1, W2, b2):
+        h8 = _q8_rows(_bf(h))
+        u = _bf(F.linear(h8, _q8_rows(W1), b1))
+        g8 = _q8_rows(_bf(F.gelu(u, approximate="tanh")))
+        y = _bf(F.linear(g8, _q8_rows(W2), b2))
+        ctx.save_for_backward(u, W1, W2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, W1, W2 = ctx.saved_tensors
+        dg = _bf(_q8_rows(_bf(dy)) @ _q8_rows(W2.t().contiguous()).t())
+        with torch.enable_grad():
+            uu = u.detach().requires_grad_(True)
+            (gp,) = torch.autograd.grad(F.gelu(uu, approximate="tanh").sum(), uu)
+        du8 = _q8_rows(_bf(dg * gp))
+        dh = _bf(du8 @ _q8_rows(W1.t().contiguous()).t())
+        return dh, None, None, None, None
+
+
+class Params:
+    """state dict + LoRA lookup.  fp8_ffn: the feed-forward of every block with e4m3 GEMM operands (see _Fp8Ffn)."""
+
+    def __init__(self, state, lora=None, dtype=torch.float32, fp8_ffn=False):
         self.s = {k: v.detach().to(dtype) for k, v in state.items()}
         self.lora = lora or {}
         self.dtype = dtype
+        self.fp8_ffn = fp8_ffn
 
     def linear(self, name, x):
         y = F.linear(x, self.s[name + ".weight"], self.s.get(name + ".bias"))
@@ -104,7 +146,11 @@ def block(P, pre, x, e, n, grid, freqs, context, eps, cross_attn_norm=True):
     h = layer_norm(x, eps, P[pre + ".norm3.weight"], P[pre + ".norm3.bias"]) if cross_attn_norm else x
     x = x + cross_attention(P, pre + ".cross_attn", h, context, n, eps)
     y = layer_norm(x, eps) * (1 + e[4].squeeze(2)) + e[3].squeeze(2)
-    y = P.linear(pre + ".ffn.2", F.gelu(P.linear(pre + ".ffn.0", y), approximate="tanh"))
+    if P.fp8_ffn:
+        y = _Fp8Ffn.apply(y, P[pre + ".ffn.0.weight"], P[pre + ".ffn.0.bias"], P[pre + ".ffn.2.weight"], P[pre + ".ffn.2.bias"])
+        # the gate's backward writes bf16(gate * dout) straight as the e4m3 operand: _Fp8Ffn.backward rounds its incoming gradient, which is that product
+    else:
+        y = P.linear(pre + ".ffn.2", F.gelu(P.linear(pre + ".ffn.0", y), approximate="tanh"))
     return x + y * e[5].squeeze(2)
 
 

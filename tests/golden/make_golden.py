@@ -385,6 +385,40 @@ def golden_vggt_attention():
     print("vggt_attention.pt:", len(out["attention"]), "attention cases + 1 frame/global block pair")
 
 
+def golden_vggt_aggregator():
+    """tests/golden/vggt_aggregator.pt: vggt/models/aggregator.py::Aggregator IMPORTED from the reference and run in fp32 on the CPU at small dimensions
+    (patch_embed="conv", head_dim 64): the special-token assembly (slice_expand_and_flatten), PositionGetter positions, the aa_block_num x aa_order x
+    aa_block_size loop and the list of concatenated intermediates, for aa_block_size 1 and 2.  Inputs and parameters are bf16-representable."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from vggt.models.aggregator import Aggregator
+    g = torch.Generator().manual_seed(4242)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    cases = []
+    for depth, bs, B, S, H, W in ((2, 1, 2, 3, 28, 42), (2, 2, 1, 2, 42, 28)):
+        torch.manual_seed(7 + bs)
+        agg = Aggregator(img_size=H, patch_size=14, embed_dim=128, depth=depth, num_heads=2, mlp_ratio=2.0, num_register_tokens=4, patch_embed="conv",
+                         aa_block_size=bs, qk_norm=True, rope_freq=100, init_values=0.01).eval()
+        with torch.no_grad():
+            for n, p in agg.named_parameters():
+                if "gamma" in n:
+                    p.copy_(rb(0.5 + 0.1 * torch.randn(p.shape, generator=g)))
+                elif n in ("camera_token", "register_token"):
+                    p.copy_(rb(0.5 * torch.randn(p.shape, generator=g)))
+                elif n.startswith("patch_embed."):
+                    p.copy_(rb(torch.randn(p.shape, generator=g) * 0.05))
+                else:
+                    p.copy_(rb(torch.randn(p.shape, generator=g) * (0.08 if p.ndim == 2 else 0.3) + (1.0 if "norm" in n and n.endswith("weight") else 0.0)))
+        images = rb(torch.rand(B, S, 3, H, W, generator=g))
+        with torch.no_grad():
+            outs, start = agg(images)
+        cases.append({"depth": depth, "aa_block_size": bs, "B": B, "S": S, "H": H, "W": W, "embed_dim": 128, "num_heads": 2, "mlp_ratio": 2.0,
+                      "images": images.to(torch.bfloat16), "params": {k: v.detach().to(torch.bfloat16) for k, v in agg.state_dict().items()},
+                      "outputs": [o.clone() for o in outs], "patch_start_idx": start})
+    torch.save(cases, os.path.join(HERE, "vggt_aggregator.pt"))
+    print("vggt_aggregator.pt:", [(c["aa_block_size"], len(c["outputs"]), tuple(c["outputs"][0].shape)) for c in cases])
+
+
 def golden_preprocess():
     """tests/golden/preprocess.npz: the VGGT input preprocessing, utils/model_utils.py:16-85.  That module imports torchvision (not
     installed here), so it cannot be imported as a whole; its one non-trivial step is PIL's bicubic `Image.resize` (:51), which IS
@@ -446,4 +480,5 @@ if __name__ == "__main__":
     golden_scorer()
     golden_scorer2()
     golden_vggt_attention()
+    golden_vggt_aggregator()
     golden_preprocess()

@@ -63,3 +63,28 @@ def test_frame_and_global_blocks_match_reference_module_outputs(gold):
         named = dict(b.named_parameters())
         for k in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.bias", "mlp.fc2.bias"):
             _close(named[k].grad, gp[k], 0.03, k)
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_aggregator_matches_reference_module_outputs(case):
+    """videogpa_amd.vggt.Aggregator (special tokens, positions, aa_block_num x aa_order x aa_block_size loop on the HIP blocks) loaded from the
+    REFERENCE aggregator's own state dict, against that module's outputs (tests/golden/vggt_aggregator.pt: vggt/models/aggregator.py imported,
+    patch_embed="conv"; aa_block_size 1 and 2): every per-depth [B, S, P, 2C] intermediate within 2 % of its range and cosine >= 0.999."""
+    from videogpa_amd.vggt import Aggregator
+    c = torch.load(os.path.join(HERE, "golden", "vggt_aggregator.pt"))[case]
+    agg = Aggregator(img_size=c["H"], patch_size=14, embed_dim=c["embed_dim"], depth=c["depth"], num_heads=c["num_heads"], mlp_ratio=c["mlp_ratio"],
+                     num_register_tokens=4, patch_embed="conv", aa_block_size=c["aa_block_size"], qk_norm=True, rope_freq=100, init_values=0.01)
+    agg.load_state_dict({k: v.float() for k, v in c["params"].items()}, strict=True)       # the reference's names, strictly
+    agg = agg.to(device="cuda", dtype=torch.bfloat16).eval()
+    with torch.no_grad():
+        outs, start = agg(c["images"].cuda().float())
+    assert start == c["patch_start_idx"] and len(outs) == len(c["outputs"])
+    for i, (o, r) in enumerate(zip(outs, c["outputs"])):
+        assert o.shape == r.shape
+        _close(o, r, 0.02, f"depth {i}")
+    agg.train()                                   # training mode checkpoints every block, like the reference: same values
+    x = c["images"].cuda().float().requires_grad_(True)
+    outs_t, _ = agg(x)
+    outs_t[-1].float().sum().backward()
+    assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
+    _close(outs_t[-1], c["outputs"][-1], 0.02, "training-mode last depth")

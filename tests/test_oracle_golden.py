@@ -166,6 +166,26 @@ def test_vggt_frame_global_block_pair_oracle_matches_reference(golden_dir):
                 assert (p[k].grad - g).abs().max().item() <= 5e-5 * g.abs().max().item() + 2e-6, k
 
 
+def test_vggt_aggregator_oracle_matches_reference(golden_dir):
+    """oracle/vggt.py::aggregator against vggt/models/aggregator.py::Aggregator imported by make_golden.py (patch_embed="conv", aa_block_size 1 and 2):
+    every per-depth [frame | global] intermediate to 3e-5 of its range, the patch start index, and the special-token assembly -- the first frame of
+    each sequence carries camera / register entry 0, the others entry 1 -- checked on the host-side product helpers as well."""
+    from oracle import vggt as ov
+    from videogpa_amd.vggt import PositionGetter, slice_expand_and_flatten
+    cases = torch.load(os.path.join(golden_dir, "vggt_aggregator.pt"))
+    assert [c["aa_block_size"] for c in cases] == [1, 2]
+    for c in cases:
+        p = {k: v.float() for k, v in c["params"].items()}
+        outs, start = ov.aggregator(c["images"].float(), p, c["num_heads"], c["depth"], 14, aa_block_size=c["aa_block_size"])
+        assert start == c["patch_start_idx"] == 5 and len(outs) == len(c["outputs"]) == c["depth"]
+        for o, r in zip(outs, c["outputs"]):
+            assert o.shape == r.shape and (o - r).abs().max().item() <= 3e-5 * r.abs().max().item()
+        t = slice_expand_and_flatten(p["register_token"], c["B"], c["S"]).view(c["B"], c["S"], 4, -1)
+        assert torch.equal(t[:, 0], p["register_token"][:, 0].expand(c["B"], -1, -1)) and torch.equal(t[:, 1:], p["register_token"][:, 1:2].expand(c["B"], c["S"] - 1, -1, -1))
+    pos = PositionGetter()(2, 2, 3, "cpu")
+    assert pos.shape == (2, 6, 2) and pos[0].tolist() == [[0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [1, 2]]
+
+
 def test_preprocess_oracle_matches_pil_fixture(golden_dir):
     """oracle/preprocess.py (Pillow's 8-bit bicubic resample restated + utils/model_utils.py:36-71) against the fixture made by
     calling PIL itself: bit-exact, every case (down / up scaling, crop, pad, unchanged axis, both round-half-to-even directions)."""

@@ -7,6 +7,9 @@ checkpoints load by name:
                                                                 fused into the QK-norm kernel, rope_mode 1)
     Block                    vggt/layers/block.py:30-108      (norm1, attn, ls1, norm2, mlp.fc1 / fc2, ls2; forward(x, pos=None))
     alternating_attention    vggt/models/aggregator.py:236-306 (frame attention on (B*S, P, C), global attention on (B, S*P, C))
+    Aggregator               vggt/models/aggregator.py:25-258  (camera / register tokens, positions, aa_block_num x aa_order loop, list of concatenated
+                                                                intermediates; state-dict names patch_embed.*, frame_blocks.N.*, global_blocks.N.*,
+                                                                camera_token, register_token)
 
 Unlike the CogVideoX attention (un-vendored diffusers), this code is IN the reference tree, so the kernels behind it are pinned
 against reference outputs: tests/golden/vggt_attention.pt, tests/test_gpu_vggt.py.  The backbone is frozen in the reference's use
@@ -114,3 +117,124 @@ def alternating_attention(tokens, frame_blocks, global_blocks, B, S, pos=None, a
             inter[kind] = tokens.reshape(B, S, P, C)
         outs.append(torch.cat([inter["frame"], inter["global"]], dim=-1))
     return outs, tokens
+
+
+class PositionGetter:
+    """vggt/layers/rope.py:24-57: (y, x) grid coordinates of the patches, [batch, height * width, 2] integer, cached per grid size"""
+
+    def __init__(self):
+        self.position_cache = {}
+
+    def __call__(self, batch_size, height, width, device):
+        key = (height, width, str(device))
+        if key not in self.position_cache:
+            yy, xx = torch.meshgrid(torch.arange(height, device=device), torch.arange(width, device=device), indexing="ij")
+            self.position_cache[key] = torch.stack([yy.reshape(-1), xx.reshape(-1)], dim=-1)
+        return self.position_cache[key][None].expand(batch_size, -1, -1).clone()
+
+
+class PatchEmbed(nn.Module):
+    """vggt/layers/patch_embed.py:25-78 (the aggregator's patch_embed="conv" form): Conv2d with kernel = stride = patch, flattened row-major"""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = nn.Identity()
+
+    def forward(self, x):
+        ph, pw = self.patch_size
+        if x.shape[-2] % ph or x.shape[-1] % pw:
+            raise AssertionError(f"input image size {tuple(x.shape[-2:])} is not a multiple of the patch size {self.patch_size}")
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+def slice_expand_and_flatten(token_tensor, B, S):
+    """vggt/models/aggregator.py:309-331: a (1, 2, X, C) special token -> (B*S, X, C): entry 0 for the first frame of every sequence, entry 1 for the
+    other S - 1 frames"""
+    first = token_tensor[:, 0:1].expand(B, 1, *token_tensor.shape[2:])
+    rest = token_tensor[:, 1:2].expand(B, S - 1, *token_tensor.shape[2:])
+    return torch.cat([first, rest], dim=1).reshape(B * S, *token_tensor.shape[2:])
+
+
+class Aggregator(nn.Module):
+    """vggt/models/aggregator.py:25-258 on the HIP attention path: `forward(images [B, S, 3, H, W] in [0, 1]) -> (list of [B, S, P, 2C] per depth,
+    patch_start_idx)`.  Constructor arguments, parameter names and the order of operations are the reference's, so an aggregator state dict loads with
+    load_state_dict.  patch_embed: "conv" builds the reference's PatchEmbed; the DINOv2 backbones ("dinov2_vitl14_reg", ...) are third-party networks
+    outside this path -- pass the constructed module instead (anything mapping [B*S, 3, H, W] to patch tokens [B*S, N, C] or to a dict carrying
+    "x_norm_patchtokens"), it is registered under the same name `patch_embed`."""
+
+    def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4.0, num_register_tokens=4, block_fn=Block,
+                 qkv_bias=True, proj_bias=True, ffn_bias=True, patch_embed="dinov2_vitl14_reg", aa_order=("frame", "global"), aa_block_size=1,
+                 qk_norm=True, rope_freq=100, init_values=0.01):
+        super().__init__()
+        if isinstance(patch_embed, nn.Module):
+            self.patch_embed = patch_embed
+        elif "conv" in patch_embed:
+            self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=3, embed_dim=embed_dim)
+        else:
+            raise NotImplementedError(f"patch_embed={patch_embed!r}: the DINOv2 backbone is a third-party network outside this path; construct it and pass "
+                                      "the module as patch_embed=")
+        self.rope = RotaryPositionEmbedding2D(frequency=rope_freq) if rope_freq > 0 else None
+        self.position_getter = PositionGetter() if self.rope is not None else None
+        mk = lambda: block_fn(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, proj_bias=proj_bias, ffn_bias=ffn_bias,
+                              init_values=init_values, qk_norm=qk_norm, rope=self.rope)
+        self.frame_blocks = nn.ModuleList([mk() for _ in range(depth)])
+        self.global_blocks = nn.ModuleList([mk() for _ in range(depth)])
+        self.depth, self.aa_order, self.patch_size, self.aa_block_size = depth, list(aa_order), patch_size, aa_block_size
+        if depth % aa_block_size != 0:
+            raise ValueError(f"depth ({depth}) must be divisible by aa_block_size ({aa_block_size})")
+        self.aa_block_num = depth // aa_block_size
+        # two camera tokens and two sets of register tokens: one for the first frame, one for the rest
+        self.camera_token = nn.Parameter(torch.randn(1, 2, 1, embed_dim))
+        self.register_token = nn.Parameter(torch.randn(1, 2, num_register_tokens, embed_dim))
+        self.patch_start_idx = 1 + num_register_tokens
+        nn.init.normal_(self.camera_token, std=1e-6)
+        nn.init.normal_(self.register_token, std=1e-6)
+        self.register_buffer("_resnet_mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1), persistent=False)
+        self.register_buffer("_resnet_std", torch.tensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1), persistent=False)
+        self.use_reentrant = False
+
+    def _run(self, blocks, idx, tokens, pos):
+        if self.training and torch.is_grad_enabled():      # the reference checkpoints every block in training mode (:268-271, :292-295)
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(blocks[idx], tokens, pos, use_reentrant=self.use_reentrant)
+        return blocks[idx](tokens, pos=pos)
+
+    def forward(self, images):
+        B, S, C_in, H, W = images.shape
+        if C_in != 3:
+            raise ValueError(f"Expected 3 input channels, got {C_in}")
+        images = ((images - self._resnet_mean) / self._resnet_std).reshape(B * S, C_in, H, W)
+        patch_tokens = self.patch_embed(images.to(next(self.frame_blocks.parameters()).dtype))
+        if isinstance(patch_tokens, dict):
+            patch_tokens = patch_tokens["x_norm_patchtokens"]
+        tokens = torch.cat([slice_expand_and_flatten(self.camera_token, B, S).to(patch_tokens.dtype),
+                            slice_expand_and_flatten(self.register_token, B, S).to(patch_tokens.dtype), patch_tokens], dim=1)
+        pos = None
+        if self.rope is not None:
+            pos = self.position_getter(B * S, H // self.patch_size, W // self.patch_size, device=images.device)
+            if self.patch_start_idx > 0:      # special tokens sit at position 0, the patch grid starts at 1 (:215-224)
+                pos = torch.cat([pos.new_zeros(B * S, self.patch_start_idx, 2), pos + 1], dim=1)
+        _, P, C = tokens.shape
+        tokens = tokens.contiguous()
+        fi = gi = 0
+        out = []
+        for _ in range(self.aa_block_num):
+            inter = {}
+            for kind in self.aa_order:
+                if kind not in ("frame", "global"):
+                    raise ValueError(f"Unknown attention type: {kind}")
+                shape = (B * S, P) if kind == "frame" else (B, S * P)
+                tokens = tokens.reshape(*shape, C)
+                pk = None if pos is None else pos.reshape(*shape, 2)
+                got = []
+                for _ in range(self.aa_block_size):
+                    if kind == "frame":
+                        tokens, fi = self._run(self.frame_blocks, fi, tokens, pk), fi + 1
+                    else:
+                        tokens, gi = self._run(self.global_blocks, gi, tokens, pk), gi + 1
+                    got.append(tokens.reshape(B, S, P, C))
+                inter[kind] = got
+            out += [torch.cat([f, g], dim=-1) for f, g in zip(inter["frame"], inter["global"])]
+        return out, self.patch_start_idx
