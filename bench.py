@@ -37,7 +37,7 @@ TEXT_LEN = 226
 # live per-kernel HIP events (ops.KernelTimer): every launch during the first TIMER_FULL_STEPS timed steps, afterwards only the attention kernels
 # the roofline objects are computed from -- event packets between ALL ~1500 launches of a step cost 1.3 % of it
 TIMER_FULL_STEPS = 3
-TIMER_ALWAYS = ("attn_fwd_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn128_fwd", "attn128_bwd")
+TIMER_ALWAYS = ("attn_fwd_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn128_fwd", "attn128_fwd_f8", "attn128_bwd")
 
 # BASELINE.json configs that fit a bench line (SURVEY section 8 sizes).  cfg2 is the headline the metric is quoted on.
 CONFIGS = {
@@ -51,7 +51,7 @@ CONFIGS = {
                  label="BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t=2), 81f x 768x1360 (21 latent frames, even-cropped to 20)"),
     "cfg5": dict(model="WAN22_TI2V_5B", frames=21, height=44, width=80, checkpoint=False, cond=True,
                  label="BASELINE configs[4]: Wan2.2-TI2V-5B (30 blocks, dim 3072, 24x128 heads, ffn 14336, text 512), 81f x 704x1280 -> latent 48x21x44x80, "
-                       "e4m3 feed-forward GEMMs (fp8 MFMA path), bf16 attention and LoRA-carrying projections"),
+                       "fp8 MFMA path = e4m3 self-attention forward (hand-written kernel) + e4m3 feed-forward GEMMs; bf16 attention backward and LoRA-carrying projections"),
 }
 WAN_TEXT_LEN = 512
 
@@ -186,8 +186,8 @@ def add_kernel_report(out, ops, steps, ms, use_pmc=True):
             n_st = s.get("steps") or steps            # kernels outside the roofline set are sampled on the first timed steps only (ops.KernelTimer)
             k = {"launches_per_step": s["launches"] / n_st, "avg_ms": s["avg_ms"], "total_ms_per_step": s["total_ms"] / n_st, "timed_steps": n_st}
             if s["unit"] == "flop":
-                peak = PEAK_FP8_DENSE_TFLOPS if "fp8" in name else PEAK_BF16_DENSE_TFLOPS
-                k.update(bound="mfma", algorithmic_flops_per_launch=s["work_per_launch"], achieved_tflops=rate / 1e12, frac=rate / 1e12 / peak)
+                peak = PEAK_FP8_DENSE_TFLOPS if ("fp8" in name or name.endswith("_f8")) else PEAK_BF16_DENSE_TFLOPS      # e4m3 kernels are priced against the fp8 peak
+                k.update(bound="mfma", algorithmic_flops_per_launch=s["work_per_launch"], achieved_tflops=rate / 1e12, frac=rate / 1e12 / peak, peak_tflops=peak)
             else:
                 k.update(bound="hbm", algorithmic_bytes_per_launch=s["work_per_launch"], achieved_gbs=rate / 1e9,
                          frac=rate / 1e9 / PEAK_HBM_GBS)
@@ -212,7 +212,7 @@ def add_kernel_report(out, ops, steps, ms, use_pmc=True):
         def roof(name):
             k = kernels[name]
             r = {"kernel": name, "bound": k["bound"], "achieved": k.get("achieved_tflops", k.get("achieved_gbs")),
-                 "peak": PEAK_BF16_DENSE_TFLOPS if k["bound"] == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if k["bound"] == "mfma" else "GB/s",
+                 "peak": k.get("peak_tflops", PEAK_BF16_DENSE_TFLOPS) if k["bound"] == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if k["bound"] == "mfma" else "GB/s",
                  "frac": k["frac"], "avg_launch_ms": k["avg_ms"], "share_of_step": k["total_ms_per_step"] / ms,
                  "traffic": pmc_all.get(name, {}).get("hbm_bytes_per_launch")}
             for key in ("mfma_busy", "clock_mhz"):        # from the round's PMC pass (tools/profile_round.sh), when present
@@ -222,7 +222,7 @@ def add_kernel_report(out, ops, steps, ms, use_pmc=True):
                 r["pmc_source"] = pmc_source
             return r
         if kd["bound"] == "mfma":
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["achieved_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS,
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["achieved_tflops"], "peak": kd.get("peak_tflops", PEAK_BF16_DENSE_TFLOPS),
                                "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "avg_launch_ms": kd["avg_ms"],
                                "note": "largest hand-written kernel of the step; the vendor GEMMs are listed under kernels"}
             for key in ("mfma_busy", "clock_mhz"):
@@ -318,7 +318,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
         torch.set_default_dtype(prev)
     with torch.no_grad():
         torch.nn.init.normal_(model.head.head.weight, std=0.02)      # upstream zero-inits the output layer: give the loss a signal
-    model.enable_fp8(not args.no_fp8)
+    model.enable_fp8(not args.no_fp8, attention=not (args.no_fp8 or args.no_fp8_attn))
     trainer = WanDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2.0 * args.rank_r, "accumulate_grad_batches": 1, "seed": 1234,
                              "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": stride}, model)
     gB = torch.Generator(device=dev).manual_seed(1)
@@ -359,12 +359,14 @@ def main_wan(args, C, world, rank, dev, force_dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     if rank == 0:
-        named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8) == (30, C["frames"], C["height"], C["width"], 64, False, False)
+        named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8, args.no_fp8_attn) == (30, C["frames"], C["height"], C["width"], 64, False, False, False)
         ms = dt / args.steps * 1e3
         out = {
             "metric": "DPO preference-pair steps/sec, Wan2.2-TI2V-5B 81f@704x1280", "value": world * args.steps / dt, "unit": "pair-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.no_fp8 else "bf16 (attention, LoRA-carrying projections) + fp8 e4m3 (feed-forward GEMMs)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.no_fp8 else ("bf16 (attention, LoRA-carrying projections) + fp8 e4m3 (feed-forward GEMMs)" if args.no_fp8_attn else
+                                                 "fp8 e4m3 (self-attention forward: hand-written MFMA kernel; feed-forward GEMMs) + bf16 (attention backward, cross-attention, "
+                                                 "LoRA-carrying projections)"),
             "data": "synthetic",
             "config": {"workload": (C["label"] + " -> " if named else "NOT a BASELINE config (debug flags): Wan2.2-shaped denoiser, ")
                                    + f"paired latents 2 x [1,48,{F_},{H_},{W_}], {L_tok} tokens, {layers} blocks, LoRA r={args.rank_r} on q/k/v/o of self- and "
@@ -398,7 +400,8 @@ def main():
     ap.add_argument("--no-checkpoint", dest="checkpoint", action="store_false", help="keep every block's activations (overrides a config's default recompute)")
     ap.add_argument("--checkpoint-stride", type=int, default=None, help="with --checkpoint: recompute only every k-th block (1 = all, like the reference)")
     ap.add_argument("--lean", action="store_true", default=None, help="lean activations: the LN output and the normalised q / k are made again in the backward (23 %% fewer saved bytes per block)")
-    ap.add_argument("--no-fp8", action="store_true", help="cfg5 only: bf16 feed-forward GEMMs instead of the e4m3 path")
+    ap.add_argument("--no-fp8", action="store_true", help="cfg5 only: bf16 feed-forward GEMMs and bf16 attention instead of the e4m3 paths")
+    ap.add_argument("--no-fp8-attn", action="store_true", help="cfg5 only: keep the e4m3 feed-forward but run the self-attention forward in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (1 GPU, cfg2, no debug flags) also measures cfg3 / cfg4 / cfg5 for 3 steps each "

@@ -230,6 +230,15 @@ size_t vgpa_attn128_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq);
 int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                          const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
                          void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* The head_dim-128 forward on OCP-e4m3 matrix operands (BASELINE configs[4] "fp8 MFMA path"): q (with scale * log2 e folded in), k and v are quantised
+ * with one power-of-two scale per (batch, head) and tensor, v transposed, by two prep kernels; both products run as v_mfma_scale_f32_32x32x64_f8f6f4
+ * with the scales -- and a per-tile, per-row power of two for the softmax weights -- on the instruction's E8M0 operands; row sums and lse2 stay fp32.
+ * Arguments and results as vgpa_attn128_fwd; the workspace (>= vgpa_attn128_fwd_f8_workspace_bytes, 256-byte aligned) is REQUIRED and is scratch.
+ * Forward only: the backward (vgpa_attn128_bwd) runs on the bf16 operands with this call's lse2. */
+size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int64_t Sq, int64_t Skv);
+int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
+                            const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
+                            void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* workspace (vgpa_attn128_bwd_workspace_bytes): delta + the statistics planes.  dkv_mode -1 = automatic (w1 dK/dV kernel from 1024 queries on),
  * 0 = compiler-scheduled kernel, 1 = w1 kernel */
 size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq);

@@ -75,6 +75,85 @@ def test_attention128_w1_forward_long_keys_vs_fp64(B, H, Sq, Skv):
     assert (o.float() - o2.float()).abs().max().item() <= 2 ** -7 * ro.abs().max().item()
 
 
+def _ref_e4m3(q, k, v, scale):
+    """fp64 attention on the operands the e4m3 forward really multiplies: q * scale * log2(e), k and v rounded to e4m3 after a power-of-two scale per
+    (batch, head) and tensor (csrc/attention_hd128.hip attn128_f8_quant_kernel); P is left unquantised (its e4m3 rounding is the remaining difference)"""
+    c = scale * 1.4426950408889634
+
+    def q8(t, mul=1.0):
+        t = t.float() * mul
+        amax = t.abs().amax(dim=(2, 3), keepdim=True)
+        e = torch.ceil(torch.log2(amax / 448.0))
+        sc = torch.exp2(e)
+        return (t / sc).to(torch.float8_e4m3fn).double() * sc.double()
+    s2 = q8(q, c) @ q8(k).transpose(-1, -2)                       # log2 units
+    p = torch.softmax(s2 * 0.6931471805599453, dim=-1)
+    return p @ q8(v), torch.logsumexp(s2 * 0.6931471805599453, -1) / 0.6931471805599453
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,qmul,vmean", [(1, 2, 1024, 1024, 1.0, 0.0), (1, 3, 700, 1500, 1.0, 0.0), (2, 2, 1030, 1091, 1.0, 0.0), (1, 1, 64, 4096, 1.0, 0.0),
+                                                   (1, 2, 512, 4096, 0.1, 2.0), (1, 2, 300, 2048, 3.0, 0.5)])
+def test_attention128_e4m3_forward_vs_fp64(B, H, Sq, Skv, qmul, vmean):
+    """vgpa_attn128_fwd_f8 (BASELINE configs[4] "fp8 MFMA path": both products of the forward as v_mfma_scale_f32_32x32x64_f8f6f4) at self-attention
+    shapes with ragged query / key tails, on the model's token-major views.  Two references, two stated tolerances:
+      (a) fp64 attention over the SAME e4m3-rounded q, k, v (power-of-two scale per head): what is left is the e4m3 rounding of the softmax weights
+          (2^-4 relative per weight: 2.6 % of a noise-like output, measured) and fp32 accumulation -- output within 6 % of the tensor's range, cosine
+          >= 0.9993, lse2 (made from the unquantised weights) within 2e-3;
+      (b) plain fp64 attention on the bf16 inputs: the price of e4m3 itself -- with unit-normal q and k a score carries an error of ~0.05 (|q| |k| d^-1/2
+          times 2^-4 / sqrt(d)), i.e. ~5 % per weight: output cosine >= 0.995 and relative error <= 12 % for random v (a noise-like sum), <= 1 % for the
+          diffuse case with a coherent v."""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(Sq * 7 + Skv)
+    q = (qmul * torch.randn(B, Sq, H, 128, device="cuda", generator=g)).bfloat16().permute(0, 2, 1, 3)
+    k = torch.randn(B, Skv, H, 128, device="cuda", generator=g).bfloat16().permute(0, 2, 1, 3)
+    v = (torch.randn(B, Skv, H, 128, device="cuda", generator=g) + vmean).bfloat16().permute(0, 2, 1, 3)
+    scale = 128 ** -0.5
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=True)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all() and o.permute(0, 2, 1, 3).is_contiguous()
+    r8, l8 = _ref_e4m3(q, k, v, scale)
+    ro = torch.softmax((q.double() @ k.double().transpose(-1, -2)) * scale, dim=-1) @ v.double()
+
+    def rel(a, r):
+        return float((a.double() - r).norm() / r.norm())
+
+    def cos(a, r):
+        a, r = a.double().flatten(), r.flatten()
+        return float(a @ r / (a.norm() * r.norm()))
+    assert (o.double() - r8).abs().max().item() <= 0.06 * r8.abs().max().item() and cos(o, r8) >= 0.9993, ((o.double() - r8).abs().max().item() / r8.abs().max().item(), cos(o, r8))
+    assert (lse.double() - l8).abs().max().item() <= 2e-3, (lse.double() - l8).abs().max().item()
+    assert cos(o, ro) >= 0.995 and rel(o, ro) <= (0.01 if vmean >= 2.0 else 0.12), (cos(o, ro), rel(o, ro))
+    # the same call is deterministic (atomicMax statistics only): the frozen-reference pass and the policy pass at B = 0 must agree bit for bit
+    o2, lse2 = ops.attention128_fwd_raw(q, k, v, scale, f8=True)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+
+
+def test_attention128_e4m3_outlier_rows_and_short_sweeps():
+    """a 40x query row (bound above 160 -> strip flagged, redone in bf16), a 40x key row (every bound loose), and a 512-key sweep (below
+    ATTN128_F8_MIN_KEYS: the bf16 kernels serve it -- the Wan2.2 cross-attention over the text tokens)"""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(78)
+    B, H, Sq, Skv = 1, 2, 600, 1200
+    scale = 128 ** -0.5
+    for which in ("q", "k"):
+        q = torch.randn(B, H, Sq, 128, device="cuda", generator=g).bfloat16()
+        k = torch.randn(B, H, Skv, 128, device="cuda", generator=g).bfloat16()
+        v = torch.randn(B, H, Skv, 128, device="cuda", generator=g).bfloat16()
+        if which == "q":
+            q[0, 0, 300] *= 40
+        else:
+            k[0, 1, 17] *= 40
+        o, _ = ops.attention128_fwd_raw(q, k, v, scale, f8=True)
+        ro = torch.softmax((q.double() @ k.double().transpose(-1, -2)) * scale, dim=-1) @ v.double()
+        assert torch.isfinite(o).all()
+        a, r = o.double().flatten(), ro.flatten()
+        assert float(a @ r / (a.norm() * r.norm())) >= 0.995, which
+    q = torch.randn(1, 2, 300, 128, device="cuda", generator=g).bfloat16()
+    k, v = (torch.randn(1, 2, 512, 128, device="cuda", generator=g).bfloat16() for _ in range(2))
+    o8, l8 = ops.attention128_fwd_raw(q, k, v, scale, f8=True)
+    ob, lb = ops.attention128_fwd_raw(q, k, v, scale)
+    assert torch.equal(o8, ob) and torch.equal(l8, lb)
+
+
 def test_attention128_w1_kernels_on_token_major_views():
     """the layout the Wan model uses: [B, S, H, 128] storage (projection outputs) viewed as [B, H, S, 128], long enough for all three w1 kernels"""
     from videogpa_amd import ops

@@ -169,6 +169,53 @@ def test_wan_model_fp8_feed_forward_stays_close_to_the_oracle():
             _close(got, leaves[name][idx].grad, f"{name}.{which}", tol=0.15, cos_min=0.98)
 
 
+def test_wan_model_e4m3_self_attention_stays_close_to_the_oracle():
+    """enable_fp8(False, attention=True): the self-attention FORWARD on e4m3 operands (csrc/attention_hd128.hip attn128_fwd_f8_kernel) in a model long
+    enough for it (1152 tokens >= ops.ATTN128_F8_MIN_KEYS; the 32-key cross-attention stays bf16), backward on bf16 operands with the e4m3 forward's
+    lse2.  Against the fp64 oracle: outputs cosine >= 0.995 / 6 % of range, every LoRA gradient (lora_A and lora_B, both attentions) cosine >= 0.98 /
+    12 % of range -- e4m3 scores carry ~0.05 of noise each (tests/test_gpu_wan_kernels.py::test_attention128_e4m3_forward_vs_fp64), which the bf16
+    path does not have (its bounds in this file: 0.995 / 4-6 %).  The policy and the adapter-off reference pass use the same kernel, so at B = 0 they
+    agree bit for bit (loss = ln 2: tests/test_gpu_fullmodel.py at full size)."""
+    from videogpa_amd import ops
+    pm, state, lora = _build()
+    base = pm.get_base_model()
+    base.enable_fp8(False, attention=True)
+    assert all(b.self_attn.fp8_attn and not b.fp8_ffn for b in base.blocks)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    C, Fr, H, W = CFG["in_dim"], 3, 32, 48
+    x = [torch.randn(C, Fr, H, W, device="cuda", generator=g).bfloat16().float() for _ in range(2)]
+    L = Fr * (H // 2) * (W // 2)
+    assert L >= ops.ATTN128_F8_MIN_KEYS
+    t = torch.tensor([417.0, 902.0], device="cuda")[:, None].expand(2, L).clone()
+    t[:, : (H // 2) * (W // 2)] = 0.0
+    ctx = [torch.randn(n, CFG["text_dim"], device="cuda", generator=g).bfloat16() for n in (20, 32)]
+    gout = [torch.randn(CFG["out_dim"], Fr, H, W, device="cuda", generator=g) for _ in range(2)]
+    seen = []
+    orig = ops.attention128_fwd_raw
+
+    def spy(q, k, v, scale, o_pad=0, f8=False):
+        seen.append((k.shape[2], f8))
+        return orig(q, k, v, scale, o_pad, f8=f8)
+    ops.attention128_fwd_raw = spy
+    try:
+        out = pm(x, t=t, context=ctx, seq_len=L)
+    finally:
+        ops.attention128_fwd_raw = orig
+    assert (L, True) in seen and all(f8 == (n == L) for n, f8 in seen)          # self-attention e4m3, cross-attention (32 keys) bf16
+    sum((o * g_).sum() for o, g_ in zip(out, gout)).backward()
+    ref, leaves = _oracle(state, lora, x, t, ctx, L, gout)
+    worst = {"out_cos": 1.0, "grad_cos": 1.0}
+    for b in range(2):
+        _close(out[b], ref[b], f"out[{b}]", tol=0.06, cos_min=0.995)
+    for name, mod in lora.items():
+        for which, idx in (("A", 0), ("B", 1)):
+            got = (mod.lora_A if idx == 0 else mod.lora_B)["default"].weight.grad
+            _close(got, leaves[name][idx].grad, f"{name}.{which}", tol=0.12, cos_min=0.98)
+            a, r = got.double().flatten().cpu(), leaves[name][idx].grad.double().flatten().cpu()
+            worst["grad_cos"] = min(worst["grad_cos"], float(a @ r / (a.norm() * r.norm())))
+    print("e4m3 self-attention, worst LoRA gradient cosine vs fp64 oracle:", worst["grad_cos"])
+
+
 def test_wan_adapter_mount_scale_merge_as_the_generate_script_does(tmp_path):
     """generate/Wan2.2-TI2V-5B.py:53-71: PeftModel.from_pretrained on the engine's model, scaling *= lora_weight, merge_and_unload.  The merged
     plain model must reproduce the LoRA-active model at that weight (bf16 weight rounding of the merged delta: 3 % of range, cos >= 0.999)."""

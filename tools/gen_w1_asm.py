@@ -85,7 +85,7 @@ class Emitter:
 
 
 # ------------------------------------------------------------------------------------------------------ stream scheduling
-def schedule(em, mfmas, frag_issue, frag_need, valu, lead, pre_issued=(), post_issue=(), fill_first=()):
+def schedule(em, mfmas, frag_issue, frag_need, valu, lead, pre_issued=(), post_issue=(), fill_first=(), raw_after=None):
     """Emit one straight-line stretch: `mfmas` = list of (text, frag id or None); `frag_need[f]` = index of the first MFMA that
     reads fragment f; `frag_issue(f)` emits its LDS read(s) (tags them f).  Fragments are requested `lead` MFMAs ahead (those in
     `pre_issued` already are); `post_issue` = callables emitting the next stretch's first requests, placed in the last gaps.
@@ -146,6 +146,8 @@ def schedule(em, mfmas, frag_issue, frag_need, valu, lead, pre_issued=(), post_i
         if i < len(fixed):
             for t in fixed[i]:
                 em.raw(t)
+        for t in (raw_after or {}).get(i, ()):       # a (mostly branch-skipped) block pinned behind MFMA i: not part of the water-fill
+            em.raw(t)
         for item in gap_ds[i]:
             if callable(item):
                 item()
@@ -781,6 +783,167 @@ class Fwd128Loop:
         return em.text() + "\n"
 
 
+# ---------------------------------------------------------------------------------------------------- forward, head_dim 128, e4m3 operands
+MFMA8 = "v_mfma_scale_f32_32x32x64_f8f6f4"
+
+
+class Fwd128F8Loop:
+    """The head_dim-128 forward on OCP-e4m3 operands (csrc/attention_f8.hip; BASELINE configs[4] "fp8 MFMA path"): both products of a 64-key tile
+       run as v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 per instruction, 64 cycles: twice the bf16 matrix rate).  Per tile T, one straight-line block:
+         C(T-2): O^T[j][db] += V8^T P8            8 MFMAs (4 d-blocks x 2 q-blocks; contraction = the tile's 64 keys)
+         A(T)  : S[T&1][j][b] = -M[q] + K8 Q8^T   8 MFMAs (2 key blocks x 2 k-steps of 64 x 2 q-blocks)
+         B(T-1): p = exp2(S), tile sums, P8 = e4m3(p / 2^x)   ~180 VALU
+       Scales ride the instruction's E8M0 operands: 2^eq, 2^ek, 2^ev (one power of two per (batch, head) and tensor, made by the prep kernels) and, for P,
+       a power of two PER TILE AND QUERY ROW: x = exponent of the row's sum over the tile's 64 keys (both lane halves, one v_permlane32_swap) minus 8, so
+       every p / 2^x < 2^8 <= 448 whatever the distance between the row bound M and the true maximum -- no running maximum, and e4m3's 17 binades sit
+       right below each tile's own largest weight.  Row sums stay fp32 (of the unquantised p).
+       Operand layout of the instruction (measured, tools/f8_probe.hip): lane (i = lane % 32, h = lane / 32) holds row i of A (column i of B), bytes
+       0..15 = k in [16 h, 16 h + 16), bytes 16..31 = k in [32 + 16 h, 48 + 16 h); its scale operand covers k in [32 h, 32 h + 32) of row i.
+       Key order: row i of key block b is key 32 b + 16 ((i >> 2) & 1) + (i & 3) + 4 (i >> 3), so that score register r of lane half h' is key
+       32 b + 16 h' + r and the packed P8 bytes (16 b + r) are the B operand of the PV product against V8^T rows = d, columns = the tile's keys in order.
+       LDS ring: 4 slots of [K8 tile 64 x 128 B | V8^T tile 128 x 64 B] = 16 KiB; 16-B chunks of K row r at c ^ ((r >> 1) & 7), of V^T row d at
+       c ^ ((d >> 2) & 3) (both ds_read_b128 patterns conflict-free).  LDS-DMA one tile ahead (V8^T of tile T-2 is still being read when K8 of T is).
+       register map   a[0:127] O[j][db]   a[128:159] Q8 fragments [j][ks]   a[160:223] fragment ring: V^T[db] (4 x 8), K[b][ks] (4 x 8)
+                      v[0:127] S[p][j][b]   v[128:159] P8[p][j]   v[160:191] srcC tuples -M[j]   v[192:197] lane LDS offsets K[ks][u], V[u]
+                      v[200:203] LDS-DMA source offsets   v204 v205 l[j]   v[206:213] partial sums   v[214:217] E8M0 of x [p][j]   v218 v219 2^x
+                      v220 v221 v222 E8M0 of eq, ek, ev   v223 -inf   v224 16 h   v225 v226 -M[j]   v227 v228 temporaries"""
+
+    T0, LAK, LAV, VOFF, L, TP, XS, FS, EQ, EK, EV, NINF, HI16, NEGM, U, E = 160, 192, 196, 200, 204, 206, 214, 218, 220, 221, 222, 223, 224, 225, 227, 228
+    QF, FR = 128, 160
+    LEAD = KNOB.get("lead8", 6)
+
+    def S(self, p, j, b):
+        return 64 * p + 32 * j + 16 * b
+
+    def P8(self, p, j):
+        return 128 + 16 * p + 8 * j
+
+    def frag_reg(self, f):
+        return self.FR + 8 * f
+
+    def issue_frag(self, em, f, slotK, slotV, tag=None):
+        """f 0..3: V8^T d-block f of ring slot slotV; f 4..7: K8 (b, ks) = ((f - 4) >> 1, (f - 4) & 1) of ring slot slotK.  Two 16-byte reads each."""
+        tag = f if tag is None else tag
+        r = self.frag_reg(f)
+        for u in range(2):
+            if f < 4:
+                em.ds(f"ds_read_b128 {ar(r + 4 * u, 4)}, v{self.LAV + u} offset:{slotV * 16384 + 8192 + f * 2048}", tag)
+            else:
+                b, ks = (f - 4) >> 1, (f - 4) & 1
+                em.ds(f"ds_read_b128 {ar(r + 4 * u, 4)}, v{self.LAK + 2 * ks + u} offset:{slotK * 16384 + b * 4096}", tag)
+
+    def mfmas(self, pa, pc):
+        out = []
+        for db in range(4):
+            for j in range(2):
+                d = ar(64 * j + 16 * db, 16)
+                out.append((f"{MFMA8} {d}, {ar(self.frag_reg(db), 8)}, {vr(self.P8(pc, j), 8)}, {d}, v{self.EV}, v{self.XS + 2 * pc + j} op_sel_hi:[0,0,0]", db))
+        for b in range(2):
+            for ks in range(2):
+                for j in range(2):
+                    d = vr(self.S(pa, j, b), 16)
+                    c = vr(self.T0 + 16 * j, 16) if ks == 0 else d
+                    out.append((f"{MFMA8} {d}, {ar(self.frag_reg(4 + 2 * b + ks), 8)}, {ar(self.QF + 16 * j + 8 * ks, 8)}, {c}, v{self.EK}, v{self.EQ} op_sel_hi:[0,0,0]",
+                                4 + 2 * b + ks))
+        return out
+
+    def valu_ops(self, pb):
+        if "novalu" in ABLATE:
+            return []
+        ops = []
+        for j in range(2):
+            s = [self.S(pb, j, b) + r for b in range(2) for r in range(16)]          # byte order of the packed P8: 16 b + r
+            tp = [self.TP + 4 * j + k for k in range(4)]
+            # four partial sums; an add consumes values whose v_exp was issued at least four instructions earlier (gfx940 forwards a transcendental's
+            # result to the NEXT instruction only through a hazard wait state)
+            for i in range(0, 32, 4):
+                for k in range(4):
+                    ops.append(f"v_exp_f32 v{s[i + k]}, v{s[i + k]}")
+                    if i == 8:
+                        ops.append(f"v_add_f32 v{tp[k]}, v{s[k]}, v{s[4 + k]}")
+                    elif i > 8:
+                        ops.append(f"v_add_f32 v{tp[k]}, v{tp[k]}, v{s[i - 4 + k]}")
+            for k in range(4):
+                ops.append(f"v_add_f32 v{tp[k]}, v{tp[k]}, v{s[28 + k]}")
+            ops += [f"v_add_f32 v{tp[0]}, v{tp[0]}, v{tp[1]}", f"v_add_f32 v{tp[2]}, v{tp[2]}, v{tp[3]}", f"v_add_f32 v{tp[0]}, v{tp[0]}, v{tp[2]}",
+                    f"v_mov_b32 v{self.U}, v{tp[0]}", "s_nop 1", f"v_permlane32_swap_b32 v{self.U}, v{tp[0]}", "s_nop 0", f"v_add_f32 v{tp[0]}, v{tp[0]}, v{self.U}",
+                    f"v_add_f32 v{self.L + j}, v{self.L + j}, v{tp[0]}",                                    # l[j] += the row's sum over all 64 keys (both halves)
+                    f"v_frexp_exp_i32_f32 v{self.E}, v{tp[0]}",                                              # sum in [2^(e-1), 2^e)
+                    f"v_add_u32 v{self.E}, 119, v{self.E}",                                                  # E8M0 of 2^(e - 8)
+                    f"v_max_i32 v{self.XS + 2 * pb + j}, 1, v{self.E}",                                        # e + 119 <= 247 for any finite sum
+                    f"v_lshlrev_b32 v{self.FS + j}, 23, v{self.XS + 2 * pb + j}"]                           # the same power of two as an fp32 number
+            for w in range(8):
+                d = self.P8(pb, j) + w
+                ops.append(f"v_cvt_scalef32_pk_fp8_f32 v{d}, v{s[4 * w]}, v{s[4 * w + 1]}, v{self.FS + j}")
+                ops.append(f"v_cvt_scalef32_pk_fp8_f32 v{d}, v{s[4 * w + 2]}, v{s[4 * w + 3]}, v{self.FS + j} op_sel:[0,0,0,1]")
+        return ops
+
+    def mask_lines(self, b, krem, tmp, label):
+        """keys >= krem of key block b get -inf in the srcC tuples (score register r of lane half h = key 32 b + 16 h + r); skipped for full tiles"""
+        out = [f"s_cmp_ge_i32 {krem}, 64", f"s_cbranch_scc1 {label}"]
+        for r in range(16):
+            out += [f"s_sub_i32 {tmp}, {krem}, {32 * b + r}", f"v_cmp_lt_i32 vcc, v{self.HI16}, {tmp}"]
+            out += [f"v_cndmask_b32 v{self.T0 + 16 * j + r}, v{self.NINF}, v{self.NEGM + j}, vcc" for j in range(2)]
+        out += ["s_nop 1", f"{label}:"]
+        return out
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT, KREM, TMP = "%0", "%1", "%2", "%3"
+        RK, RV, KSTEP, VSTEP, WBASE, NITER, KREM0 = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]", "%[krem]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        em.raw(f"s_mov_b32 {KREM}, {KREM0}")
+        for i in range(128):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        em.raw(f"v_mov_b32 v{self.NINF}, 0xff800000")
+        for r in range(64, 128):                       # S[1]: the first B stage (tile -1) must produce p = 0
+            em.raw(f"v_mov_b32 v{r}, v{self.NINF}")
+        for r in list(range(128, 160)) + [self.L, self.L + 1]:
+            em.raw(f"v_mov_b32 v{r}, 0")
+        for r in range(self.XS, self.XS + 4):
+            em.raw(f"v_mov_b32 v{r}, 127")
+        for j in range(2):
+            for r in range(16):
+                em.raw(f"v_mov_b32 v{self.T0 + 16 * j + r}, v{self.NEGM + j}")
+        for f in range(4):
+            self.issue_frag(em, f, 0, 2, tag=("n", f))
+        em.raw("L_w1f8_loop_%=:")
+        for ph in range(4):
+            em.raw("s_waitcnt vmcnt(0)")
+            if "nosync" not in ABLATE:
+                em.raw("s_barrier")
+            dst = ((ph + 1) & 3) * 16384
+            fill = []
+            for k in range(4):
+                isV = k >= 2
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + (8192 if isV else 0) + (k & 1) * 1024}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {RV if isV else RK}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {VSTEP if isV else KSTEP}, v{self.VOFF + k}"])
+            pa = ph & 1
+            for ln in self.mask_lines(0, KREM, TMP, f"L_w1f8_m{2 * ph}_%="):
+                em.raw(ln)
+            need = {0: 0, 1: 2, 2: 4, 3: 6, 4: 8, 5: 10, 6: 12, 7: 14}
+            slotV_next = (ph - 1) & 3                    # C of the NEXT iteration reads V8^T of tile T - 1
+            post = [lambda f=f: self.issue_frag(em, f, 0, slotV_next, tag=("n", f)) for f in range(4)]
+            em.retag({("n", f): f for f in range(4)})
+            schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, ph, (ph - 2) & 3), need, self.valu_ops(pa ^ 1), self.LEAD,
+                     pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill, raw_after={11: self.mask_lines(1, KREM, TMP, f"L_w1f8_m{2 * ph + 1}_%=")})
+            em.raw(f"s_sub_i32 {KREM}, {KREM}, 64")
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if ph < 3:
+                em.raw("s_cbranch_scc1 L_w1f8_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1f8_loop_%=")
+        em.raw("L_w1f8_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 # ---------------------------------------------------------------------------------------------------------- dK, dV, head_dim 128
 class Dkv128Loop:
     """DkvLoop for head_dim 128 (csrc/attention_hd128.hip): ONE 32-key block per wave -- dK^T, dV^T (4 d-blocks each) and the K, V
@@ -1150,6 +1313,8 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_dkv_clobbers.inc": lambda: clobbers([(0, 223)], [(192, 223)]),
            "w1_fwd128_loop.inc": lambda: Fwd128Loop().generate(),
            "w1_fwd128_clobbers.inc": lambda: clobbers([(0, 127), (185, 185)], [(192, 255)]),
+           "w1_fwd128f8_loop.inc": lambda: Fwd128F8Loop().generate(),
+           "w1_fwd128f8_clobbers.inc": lambda: clobbers([(0, 191), (206, 219), (223, 223), (227, 228)], [(160, 223)]),
            "w1_dkv128_loop.inc": lambda: Dkv128Loop().generate(),
            "w1_dkv128_clobbers.inc": lambda: clobbers([(0, 127)], [(192, 255)]),
            "w1_dq128_loop.inc": lambda: Dq128Loop().generate(),

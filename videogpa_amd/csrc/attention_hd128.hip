@@ -793,6 +793,279 @@ extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v,
     return VGPA_OK;
 }
 
+// ===================================================================================================== forward on OCP-e4m3 operands
+// BASELINE configs[4] "fp8 MFMA path" (train/Wan2.2-TI2V-5B/03_train.py:189-242 calls the denoiser four times per pair; its self-attention is
+// 58 % of the cfg5 step).  Both products of the forward run as v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 matrix rate):
+//   prep 1  attn128_f8_amax_kernel : max |q|, |k|, |v| per (batch, head)                                   -> one power-of-two scale per tensor and head
+//   prep 2  attn128_f8_quant_kernel: q8 = e4m3(q c 2^-eq) [B,H,Sq,128], k8 = e4m3(k 2^-ek) [B,H,Skv,128], v8t = e4m3(v 2^-ev) TRANSPOSED [B,H,128,Lp],
+//                                     |q8 row|^2 (in the units of the scores) and max_k |k8 row|^2 for the row bound M[q] >= every score of the row
+//   main    attn128_fwd_f8_kernel  : tools/gen_w1_asm.py::Fwd128F8Loop (w1_fwd128f8_loop.inc) -- operand layout, key order, per-tile power-of-two P scale
+//                                     and the LDS image are documented there; this wrapper owns prologue, epilogue and the redo flags
+// e4m3 is a floating-point format (4 exponent bits: 17 binades), so one scale per tensor and head keeps every element's RELATIVE error at 2^-4; the scales
+// are powers of two because then they ride the instruction's E8M0 scale operands for free.  c = scale * log2(e) is folded into q8: the accumulators hold
+// the scores in log2 units.  Row sums stay fp32 of the unquantised weights; lse2 = M + log2(l) as in the bf16 kernels (the backward runs on bf16 operands).
+#define F8_SLOT_BYTES 16384
+#define F8_RING_BYTES (4 * F8_SLOT_BYTES)
+__device__ __forceinline__ int f8_exp_of(float amax) {   // the smallest e with amax * 2^-e <= 448 (e4m3's largest finite value)
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 0;
+    int e;
+    (void)frexpf(amax * (1.f / 448.f), &e);
+    return e;
+}
+__device__ __forceinline__ uint32_t f8_pack4(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+__device__ __forceinline__ float f8_norm2_4(uint32_t w) {   // sum of squares of the four e4m3 values of a dword
+    const float a = __builtin_amdgcn_cvt_f32_fp8((int)w, 0), b = __builtin_amdgcn_cvt_f32_fp8((int)w, 1), c = __builtin_amdgcn_cvt_f32_fp8((int)w, 2),
+                d = __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
+    return (a * a + b * b) + (c * c + d * d);
+}
+
+// stats[bh * 4 + {0, 1, 2}] = max |q|, |k|, |v| (bit patterns of non-negative floats order like unsigned integers)
+__global__ __launch_bounds__(256) void attn128_f8_amax_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, TStride sq,
+                                                                TStride sk, TStride sv, int Sq, int Skv, int H, unsigned* __restrict__ stats) {
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int which = 0; which < 3; ++which) {
+        const bf16_t* base = which == 0 ? Q + ((size_t)b * sq.b + (size_t)h * sq.h) : which == 1 ? K + ((size_t)b * sk.b + (size_t)h * sk.h) : V + ((size_t)b * sv.b + (size_t)h * sv.h);
+        const uint32_t rs = which == 0 ? sq.s : which == 1 ? sk.s : sv.s;
+        const int S = which == 0 ? Sq : Skv;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)S * 16; i += (int64_t)gridDim.x * 256) {   // 16 lanes per row, 16 B each
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(base + ((size_t)(i >> 4) * rs + (size_t)(i & 15) * 8)), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[which] = fmaxf(m[which], fabsf(f[j]));
+        }
+    }
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const float w = wave_max(m[which]);
+        if ((threadIdx.x & 63) == 0) atomicMax(stats + bh * 4 + which, __float_as_uint(w));
+    }
+}
+
+// one workgroup = 64 tokens of one (batch, head): thread t -> token t / 4, 32 features from 32 (t % 4)
+__global__ __launch_bounds__(256) void attn128_f8_quant_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, TStride sq,
+                                                                 TStride sk, TStride sv, int Sq, int Skv, int Lp, int H, float c, const unsigned* __restrict__ stats,
+                                                                 uint8_t* __restrict__ q8, uint8_t* __restrict__ k8, uint8_t* __restrict__ v8t,
+                                                                 float* __restrict__ qn2, unsigned* __restrict__ kmax2) {
+    __shared__ __attribute__((aligned(16))) uint8_t vt[128 * 68];   // the tile's V, e4m3, transposed: [d][token], pitch 68
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int tok = blockIdx.x * 64 + ((int)threadIdx.x >> 2), d0 = 32 * ((int)threadIdx.x & 3);
+    const int eq = f8_exp_of(__uint_as_float(stats[bh * 4]) * c), ek = f8_exp_of(__uint_as_float(stats[bh * 4 + 1])), ev = f8_exp_of(__uint_as_float(stats[bh * 4 + 2]));
+    float kn = 0.f;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const bf16_t* base = which == 0 ? Q + ((size_t)b * sq.b + (size_t)h * sq.h) : which == 1 ? K + ((size_t)b * sk.b + (size_t)h * sk.h) : V + ((size_t)b * sv.b + (size_t)h * sv.h);
+        const uint32_t rs = which == 0 ? sq.s : which == 1 ? sk.s : sv.s;
+        const int S = which == 0 ? Sq : Skv;
+        const float mul = which == 0 ? ldexpf(c, -eq) : ldexpf(1.f, which == 1 ? -ek : -ev);
+        uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        if (tok < S) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float f[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(base + ((size_t)tok * rs + (size_t)(d0 + 8 * g))), f);
+                w[2 * g] = f8_pack4(f[0] * mul, f[1] * mul, f[2] * mul, f[3] * mul);
+                w[2 * g + 1] = f8_pack4(f[4] * mul, f[5] * mul, f[6] * mul, f[7] * mul);
+            }
+        }
+        if (which < 2) {
+            float n2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) n2 += f8_norm2_4(w[g]);
+            n2 += __shfl_xor(n2, 1, 64);
+            n2 += __shfl_xor(n2, 2, 64);
+            n2 = ldexpf(n2, 2 * (which == 0 ? eq : ek));           // back in the tensor's own units (q: incl. c)
+            if (tok < S) {
+                uint8_t* dst = (which == 0 ? q8 : k8) + (((size_t)bh * S + tok) * 128 + d0);
+                *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<u32x4_t*>(dst + 16) = u32x4_t{w[4], w[5], w[6], w[7]};
+                if (which == 0 && d0 == 0) qn2[(size_t)bh * Sq + tok] = n2;
+                if (which == 1) kn = n2;
+            }
+        } else {   // V: bytes into the transposed LDS image (zeros for tokens past Skv: the padded columns of v8t must be finite)
+            const int tl = (int)threadIdx.x >> 2;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vt[(d0 + 4 * g + i) * 68 + tl] = (uint8_t)(w[g] >> (8 * i));
+        }
+    }
+    kn = wave_max(kn);
+    if ((threadIdx.x & 63) == 0 && kn > 0.f) atomicMax(kmax2 + bh, __float_as_uint(kn));
+    __syncthreads();
+    if (blockIdx.x * 64 < Lp) {
+        const int d = (int)threadIdx.x >> 1, half = (int)threadIdx.x & 1;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(vt + d * 68 + 32 * half);
+        uint8_t* dst = v8t + (((size_t)bh * 128 + d) * Lp + (size_t)blockIdx.x * 64 + 32 * half);
+        *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{src[0], src[1], src[2], src[3]};
+        *reinterpret_cast<u32x4_t*>(dst + 16) = u32x4_t{src[4], src[5], src[6], src[7]};
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void attn128_fwd_f8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ K8, const uint8_t* __restrict__ V8T,
+                                                                  const float* __restrict__ QN2, const unsigned* __restrict__ KMAX2, const unsigned* __restrict__ STATS,
+                                                                  bf16_t* __restrict__ O, float* __restrict__ LSE2, int* __restrict__ flags, TStride so, int Sq, int Skv,
+                                                                  int Lp, int H, int n_qt, float c) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[F8_RING_BYTES];   // slot = [K8 tile 64 x 128 B | V8^T tile 128 x 64 B]
+    const int vid = blockIdx.x;
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, m = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int q0 = (qt * 4 + wave) * 64;
+    const int eq = f8_exp_of(__uint_as_float(STATS[bh * 4]) * c), ek = f8_exp_of(__uint_as_float(STATS[bh * 4 + 1])), ev = f8_exp_of(__uint_as_float(STATS[bh * 4 + 2]));
+
+    // Q8 fragments: B operand of S^T = K8 Q8^T -- column q = lane % 32, bytes 0..15 = d 64 ks + 16 hi .., bytes 16..31 = d 64 ks + 32 + 16 hi ..
+    u32x4_t qf[2][2][2];
+    float nm[2];
+    const float kmax = sqrtf(__uint_as_float(KMAX2[bh]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int q = q0 + 32 * j + m;
+        q = q < Sq ? q : Sq - 1;
+        const uint8_t* row = Q8 + ((size_t)bh * Sq + q) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) qf[j][ks][u] = *reinterpret_cast<const u32x4_t*>(row + 64 * ks + 32 * u + 16 * hi);
+        nm[j] = -(sqrtf(QN2[(size_t)bh * Sq + q]) * kmax * 1.0009765625f);      // -M[q]: a hair above |q8 row| max |k8 row| >= every score of the row
+    }
+    {   // C of the first two iterations reads the V8^T halves of ring slots 2 and 3: make them finite (P8 = 0 there)
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int sl = 2; sl < 4; ++sl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(lds + sl * F8_SLOT_BYTES + 8192 + i * 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const W1Rsrc krs = w1_rsrc(K8 + (size_t)bh * Skv * 128, (uint32_t)Skv * 128u);                 // rows >= Skv read as zeros
+    const W1Rsrc vrs = w1_rsrc(V8T + (size_t)bh * 128 * Lp, 128u * (uint32_t)Lp);
+    // this wave moves pieces 2 wave, 2 wave + 1 of both tiles.  K8 piece p = rows 8p .. 8p+7 (lane -> row 8p + lane / 8, LDS chunk lane % 8 holds the
+    // row's 16-byte chunk (lane % 8) ^ ((row >> 1) & 7));  V8^T piece p = rows d 16p .. 16p+15 (lane -> d 16p + lane / 4, chunk (lane % 4) ^ ((d >> 2) & 3))
+    u32x4_t voff;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t kr = 8u * (uint32_t)(2 * wave + i) + (uint32_t)(lane >> 3);
+        voff[i] = kr * 128u + ((((uint32_t)lane & 7u) ^ ((kr >> 1) & 7u)) << 4);
+        const uint32_t vd = 16u * (uint32_t)(2 * wave + i) + (uint32_t)(lane >> 2);
+        voff[2 + i] = vd * (uint32_t)Lp + ((((uint32_t)lane & 3u) ^ ((vd >> 2) & 3u)) << 4);
+    }
+    const uint32_t kstep = __builtin_amdgcn_readfirstlane(64u * 128u), vstep = __builtin_amdgcn_readfirstlane(64u);
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds + (uint32_t)wave * 2048u);
+    w1_dma(wbase, krs, voff[0], 0u);                 // tile 0 -> ring slot 0
+    w1_dma(wbase + 1024u, krs, voff[1], 0u);
+    w1_dma(wbase + 8192u, vrs, voff[2], 0u);
+    w1_dma(wbase + 8192u + 1024u, vrs, voff[3], 0u);
+    voff[0] += kstep; voff[1] += kstep; voff[2] += vstep; voff[3] += vstep;
+
+    // lane-constant LDS read offsets: K8 row of key block b: 16 ((m >> 2) & 1) + (m & 3) + 4 (m >> 3)  (+ 32 b rows as an immediate), chunk 4 ks + 2 u + hi;
+    //                                 V8^T row d = m (+ 32 db as an immediate), chunk 2 u + hi
+    const uint32_t krow = 16u * (((uint32_t)m >> 2) & 1u) + ((uint32_t)m & 3u) + 4u * ((uint32_t)m >> 3);
+    u32x8_t la;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) la[2 * ks + u] = krow * 128u + ((((uint32_t)(4 * ks + 2 * u) + (uint32_t)hi) ^ ((krow >> 1) & 7u)) << 4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) la[4 + u] = (uint32_t)m * 64u + ((((uint32_t)(2 * u) + (uint32_t)hi) ^ (((uint32_t)m >> 2) & 3u)) << 4);
+    la[6] = la[7] = 0u;
+
+    const int nt = (Skv + 63) / 64;
+    const uint32_t niter = (uint32_t)(nt + 2);       // two extra steps drain the pipeline (A on zero-filled tiles with every key masked)
+    const uint32_t krem = (uint32_t)Skv;
+    const uint32_t hi16 = 16u * (uint32_t)hi;
+    const uint32_t e8q = (uint32_t)(127 + eq), e8k = (uint32_t)(127 + ek), e8v = (uint32_t)(127 + ev);
+    u32x16_t q0p, q1p;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                q0p[8 * ks + 4 * u + i] = qf[0][ks][u][i];
+                q1p[8 * ks + 4 * u + i] = qf[1][ks][u][i];
+            }
+    f32x16_t o[2][4];
+    u32x2_t lv;
+    uint32_t t0, t1, t2, t3;
+    asm volatile(
+#include "w1_fwd128f8_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "={a[0:15]}"(o[0][0]), "={a[16:31]}"(o[0][1]), "={a[32:47]}"(o[0][2]), "={a[48:63]}"(o[0][3]),
+          "={a[64:79]}"(o[1][0]), "={a[80:95]}"(o[1][1]), "={a[96:111]}"(o[1][2]), "={a[112:127]}"(o[1][3]), "={v[204:205]}"(lv), "+{v[200:203]}"(voff)
+        : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [krem] "s"(krem),
+          "{a[128:143]}"(q0p), "{a[144:159]}"(q1p), "{v[192:199]}"(la), "{v220}"(e8q), "{v221}"(e8k), "{v222}"(e8v), "{v224}"(hi16), "{v225}"(nm[0]), "{v226}"(nm[1])
+        : "memory", "scc", "vcc",
+#include "w1_fwd128f8_clobbers.inc"
+    );
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) asm volatile("" : "+v"(o[j][db]));
+
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float l = __uint_as_float(lv[j]);      // the loop adds the sum over all 64 keys of a tile in both lane halves
+        const float M = -nm[j];
+        const int q = q0 + 32 * j + m;
+        if (q < Sq) {
+            bad = bad || !(l >= W1H_L_MIN && l < INFINITY) || !(M <= W1H_M_MAX);
+            store_col128(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), o[j], 1.f / l, hi);
+            if (hi == 0) LSE2[(size_t)bh * Sq + q] = M + __builtin_amdgcn_logf(l);
+        }
+    }
+    if (__any(bad) && lane == 0) flags[vid] = 1;
+}
+
+static inline size_t f8_align(size_t x) { return (x + 255) / 256 * 256; }
+// workspace of vgpa_attn128_fwd_f8: [stats B H 4 | kmax2 B H | flags per 256-row strip] [|q8 row|^2] [q8] [k8] [v8t]
+extern "C" size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int64_t Sq, int64_t Skv) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return 0;
+    const int64_t Lp = (Skv + 63) / 64 * 64;
+    return f8_align((size_t)(B * H * 5 + B * H * ((Sq + 255) / 256)) * 4) + f8_align((size_t)(B * H * Sq) * 4) + f8_align((size_t)(B * H * Sq) * 128) +
+           f8_align((size_t)(B * H * Skv) * 128) + f8_align((size_t)(B * H * 128 * Lp));
+}
+// softmax(scale q k^T) v with e4m3 matrix operands (forward only: same arguments and results as vgpa_attn128_fwd; the workspace holds the quantised
+// copies and is scratch).  Strips the kernel flags (row sum near underflow, bound too large) are redone by the bf16 running-max kernel.
+extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
+                                       const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
+                                       void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !o || !lse2 || !workspace || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
+    if (!sok128(q_strides) || !sok128(k_strides) || !sok128(v_strides) || !sok128(o_strides) || !a16(q) || !a16(k) || !a16(v) || !a16(o)) return VGPA_ERR_INVALID;
+    if (!rok128(q_strides, B, H, Sq) || !rok128(k_strides, B, H, Skv) || !rok128(v_strides, B, H, Skv) || !rok128(o_strides, B, H, Sq)) return VGPA_ERR_INVALID;
+    if (ws_bytes < vgpa_attn128_fwd_f8_workspace_bytes(B, H, Sq, Skv) || ((uintptr_t)workspace & 255)) return VGPA_ERR_WORKSPACE;
+    const int64_t Lp = (Skv + 63) / 64 * 64, n_q256 = (Sq + 255) / 256, tasks256 = B * H * n_q256, n_qt = (Sq + 127) / 128, tasks = B * H * n_qt;
+    if (tasks >= ((int64_t)1 << 31) || B * H > 65535 || Skv * 128 >= ((int64_t)1 << 31) || 128 * Lp >= ((int64_t)1 << 31)) return VGPA_ERR_INVALID;
+    const float c = scale * LOG2E_F;
+    char* w = (char*)workspace;
+    const size_t head = f8_align((size_t)(B * H * 5 + tasks256) * 4);
+    unsigned* stats = (unsigned*)w;
+    unsigned* kmax2 = stats + B * H * 4;
+    int* flags = (int*)(kmax2 + B * H);
+    float* qn2 = (float*)(w + head);
+    uint8_t* q8 = (uint8_t*)qn2 + f8_align((size_t)(B * H * Sq) * 4);
+    uint8_t* k8 = q8 + f8_align((size_t)(B * H * Sq) * 128);
+    uint8_t* v8t = k8 + f8_align((size_t)(B * H * Skv) * 128);
+    if (hipMemsetAsync(workspace, 0, head, stream) != hipSuccess) return VGPA_ERR_LAUNCH;
+    VGPA_LAUNCH(attn128_f8_amax_kernel, dim3(32, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mk128(q_strides),
+                mk128(k_strides), mk128(v_strides), (int)Sq, (int)Skv, (int)H, stats);
+    const int64_t nblk = (Sq > Lp ? (Sq + 63) / 64 : Lp / 64);
+    VGPA_LAUNCH(attn128_f8_quant_kernel, dim3((unsigned)nblk, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                mk128(q_strides), mk128(k_strides), mk128(v_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, c, (const unsigned*)stats, q8, k8, v8t, qn2, kmax2);
+    VGPA_LAUNCH(attn128_fwd_f8_kernel, dim3((unsigned)tasks256), dim3(256), 0, stream, (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)v8t, (const float*)qn2,
+                (const unsigned*)kmax2, (const unsigned*)stats, (bf16_t*)o, lse2, flags, mk128(o_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, (int)n_q256, c);
+    VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
+                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
 // workspace: delta [B*H*Sq] + the statistics planes [B, H, 2, Sq] (fp32)
 extern "C" size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq) {
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;

@@ -867,8 +867,12 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
 ATTN128_W1 = _os.environ.get("VGPA_ATTN128_W1", "1") == "1"    # 0: the compiler-scheduled hd128 forward everywhere
 
 
-def attention128_fwd_raw(q, k, v, scale, o_pad=0):
+ATTN128_F8_MIN_KEYS = 1024      # below this the e4m3 forward's prep passes and pipeline fill do not pay (cross-attention over 512 text tokens stays bf16)
+
+
+def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False):
     """q [B,H,Sq,128], k / v [B,H,Skv,128] bf16 views (any batch / head / token strides, last dim contiguous) -> (o, lse2 [B,H,Sq] fp32).
+    f8: the e4m3 forward (csrc/attention_hd128.hip, vgpa_attn128_fwd_f8) for sweeps of at least ATTN128_F8_MIN_KEYS keys.
     o is a [B,H,Sq,128] view of token-major storage [B, Sq, H*128 (+ o_pad)]: the caller's flatten to [B*Sq, H*128] is free, and with
     o_pad it is the head of a `_padded_empty` buffer (the output projection's LoRA tail, see LoraExt)."""
     B, H, Sq, D = q.shape
@@ -877,6 +881,13 @@ def attention128_fwd_raw(q, k, v, scale, o_pad=0):
     o2 = _padded_empty((B, Sq), H * D, o_pad, torch.bfloat16, q.device) if o_pad else torch.empty(B, Sq, H * D, dtype=torch.bfloat16, device=q.device)
     o = o2.unflatten(-1, (H, D)).permute(0, 2, 1, 3)
     lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    if f8 and Skv >= ATTN128_F8_MIN_KEYS:
+        ws_bytes = _lib.query("vgpa_attn128_fwd_f8_workspace_bytes", B, H, Sq, Skv)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        _timed("attn128_fwd_f8", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
+            "vgpa_attn128_fwd_f8", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale),
+            ws, ws_bytes, _stream()))
+        return o, lse
     ws_bytes = _lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, Sq) if ATTN128_W1 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
     _timed("attn128_fwd" if Skv >= 1024 else "attn128_fwd (short keys)", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(

@@ -170,7 +170,7 @@ class _SelfAttnFn(torch.autograd.Function):
     the output projection's forward resp. the q/k/v projection's backward operand (ops.LoraExt)."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, wk, cos, sin, H, eps, o_pad, grad_pad):
+    def forward(ctx, qkv, wq, wk, cos, sin, H, eps, o_pad, grad_pad, f8=False):
         B, L, W = qkv.shape
         D = W // 3
         hd = D // H
@@ -183,7 +183,7 @@ class _SelfAttnFn(torch.autograd.Function):
         _rms_rope_fwd_raw(q2[:, D:2 * D], ld, wk, cos, sin, L, hd, eps, kn, D, rk)
         heads = lambda t: t.unflatten(-1, (H, hd)).permute(0, 2, 1, 3)
         v = heads(q2.view(B, L, W)[:, :, 2 * D:])
-        o, lse = ops.attention128_fwd_raw(heads(qn), heads(kn), v, hd ** -0.5, o_pad)
+        o, lse = ops.attention128_fwd_raw(heads(qn), heads(kn), v, hd ** -0.5, o_pad, f8=f8)      # f8: e4m3 matrix operands (enable_fp8(attention=True))
         ctx.save_for_backward(q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin)
         ctx.meta = (B, L, D, H, hd, grad_pad)
         return o.permute(0, 2, 1, 3).flatten(2)          # [B, L, D]: a view of the token-major storage
@@ -203,7 +203,7 @@ class _SelfAttnFn(torch.autograd.Function):
         d2 = dqkv.view(B * L, W)
         _rms_rope_bwd_raw(dqn, D, q2[:, :D], q2.stride(0), rq, wq, cos, sin, L, hd, d2[:, :D], d2.stride(0))
         _rms_rope_bwd_raw(dkn, D, q2[:, D:2 * D], q2.stride(0), rk, wk, cos, sin, L, hd, d2[:, D:2 * D], d2.stride(0))
-        return dqkv, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None
 
 
 class _FfnFp8Fn(torch.autograd.Function):
@@ -324,6 +324,7 @@ class WanSelfAttention(nn.Module):
         self.norm_k = WanRMSNorm(dim, eps=eps) if qk_norm else None
         self._fused = None
         self._qkv_ext = None
+        self.fp8_attn = False
 
     def _heads(self, t, B, S):
         return t.view(B, S, self.num_heads, self.head_dim).permute(0, 2, 1, 3)
@@ -374,7 +375,7 @@ class WanSelfAttention(nn.Module):
         else:
             qkv = ops.frozen_linear(x, W, b)
         o = _SelfAttnFn.apply(qkv.view(B, L, 3 * self.dim), self.norm_q.weight, self.norm_k.weight, rope[0] if rope else None, rope[1] if rope else None,
-                              self.num_heads, self.norm_q.eps, out_pad, in_pad)
+                              self.num_heads, self.norm_q.eps, out_pad, in_pad, bool(self.fp8_attn))
         return self.o(o.reshape(B * L, self.dim))
 
 
@@ -586,12 +587,16 @@ class WanModel(nn.Module):
         self.gradient_checkpointing = bool(enabled)
         self.checkpoint_stride = max(1, int(stride))
 
-    def enable_fp8(self, enabled=True):
-        """BASELINE.json configs[4] "fp8 MFMA path": the frozen feed-forward projections (61 % of the linear FLOPs per token) take
-        OCP-e4m3 operands -- per-row dynamic activation scales (csrc/fp8.hip), per-output-row weight scales, fp32 accumulation, bf16
-        out, forward and dX.  The LoRA-carrying q/k/v/o projections stay in bf16."""
+    def enable_fp8(self, enabled=True, attention=None):
+        """BASELINE.json configs[4] "fp8 MFMA path".  (i) The frozen feed-forward projections (61 % of the linear FLOPs per token) take OCP-e4m3 operands --
+        per-row dynamic activation scales (csrc/fp8.hip), per-output-row weight scales, fp32 accumulation, bf16 out, forward and dX (the vendor's fp8 GEMM).
+        (ii) attention (default: as `enabled`): the self-attention FORWARD -- reference pass and policy pass alike, so the Diffusion-DPO identity loss = ln 2
+        at B = 0 stays exact -- runs the hand-written e4m3 kernel (csrc/attention_hd128.hip attn128_fwd_f8_kernel: both products as
+        v_mfma_scale_f32_32x32x64_f8f6f4, power-of-two scales on the instruction's E8M0 operands); its backward and the 512-key cross-attention stay bf16.
+        The LoRA-carrying q/k/v/o projections stay in bf16."""
         for blk in self.blocks:
             blk.fp8_ffn = enabled
+            blk.self_attn.fp8_attn = bool(enabled if attention is None else attention)
 
     def _rope_tables(self, grid, device):
         key = (tuple(grid), str(device))
