@@ -266,6 +266,12 @@ int32_t vgpa_wan_ln_mod_fwd(const void* x, int32_t x_dtype, const int32_t* gid, 
                             void* q8, float* q8_scale, float* mean, float* rstd, vgpa_stream_t stream);
 int32_t vgpa_wan_ln_mod_bwd(const void* dy, const void* x, int32_t x_dtype, const float* mean, const float* rstd, const int32_t* gid, const float* ln_w,
                             const float* scale, int64_t mod_stride, int64_t rows, int64_t D, const float* dres, float* dx, vgpa_stream_t stream);
+/* the same two row kernels with an fp32 result / fp32 incoming gradient: WanModel's output head (upstream Head.forward runs LN, modulation and
+ * the projection in fp32; reference call site train/Wan2.2-TI2V-5B/03_train.py:227-233 through WanModel.forward) */
+int32_t vgpa_wan_ln_mod_fwd_f32(const float* x, const int32_t* gid, const float* shift, const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps,
+                                float* out, float* mean, float* rstd, vgpa_stream_t stream);
+int32_t vgpa_wan_ln_mod_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const int32_t* gid, const float* scale, int64_t mod_stride,
+                                int64_t rows, int64_t D, float* dx, vgpa_stream_t stream);
 int32_t vgpa_wan_gate_residual(const float* x, const void* y, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, float* out,
                                vgpa_stream_t stream);
 int32_t vgpa_wan_gate_bwd(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* dy, int64_t ld_dy,

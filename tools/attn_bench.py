@@ -18,6 +18,8 @@ ap.add_argument("--which", default="fwd,dkv,dq")
 ap.add_argument("--split", type=int, default=-1, help="forward split_mode: -1 automatic, 0 never")
 ap.add_argument("--data", default="randn", choices=["randn", "zeros", "const"], help="operand values: zeros / one constant toggle almost no datapath bits -> the time of the "
                 "instruction stream without the power throttle that random data brings (DESIGN section 4.0)")
+ap.add_argument("--energy", type=float, default=0.0, help="seconds of back-to-back launches per op bracketed by the socket energy counter (tools/energy.py): "
+                "joules per launch and mean power next to the time, also for the vendor FF1 GEMM of the step as a yardstick")
 a = ap.parse_args()
 B, H, S = a.B, a.H, a.S
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -54,3 +56,55 @@ for name, s in ops.TIMER.summary().items():
         continue
     print(f"{name:22s} avg {s['avg_ms']:8.3f} ms  algorithmic {s['work_per_launch'] / s['avg_ms'] / 1e9:7.1f} TF/s  "
           f"executed-MFMA {hw_units[name] * unit / s['avg_ms'] / 1e9:7.1f} TF/s")
+
+
+if a.energy > 0:
+    import time
+    from energy import read_joules
+    from videogpa_amd import _lib
+    w1 = set(ops.ATTN_W1)
+    scale = 64 ** -0.5
+    qs = ops.prescale_q(q, scale)
+    delta = torch.empty(B, H, S, dtype=torch.float32, device="cuda")
+    stats = torch.empty(B, H, 2, S, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    sb = ops._bhs_strides
+    _lib.call("vgpa_attn_bwd_prep_w1_res", ov, None, dov, lse, sb(ov), None, sb(dov), delta, stats, B, H, S, 64, st)
+    ws_bytes = _lib.query("vgpa_attn_bwd_split_workspace_bytes", B, H, S) if a.split != 0 else 0
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+    wsp = ws if ws_bytes else None
+    x = torch.randn(B * S, 3072, generator=g, device="cuda").to(torch.bfloat16)
+    wt = (torch.randn(12288, 3072, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    if a.data != "randn":
+        x.fill_(0.0 if a.data == "zeros" else 0.125)
+    launches = {
+        "attn_fwd": (4.0, lambda: ops.attention_fwd_raw(q, k, v, split_mode=a.split)),
+        "attn_bwd_dkv": (6.0, (lambda: _lib.call("vgpa_attn_bwd_dkv_w1", qs, k, v, dov, stats, dk, dv, sb(qs), sb(k), sb(v), sb(dov), sb(dk), sb(dv), B, H, S, 64, scale,
+                                                   a.split, wsp, ws_bytes, st)) if "dkv" in w1 else
+                         (lambda: _lib.call("vgpa_attn_bwd_dkv_ws", qs, k, v, dov, lse, delta, dk, dv, sb(qs), sb(k), sb(v), sb(dov), sb(dk), sb(dv), B, H, S, 64, scale,
+                                            a.split, wsp, ws_bytes, st))),
+        "attn_bwd_dq": (2.0, lambda: _lib.call("vgpa_attn_bwd_dq_w1" if "dq" in w1 else "vgpa_attn_bwd_dq_ws", qs, k, v, dov, lse, delta, dq, sb(qs), sb(k), sb(v),
+                                                 sb(dov), sb(dq), B, H, S, 64, scale, a.split, wsp, ws_bytes, st)),
+        "hipblaslt FF1 gemm": (None, lambda: torch.matmul(x, wt.t())),
+    }
+    idle0 = read_joules()
+    time.sleep(1.0)
+    idle_w = read_joules() - idle0
+    print(f"energy: idle {idle_w:.0f} W; >= {a.energy:.1f} s of back-to-back launches per op, data = {a.data}")
+    for name, (mult, fn) in launches.items():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        n = max(8, int(a.energy / max(time.perf_counter() - t0, 1e-4)))
+        e0, t0 = read_joules(), time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        t1, e1 = time.perf_counter(), read_joules()
+        ms, J = (t1 - t0) / n * 1e3, (e1 - e0) / n
+        flops = (mult * S * S * 64 * B * H) if mult else 2.0 * B * S * 3072 * 12288
+        print(f"{name:20s} {n:5d} launches  {ms:8.3f} ms  {J:8.3f} J/launch  {J / ms * 1e3:7.1f} W  {flops / ms / 1e9:7.1f} TF/s algorithmic  "
+              f"{flops / J / 1e12:6.3f} TFLOP/J")

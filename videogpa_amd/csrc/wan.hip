@@ -49,11 +49,11 @@ __device__ __forceinline__ void wan_quant_row(const float (*v)[8], int D, int la
 
 // y = [round_bf16](LN(x)) * w + b, then * (1 + scale[g]) + shift[g]  ->  bf16 (row stride out_ld) and / or e4m3 + per-row scale   (w, b, scale / shift optional)
 // mod: table row stride `mod_stride` floats, shift at column offset 0 of `shift`, scale of `scale` (pointers into the same table)
-template <int XDT>
+template <int XDT, int ODT = VGPA_DTYPE_BF16>
 __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const void* __restrict__ x, const int* __restrict__ gid, const float* __restrict__ w,
                                                                           const float* __restrict__ b, const float* __restrict__ shift,
                                                                           const float* __restrict__ scale, int64_t mod_stride, int D, int64_t rows, float eps,
-                                                                          int round_xhat, bf16_t* __restrict__ out, int64_t out_ld,
+                                                                          int round_xhat, void* __restrict__ out, int64_t out_ld,
                                                                           uint8_t* __restrict__ q8, float* __restrict__ q8_scale,
                                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int64_t row = wan_row();
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const vo
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = o[j] * (1.f + t0[j]) + t1[j];
             }
-            if (out) store8<VGPA_DTYPE_BF16>(out, (size_t)row * out_ld + i0, o);
+            if (out) store8<ODT>(out, (size_t)row * out_ld + i0, o);
             if (q8) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[c][j] = round_bf16(o[j]);       // the e4m3 operand is made from the bf16 value, as quant_fp8_rows does
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const vo
 }
 
 // dx = [dres +] LN-backward(dy * (1 + scale[g]) * w)           fp32 out (may alias dres)
-template <int XDT>
-__global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x, const float* __restrict__ mean,
+template <int XDT, int DYDT = VGPA_DTYPE_BF16>
+__global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x, const float* __restrict__ mean,
                                                                           const float* __restrict__ rstd, const int* __restrict__ gid, const float* __restrict__ w,
                                                                           const float* __restrict__ scale, int64_t mod_stride, int D, int64_t rows,
                                                                           const float* dres, float* dx) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const bf
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
-            load8<VGPA_DTYPE_BF16>(dy, (size_t)row * D + i0, gy[c]);
+            load8<DYDT>(dy, (size_t)row * D + i0, gy[c]);
             load8<XDT>(x, (size_t)row * D + i0, xh[c]);
             float t0[8];
             if (scale) {
@@ -336,10 +336,10 @@ extern "C" int32_t vgpa_wan_ln_mod_fwd(const void* x, int32_t x_dtype, const int
         return VGPA_ERR_INVALID;
     if (x_dtype == VGPA_DTYPE_F32)
         VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, x, gid, ln_w, ln_b, shift, scale, mod_stride, (int)D, rows,
-                    eps, round_xhat, (bf16_t*)out, out_ld, (uint8_t*)q8, q8_scale, mean, rstd);
+                    eps, round_xhat, out, out_ld, (uint8_t*)q8, q8_scale, mean, rstd);
     else if (x_dtype == VGPA_DTYPE_BF16)
         VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_BF16>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, x, gid, ln_w, ln_b, shift, scale, mod_stride, (int)D, rows,
-                    eps, round_xhat, (bf16_t*)out, out_ld, (uint8_t*)q8, q8_scale, mean, rstd);
+                    eps, round_xhat, out, out_ld, (uint8_t*)q8, q8_scale, mean, rstd);
     else
         return VGPA_ERR_INVALID;
     VGPA_CHECK_LAUNCH();
@@ -350,13 +350,33 @@ extern "C" int32_t vgpa_wan_ln_mod_bwd(const void* dy, const void* x, int32_t x_
                                        const float* scale, int64_t mod_stride, int64_t rows, int64_t D, const float* dres, float* dx, hipStream_t stream) {
     if (!dy || !x || !mean || !rstd || !dx || !wan_dims_ok(rows, D)) return VGPA_ERR_INVALID;
     if (x_dtype == VGPA_DTYPE_F32)
-        VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)dy, x, mean, rstd, gid, ln_w, scale, mod_stride,
+        VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, dy, x, mean, rstd, gid, ln_w, scale, mod_stride,
                     (int)D, rows, dres, dx);
     else if (x_dtype == VGPA_DTYPE_BF16)
-        VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_BF16>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)dy, x, mean, rstd, gid, ln_w, scale, mod_stride,
+        VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_BF16>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, dy, x, mean, rstd, gid, ln_w, scale, mod_stride,
                     (int)D, rows, dres, dx);
     else
         return VGPA_ERR_INVALID;
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// The output head of WanModel runs in fp32 upstream (LN, modulation and the projection under autocast(float32)): the same row kernels with an fp32
+// result / an fp32 incoming gradient, x fp32, no affine.
+extern "C" int32_t vgpa_wan_ln_mod_fwd_f32(const float* x, const int32_t* gid, const float* shift, const float* scale, int64_t mod_stride, int64_t rows, int64_t D,
+                                           float eps, float* out, float* mean, float* rstd, hipStream_t stream) {
+    if (!x || !out || !wan_dims_ok(rows, D) || (shift == nullptr) != (scale == nullptr) || (mean == nullptr) != (rstd == nullptr)) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_F32, VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const void*)x, gid, (const float*)nullptr,
+                (const float*)nullptr, shift, scale, mod_stride, (int)D, rows, eps, 0, (void*)out, D, (uint8_t*)nullptr, (float*)nullptr, mean, rstd);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_ln_mod_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const int32_t* gid, const float* scale,
+                                           int64_t mod_stride, int64_t rows, int64_t D, float* dx, hipStream_t stream) {
+    if (!dy || !x || !mean || !rstd || !dx || !wan_dims_ok(rows, D)) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_F32, VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const void*)dy, (const void*)x, mean, rstd, gid,
+                (const float*)nullptr, scale, mod_stride, (int)D, rows, (const float*)nullptr, dx);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

@@ -89,6 +89,37 @@ class _LnModFn(torch.autograd.Function):
         return dx.to(x.dtype), None, None, None, None, None, None, None, None, None
 
 
+class _HeadLnModFn(torch.autograd.Function):
+    """fp32( LN_eps(x) * (1 + scale[gid]) + shift[gid] ),  x [rows, D] fp32: the output head's normalisation (csrc/wan.hip, the fp32-result form of the
+    block kernels).  The modulation table takes no gradient here: the time MLP and the head's `modulation` are frozen on the DPO path (LoRA
+    targets are q / k / v / o), and a table that requires one raises instead of dropping it silently."""
+
+    @staticmethod
+    def forward(ctx, x, gid, shift, scale, eps):
+        if shift.requires_grad or scale.requires_grad:
+            raise NotImplementedError("videogpa_amd.wan_model.Head: the head's modulation / time embedding is frozen on this path")
+        rows, D = x.shape
+        x = x.contiguous()
+        out = torch.empty(rows, D, dtype=torch.float32, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ms = shift.stride(0)
+        ops._timed("wan_ln_mod_fwd", 8.0 * rows * D, lambda: _lib.call(
+            "vgpa_wan_ln_mod_fwd_f32", x, gid, shift, scale, ms, rows, D, float(eps), out, mean, rstd, _stream()), "byte")
+        ctx.save_for_backward(x, mean, rstd, gid, scale)
+        ctx.ms = ms
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gid, scale = ctx.saved_tensors
+        rows, D = x.shape
+        dx = torch.empty(rows, D, dtype=torch.float32, device=x.device)
+        ops._timed("wan_ln_mod_bwd", 12.0 * rows * D, lambda: _lib.call(
+            "vgpa_wan_ln_mod_bwd_f32", dy.float().contiguous(), x, mean, rstd, gid, scale, ctx.ms, rows, D, dx, _stream()), "byte")
+        return dx, None, None, None, None
+
+
 class _GateResidualFn(torch.autograd.Function):
     """fp32: x + y(bf16) * gate[gid]      (gate None: 1).  dy_pad: the gradient of y is returned as the head of a buffer that much wider (the
     LoRA tail of the output projection's backward GEMM)."""
@@ -443,12 +474,13 @@ class Head(nn.Module):
         self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
 
     def forward(self, x, e, gid):
-        """x [B*L, dim] fp32, e [G, dim] fp32 -> [B*L, out] fp32: upstream runs the whole head under autocast(float32); once per forward,
-        1.5 % of one block's bytes: torch elementwise + an fp32 library GEMM"""
-        tab = self.modulation.float() + e[:, None]                  # [G, 2, dim]
-        idx = gid.long()
-        h = F.layer_norm(x, (self.dim,), None, None, self.eps) * (1 + tab[:, 1][idx]) + tab[:, 0][idx]
-        return F.linear(h, self.head.weight.float(), self.head.bias.float())
+        """x [B*L, dim] fp32, e [G, dim] fp32 -> [B*L, out] fp32: upstream runs the whole head under autocast(float32).  LN + per-token modulation
+        is the row kernel of the blocks with an fp32 result (the modulation table is indexed inside the kernel: no [L, dim] gather), then one
+        fp32 library GEMM."""
+        tab = (self.modulation.float() + e[:, None]).contiguous()   # [G, 2, dim]
+        h = _HeadLnModFn.apply(x, gid, tab[:, 0], tab[:, 1], self.eps)
+        w, b = self.head.weight, self.head.bias
+        return F.linear(h, w.float() if w.requires_grad else _f32(w), b.float() if b.requires_grad else _f32(b))
 
 
 class WanModel(nn.Module):
