@@ -10,8 +10,12 @@
                                                  a sequence's first frame, entry 1 for the others), positions (0 for special tokens, grid + 1 for
                                                  patches), aa_block_num x aa_order x aa_block_size blocks, per-depth [frame | global] intermediates
 
-Pinned: tests/test_oracle_golden.py::test_vggt_* checks every function against tests/golden/vggt_attention.pt / vggt_aggregator.pt, which
-tests/golden/make_golden.py::golden_vggt_attention / golden_vggt_aggregator made by importing the reference modules."""
+  da3_local_global_pair  depth_anything_3/model/dinov2/layers/{attention,block,rope}.py + vision_transformer.py:282-364: the same family as the second
+                                                 reference-held witness (LayerNorm eps 1e-6 in the block, zero positions in the global pass)
+
+Pinned: tests/test_oracle_golden.py::test_vggt_* / test_da3_* check every function against tests/golden/vggt_attention.pt / vggt_aggregator.pt /
+da3_attention.pt, which tests/golden/make_golden.py::golden_vggt_attention / golden_vggt_aggregator / golden_da3_attention made by importing the
+reference modules."""
 import torch
 import torch.nn.functional as F
 
@@ -44,12 +48,23 @@ def attention(x, p, heads, pos=None, prefix=""):
     return F.linear(o, p[prefix + "proj.weight"], p[prefix + "proj.bias"])
 
 
-def block(x, p, heads, pos=None):
-    h = F.layer_norm(x, (x.shape[-1],), p["norm1.weight"], p["norm1.bias"], 1e-5)
+def block(x, p, heads, pos=None, ln_eps=1e-5):
+    """ln_eps: VGGT's blocks use nn.LayerNorm's default 1e-5; Depth Anything 3's DINOv2 blocks pass 1e-6
+    (depth_anything_3/model/dinov2/layers/block.py:26-75) -- q_norm / k_norm keep 1e-5 in both."""
+    h = F.layer_norm(x, (x.shape[-1],), p["norm1.weight"], p["norm1.bias"], ln_eps)
     x = x + p["ls1.gamma"] * attention(h, p, heads, pos, prefix="attn.")
-    h = F.layer_norm(x, (x.shape[-1],), p["norm2.weight"], p["norm2.bias"], 1e-5)
+    h = F.layer_norm(x, (x.shape[-1],), p["norm2.weight"], p["norm2.bias"], ln_eps)
     h = F.linear(F.gelu(F.linear(h, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
     return x + p["ls2.gamma"] * h
+
+
+def da3_local_global_pair(tokens, p_local, p_global, heads, B, S, pos, ln_eps=1e-6):
+    """Depth Anything 3's alternation (depth_anything_3/model/dinov2/vision_transformer.py:282-364): "local" attention per view on (B*S, N, C) with the
+    grid positions, "global" attention across views on (B, S*N, C) with all-zero positions (pos_nodiff).  Pinned by tests/golden/da3_attention.pt."""
+    N, C = tokens.shape[1], tokens.shape[2]
+    t1 = block(tokens, p_local, heads, pos, ln_eps)
+    t2 = block(t1.view(B, S * N, C), p_global, heads, torch.zeros(B, S * N, 2, dtype=pos.dtype), ln_eps)
+    return t1, t2
 
 
 def frame_global_pair(tokens, p_frame, p_global, heads, B, S, pos):

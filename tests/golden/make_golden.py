@@ -385,6 +385,72 @@ def golden_vggt_attention():
     print("vggt_attention.pt:", len(out["attention"]), "attention cases + 1 frame/global block pair")
 
 
+def golden_da3_attention():
+    """tests/golden/da3_attention.pt: a SECOND reference-held witness of the attention kernel family -- Depth Anything 3's DINOv2 layers
+    (depth_anything_3/model/dinov2/layers/attention.py:18-82: fused qkv, LayerNorm(head_dim) on q and k, RotaryPositionEmbedding2D rope.py, SDPA, proj;
+    block.py:26-110: LayerNorm eps 1e-6, LayerScale, Mlp) IMPORTED from the reference and run in fp32 on the CPU the way the backbone calls them
+    (vision_transformer.py:282-364): "local" attention on (B*S, N, C) with grid positions + 1 (0 for the special tokens), "global" attention on
+    (B, S*N, C) with ALL-ZERO positions (pos_nodiff: the rotation is the identity).  The package __init__ chain above the layers needs addict /
+    omegaconf (absent here), so the three parent packages are registered as plain namespaces and only the layer modules themselves execute."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for pkg in ("depth_anything_3", "depth_anything_3.model", "depth_anything_3.model.dinov2"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REF, *pkg.split("."))]
+            sys.modules[pkg] = m
+    from depth_anything_3.model.dinov2.layers.attention import Attention
+    from depth_anything_3.model.dinov2.layers.block import Block
+    from depth_anything_3.model.dinov2.layers.rope import PositionGetter, RotaryPositionEmbedding2D
+    torch.manual_seed(20261001)
+    g = torch.Generator().manual_seed(991)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    getter = PositionGetter()
+    out = {"attention": []}
+    for side_h, side_w, n_special, nodiff, dim, heads, Bx in ((14, 18, 1, False, 128, 2, 2), (9, 9, 5, True, 128, 2, 1), (37, 37, 1, False, 64, 1, 1)):
+        att = Attention(dim, num_heads=heads, qkv_bias=True, qk_norm=True, rope=RotaryPositionEmbedding2D(frequency=100.0))
+        with torch.no_grad():
+            for p in att.parameters():
+                p.copy_(rb(torch.randn(p.shape, generator=g) * (0.08 if p.ndim == 2 else 0.3) + (1.0 if p.ndim == 1 and p.shape[0] == 64 else 0.0)))
+        N = n_special + side_h * side_w
+        x = rb(torch.randn(Bx, N, dim, generator=g)).requires_grad_(True)
+        pos = getter(Bx, side_h, side_w, device=torch.device("cpu")) + 1                       # vision_transformer.py:286-295
+        pos = torch.cat([torch.zeros(Bx, n_special, 2, dtype=pos.dtype), pos], dim=1)
+        if nodiff:
+            pos = torch.zeros_like(pos)
+        y = att(x, pos=pos)
+        gy = rb(torch.randn(y.shape, generator=g))
+        y.backward(gy)
+        out["attention"].append({"N": N, "dim": dim, "heads": heads, "nodiff": nodiff, "pos": pos[0].to(torch.int16), "x": x.detach().to(torch.bfloat16),
+                                 "grad_out": gy.to(torch.bfloat16), "params": {k: v.detach().to(torch.bfloat16) for k, v in att.named_parameters()},
+                                 "y": y.detach(), "grad_x": x.grad.clone(), "grad_params": {k: v.grad.clone() for k, v in att.named_parameters()}})
+    # one local + one global block on [B = 1, S = 3 views, N tokens] (process_attention, vision_transformer.py:351-364)
+    dim, heads, Bq, Sq, sh, sw, nsp = 128, 2, 1, 3, 5, 7, 1
+    N = nsp + sh * sw
+    rope = RotaryPositionEmbedding2D(frequency=100.0)
+    blocks = [Block(dim, heads, mlp_ratio=2.0, qkv_bias=True, proj_bias=True, ffn_bias=True, init_values=0.01, qk_norm=True, rope=rope, ln_eps=1e-6) for _ in range(2)]
+    with torch.no_grad():
+        for b in blocks:
+            for n, p in b.named_parameters():
+                if "gamma" in n:
+                    p.copy_(rb(0.5 + 0.1 * torch.randn(p.shape, generator=g)))
+                else:
+                    p.copy_(rb(torch.randn(p.shape, generator=g) * (0.08 if p.ndim == 2 else 0.3) + (1.0 if "norm" in n and n.endswith("weight") else 0.0)))
+    tokens = rb(torch.randn(Bq * Sq, N, dim, generator=g)).requires_grad_(True)
+    pos = getter(Bq * Sq, sh, sw, device=torch.device("cpu")) + 1
+    pos = torch.cat([torch.zeros(Bq * Sq, nsp, 2, dtype=pos.dtype), pos], dim=1)
+    t1 = blocks[0](tokens, pos=pos)                                                              # local: (b s) n c, grid positions
+    t2 = blocks[1](t1.view(Bq, Sq * N, dim), pos=torch.zeros(Bq, Sq * N, 2, dtype=pos.dtype))    # global: b (s n) c, pos_nodiff
+    gy = rb(torch.randn(t2.shape, generator=g))
+    t2.backward(gy)
+    out["block"] = {"B": Bq, "S": Sq, "N": N, "dim": dim, "heads": heads, "ln_eps": 1e-6, "pos": pos[0].to(torch.int16), "tokens": tokens.detach().to(torch.bfloat16),
+                    "grad_out": gy.to(torch.bfloat16), "params": [{k: v.detach().to(torch.bfloat16) for k, v in b.named_parameters()} for b in blocks],
+                    "local_out": t1.detach(), "global_out": t2.detach(), "grad_tokens": tokens.grad.clone(),
+                    "grad_params": [{k: (v.grad.clone() if "mlp.fc" not in k or v.ndim == 1 else v.grad.norm()) for k, v in b.named_parameters()} for b in blocks]}
+    torch.save(out, os.path.join(HERE, "da3_attention.pt"))
+    print("da3_attention.pt:", len(out["attention"]), "attention cases + 1 local/global block pair")
+
+
 def golden_vggt_aggregator():
     """tests/golden/vggt_aggregator.pt: vggt/models/aggregator.py::Aggregator IMPORTED from the reference and run in fp32 on the CPU at small dimensions
     (patch_embed="conv", head_dim 64): the special-token assembly (slice_expand_and_flatten), PositionGetter positions, the aa_block_num x aa_order x
@@ -480,5 +546,6 @@ if __name__ == "__main__":
     golden_scorer()
     golden_scorer2()
     golden_vggt_attention()
+    golden_da3_attention()
     golden_vggt_aggregator()
     golden_preprocess()

@@ -88,3 +88,51 @@ def test_aggregator_matches_reference_module_outputs(case):
     outs_t[-1].float().sum().backward()
     assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
     _close(outs_t[-1], c["outputs"][-1], 0.02, "training-mode last depth")
+
+
+# ---------------------------------------------------------------------------------------- second witness: Depth Anything 3's DINOv2 layers
+@pytest.fixture(scope="module")
+def gold_da3():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.load(os.path.join(HERE, "golden", "da3_attention.pt"))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_da3_attention_matches_reference_module_outputs(gold_da3, case):
+    """The same HIP attention path (fused qkv GEMM -> QK-norm + half-split 2-D RoPE kernel -> attention -> proj) against outputs of
+    depth_anything_3/model/dinov2/layers/attention.py run by make_golden.py::golden_da3_attention: grid positions (cases 0, 2) and the all-zero
+    positions of DA3's global pass (case 1).  Outputs within 2 % of range, gradients within 3 % of range, cosine >= 0.999 (bf16 arithmetic)."""
+    from videogpa_amd.vggt import Attention, RotaryPositionEmbedding2D
+    c = gold_da3["attention"][case]
+    att = _load(Attention(c["dim"], num_heads=c["heads"], qk_norm=True, rope=RotaryPositionEmbedding2D(100.0)), c["params"])
+    x = c["x"].cuda().requires_grad_(True)
+    pos = c["pos"].long().cuda()[None].expand(x.shape[0], -1, -1)
+    y = att(x, pos=pos)
+    y.backward(c["grad_out"].cuda())
+    _close(y, c["y"], 0.02, "y")
+    _close(x.grad, c["grad_x"], 0.03, "grad_x")
+    for k in ("qkv.weight", "qkv.bias", "proj.weight", "proj.bias"):
+        _close(dict(att.named_parameters())[k].grad, c["grad_params"][k], 0.03, k)
+
+
+def test_da3_local_and_global_blocks_match_reference_module_outputs(gold_da3):
+    """DA3's local / global alternation (vision_transformer.py:351-364) on the HIP blocks with the block LayerNorm eps of 1e-6: local attention per
+    view with grid positions, global attention across views with zero positions."""
+    from videogpa_amd.vggt import Block, RotaryPositionEmbedding2D
+    c = gold_da3["block"]
+    rope = RotaryPositionEmbedding2D(100.0)
+    blocks = [_load(Block(c["dim"], c["heads"], mlp_ratio=2.0, init_values=0.01, qk_norm=True, rope=rope, ln_eps=c["ln_eps"]), p) for p in c["params"]]
+    assert blocks[0].norm1.eps == 1e-6 and blocks[0].attn.q_norm.eps == 1e-5
+    tok = c["tokens"].cuda().requires_grad_(True)
+    pos = c["pos"].long().cuda()[None].expand(c["B"] * c["S"], -1, -1).contiguous()
+    t1 = blocks[0](tok, pos=pos)
+    t2 = blocks[1](t1.view(c["B"], c["S"] * c["N"], c["dim"]), pos=torch.zeros(c["B"], c["S"] * c["N"], 2, dtype=torch.long, device="cuda"))
+    t2.backward(c["grad_out"].cuda().reshape(t2.shape))
+    _close(t1, c["local_out"], 0.02, "local block")
+    _close(t2, c["global_out"], 0.02, "global block")
+    _close(tok.grad, c["grad_tokens"], 0.03, "grad_tokens")
+    for b, gp in zip(blocks, c["grad_params"]):
+        named = dict(b.named_parameters())
+        for k in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.bias", "mlp.fc2.bias"):
+            _close(named[k].grad, gp[k], 0.03, k)

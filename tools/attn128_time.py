@@ -26,6 +26,13 @@ def fwd(w1):
     _lib.call("vgpa_attn128_fwd", q, k, v, o, lse, st(q), st(k), st(v), st(o), B, H, S, S, scale, wsf if w1 else None, wsf.numel() if w1 else 0, stream)
 
 
+wsf8 = torch.empty(_lib.query("vgpa_attn128_fwd_f8_workspace_bytes", B, H, S, S), dtype=torch.uint8, device="cuda")
+
+
+def fwd_f8():
+    _lib.call("vgpa_attn128_fwd_f8", q, k, v, o, lse, st(q), st(k), st(v), st(o), B, H, S, S, scale, wsf8, wsf8.numel(), stream)
+
+
 def bwd(mode):
     _lib.call("vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv), B, H, S, S, scale, mode, wsb, wsb.numel(), stream)
 
@@ -43,8 +50,9 @@ def timeit(fn, n=a_.iters):
 ff = 4.0 * B * H * S * S * D
 cases = [("fwd w1", lambda: fwd(True), ff), ("fwd simple", lambda: fwd(False), ff), ("bwd (w1 dq + w1 dkv)", lambda: bwd(1), 2.0 * ff),
          ("bwd (compiler-scheduled)", lambda: bwd(0), 2.0 * ff)]
+cases.insert(1, ("fwd e4m3 (amax + quantise + MFMA f8f6f4)", fwd_f8, ff))
 if a_.product_only:
-    cases = [cases[0], cases[2]]
+    cases = [cases[0], cases[1], cases[3]]
 for name, fn, fl in cases:
     t = timeit(fn)
     print(f"{name:32s} {t:8.3f} ms   {fl / t / 1e9:7.0f} TFLOP/s algorithmic")

@@ -840,38 +840,54 @@ __global__ __launch_bounds__(256) void attn128_f8_amax_kernel(const bf16_t* __re
             for (int j = 0; j < 8; ++j) m[which] = fmaxf(m[which], fabsf(f[j]));
         }
     }
+    __shared__ float mw[3][4];
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
         const float w = wave_max(m[which]);
-        if ((threadIdx.x & 63) == 0) atomicMax(stats + bh * 4 + which, __float_as_uint(w));
+        if ((threadIdx.x & 63) == 0) mw[which][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {      // one conditional atomic per workgroup and tensor (same-address atomics serialise at the memory side)
+        const float w = fmaxf(fmaxf(mw[threadIdx.x][0], mw[threadIdx.x][1]), fmaxf(mw[threadIdx.x][2], mw[threadIdx.x][3]));
+        unsigned* dst = stats + bh * 4 + threadIdx.x;
+        if (__float_as_uint(w) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, __float_as_uint(w));
     }
 }
 
-// one workgroup = 64 tokens of one (batch, head): thread t -> token t / 4, 32 features from 32 (t % 4)
+// one workgroup = 64 tokens of one (batch, head): thread t -> token t / 4, 32 features from 32 (t % 4).  All twelve 16-byte loads of the thread (q, k, v) are
+// issued before any use.  V leaves transposed: the thread's eight e4m3 dwords (4 features each) go into an LDS image [feature quad][token] (pitch 66 dwords),
+// then thread (quad = t / 8, token group = t % 8) reads its 4 features x 8 tokens as four 8-byte pieces, transposes the two 4 x 4 byte blocks in registers
+// (v_perm_b32) and stores 8 contiguous token bytes to each of its four v8t rows.
 __global__ __launch_bounds__(256) void attn128_f8_quant_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, TStride sq,
                                                                  TStride sk, TStride sv, int Sq, int Skv, int Lp, int H, float c, const unsigned* __restrict__ stats,
                                                                  uint8_t* __restrict__ q8, uint8_t* __restrict__ k8, uint8_t* __restrict__ v8t,
                                                                  float* __restrict__ qn2, unsigned* __restrict__ kmax2) {
-    __shared__ __attribute__((aligned(16))) uint8_t vt[128 * 68];   // the tile's V, e4m3, transposed: [d][token], pitch 68
+    __shared__ __attribute__((aligned(16))) uint32_t vt[32 * 66];
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int tok = blockIdx.x * 64 + ((int)threadIdx.x >> 2), d0 = 32 * ((int)threadIdx.x & 3);
+    const int tl = (int)threadIdx.x >> 2, tok = blockIdx.x * 64 + tl, d0 = 32 * ((int)threadIdx.x & 3);
     const int eq = f8_exp_of(__uint_as_float(stats[bh * 4]) * c), ek = f8_exp_of(__uint_as_float(stats[bh * 4 + 1])), ev = f8_exp_of(__uint_as_float(stats[bh * 4 + 2]));
-    float kn = 0.f;
+    const u32x4_t z4 = {0u, 0u, 0u, 0u};
+    u32x4_t raw[3][4];
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
         const bf16_t* base = which == 0 ? Q + ((size_t)b * sq.b + (size_t)h * sq.h) : which == 1 ? K + ((size_t)b * sk.b + (size_t)h * sk.h) : V + ((size_t)b * sv.b + (size_t)h * sv.h);
         const uint32_t rs = which == 0 ? sq.s : which == 1 ? sk.s : sv.s;
+        const bool in = tok < (which == 0 ? Sq : Skv);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) raw[which][g] = in ? *reinterpret_cast<const u32x4_t*>(base + ((size_t)tok * rs + (size_t)(d0 + 8 * g))) : z4;
+    }
+    float kn = 0.f;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
         const int S = which == 0 ? Sq : Skv;
         const float mul = which == 0 ? ldexpf(c, -eq) : ldexpf(1.f, which == 1 ? -ek : -ev);
-        uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        if (tok < S) {
+        uint32_t w[8];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float f[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(base + ((size_t)tok * rs + (size_t)(d0 + 8 * g))), f);
-                w[2 * g] = f8_pack4(f[0] * mul, f[1] * mul, f[2] * mul, f[3] * mul);
-                w[2 * g + 1] = f8_pack4(f[4] * mul, f[5] * mul, f[6] * mul, f[7] * mul);
-            }
+        for (int g = 0; g < 4; ++g) {
+            float f[8];
+            unpack8(raw[which][g], f);
+            w[2 * g] = f8_pack4(f[0] * mul, f[1] * mul, f[2] * mul, f[3] * mul);
+            w[2 * g + 1] = f8_pack4(f[4] * mul, f[5] * mul, f[6] * mul, f[7] * mul);
         }
         if (which < 2) {
             float n2 = 0.f;
@@ -887,23 +903,44 @@ __global__ __launch_bounds__(256) void attn128_f8_quant_kernel(const bf16_t* __r
                 if (which == 0 && d0 == 0) qn2[(size_t)bh * Sq + tok] = n2;
                 if (which == 1) kn = n2;
             }
-        } else {   // V: bytes into the transposed LDS image (zeros for tokens past Skv: the padded columns of v8t must be finite)
-            const int tl = (int)threadIdx.x >> 2;
+        } else {   // V: feature quads into the LDS image (zeros for tokens past Skv: the padded columns of v8t must be finite)
 #pragma unroll
-            for (int g = 0; g < 8; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vt[(d0 + 4 * g + i) * 68 + tl] = (uint8_t)(w[g] >> (8 * i));
+            for (int g = 0; g < 8; ++g) vt[((d0 >> 2) + g) * 66 + tl] = w[g];
         }
     }
+    // one atomic per workgroup at most, and only when it would raise the value: thousands of same-address atomics per (batch, head) serialise at the
+    // memory side (they were the whole cost of this kernel: 475 us against 230 for the traffic).  A stale read only errs towards issuing the atomic.
+    __shared__ float knw[4];
     kn = wave_max(kn);
-    if ((threadIdx.x & 63) == 0 && kn > 0.f) atomicMax(kmax2 + bh, __float_as_uint(kn));
+    if ((threadIdx.x & 63) == 0) knw[threadIdx.x >> 6] = kn;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        kn = fmaxf(fmaxf(knw[0], knw[1]), fmaxf(knw[2], knw[3]));
+        if (kn > 0.f && __float_as_uint(kn) > __hip_atomic_load(kmax2 + bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(kmax2 + bh, __float_as_uint(kn));
+    }
     if (blockIdx.x * 64 < Lp) {
-        const int d = (int)threadIdx.x >> 1, half = (int)threadIdx.x & 1;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(vt + d * 68 + 32 * half);
-        uint8_t* dst = v8t + (((size_t)bh * 128 + d) * Lp + (size_t)blockIdx.x * 64 + 32 * half);
-        *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{src[0], src[1], src[2], src[3]};
-        *reinterpret_cast<u32x4_t*>(dst + 16) = u32x4_t{src[4], src[5], src[6], src[7]};
+        const int dq = (int)threadIdx.x >> 3, tg = (int)threadIdx.x & 7;
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x2_t t2 = *reinterpret_cast<const u32x2_t*>(vt + dq * 66 + 8 * tg + 2 * i);
+            x[2 * i] = t2[0];
+            x[2 * i + 1] = t2[1];
+        }
+        uint32_t o[4][2];          // [feature 4 dq + r][tokens 0..3 | 4..7 of the group]
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const uint32_t x0 = x[4 * hb], x1 = x[4 * hb + 1], x2 = x[4 * hb + 2], x3 = x[4 * hb + 3];
+            const uint32_t a = __builtin_amdgcn_perm(x1, x0, 0x05010400u), bq = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+            const uint32_t cq = __builtin_amdgcn_perm(x3, x2, 0x05010400u), dd = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+            o[0][hb] = __builtin_amdgcn_perm(cq, a, 0x05040100u);
+            o[1][hb] = __builtin_amdgcn_perm(cq, a, 0x07060302u);
+            o[2][hb] = __builtin_amdgcn_perm(dd, bq, 0x05040100u);
+            o[3][hb] = __builtin_amdgcn_perm(dd, bq, 0x07060302u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<u32x2_t*>(v8t + (((size_t)bh * 128 + 4 * dq + r) * Lp + (size_t)blockIdx.x * 64 + 8 * tg)) = u32x2_t{o[r][0], o[r][1]};
     }
 }
 

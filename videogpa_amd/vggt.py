@@ -79,10 +79,13 @@ class Mlp(nn.Module):
 
 class Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, proj_bias=True, ffn_bias=True, init_values=None, norm_layer=nn.LayerNorm,
-                 qk_norm=False, fused_attn=True, rope=None):
+                 qk_norm=False, fused_attn=True, rope=None, ln_eps=None):
         super().__init__()
         if not init_values:
             raise NotImplementedError("blocks without LayerScale are not used by VGGT's aggregator")
+        if ln_eps is not None:      # Depth Anything 3's DINOv2 block (depth_anything_3/model/dinov2/layers/block.py:26-75) passes ln_eps = 1e-6
+            base_norm = norm_layer
+            norm_layer = lambda d: base_norm(d, eps=ln_eps)
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, proj_bias=proj_bias, qk_norm=qk_norm, rope=rope)
         self.ls1 = LayerScale(dim, init_values)
