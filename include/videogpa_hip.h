@@ -210,6 +210,12 @@ int32_t vgpa_lora_grad(const void* U, int64_t ldu, const void* V, int64_t ldv, f
 size_t vgpa_lora_grad_workspace_bytes(int64_t M, int64_t P, int64_t Q);
 int32_t vgpa_lora_grad_ws(const void* U, int64_t ldu, const void* V, int64_t ldv, float* G, int64_t ldg, float s, int64_t M,
                           int64_t P, int64_t Q, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* adapter refresh of the K-extended projection operands after an optimizer step (PEFT re-reads lora_A / lora_B in every forward,
+ * peft/tuners/lora/layer.py Linear.forward; here the extended GEMM operands cache them): a = bf16(A[r, K]), sB = bf16(float(bf16(B[Dn, r])) * s)
+ * -> a_cat [r, K], wt_tail[k * ld_wt + rr] = a (the [K, N + R] operand's tail columns), w_tail[n * ld_w + rr] = sB (the [N, K + R] operand's
+ * tail columns), sbt [rr * Dn + n] = sB.  A, B fp32 contiguous, outputs bf16. */
+int32_t vgpa_lora_ext_refresh(const float* A, const float* B, float s, int64_t r, int64_t K, int64_t Dn, void* a_cat, void* wt_tail, int64_t ld_wt,
+                              void* w_tail, int64_t ld_w, void* sbt, vgpa_stream_t stream);
 
 /* ---- feed-forward GEMM with fused epilogue: diffusers FeedForward(activation_fn="gelu-approximate") inside CogVideoXBlock
  * (the reference reaches it through diffusers cogvideox_transformer_3d.py; train/CogVideoX-5B/utils.py:255-289 drives the blocks).

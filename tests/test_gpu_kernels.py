@@ -557,6 +557,46 @@ def test_linear_lora_ext_padded_zero_copy_and_reference_pass(ops):
     assert torch.equal(ops.linear_lora_ext(n, W, bias, ext, [(A, B1, 2.0)], enabled=True), y_b0)
 
 
+@pytest.mark.parametrize("r,n_slices", [(8, 1), (64, 3), (12, 3)])
+def test_lora_ext_refresh_kernel_is_bit_exact_with_pefts_rounding(ops, r, n_slices):
+    """vgpa_lora_ext_refresh (one launch per adapter after an optimizer step) against the torch statements it replaces, which follow PEFT's forward
+    (peft/tuners/lora/layer.py: the adapter is cast to the activation dtype, then scaled): A_cat = bf16(A); sB = bf16(float(bf16(B)) * s) into the
+    [N, K + R] operand's tail columns and into sBt; A^T into the [K, N + R] operand's tail columns.  Bit-exact, padding columns stay zero, a fused
+    q/k/v projection (3 slices) addresses every adapter's own rows / columns; the refresh after an in-place update sees the new values."""
+    g = torch.Generator().manual_seed(100 + r)
+    K, Dn = 192, 128
+    N = n_slices * Dn
+    W = dev((torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16))
+    loras = [(dev(torch.randn(r, K, generator=g) / K ** 0.5), dev(torch.randn(Dn, r, generator=g) * 0.3), 2.0 * (i + 1) / 3.0) for i in range(n_slices)]
+    ext = ops.LoraExt().refresh(W, n_slices, loras)
+    rp, R = ext.rp, ext.R
+    assert R == n_slices * rp and ext.W_ext.shape == (N, K + R) and ext.Wt_ext.shape == (K, N + R)
+
+    def expect():
+        W_ext = torch.zeros(N, K + R, dtype=torch.bfloat16, device="cuda")
+        W_ext[:, :K] = W
+        A_cat = torch.zeros(R, K, dtype=torch.bfloat16, device="cuda")
+        sBt = torch.zeros(n_slices, rp, Dn, dtype=torch.bfloat16, device="cuda")
+        for j, (A, Bm, sc) in enumerate(loras):
+            A_cat[j * rp:j * rp + r] = A.to(torch.bfloat16)
+            sB = (Bm.to(torch.bfloat16).float() * sc).to(torch.bfloat16)
+            W_ext[j * Dn:(j + 1) * Dn, K + j * rp:K + j * rp + r] = sB
+            sBt[j, :r] = sB.t()
+        Wt_ext = torch.zeros(K, N + R, dtype=torch.bfloat16, device="cuda")
+        Wt_ext[:, :N] = W.t()
+        Wt_ext[:, N:] = A_cat.t()
+        return W_ext, Wt_ext, A_cat, sBt
+    for got, want, name in zip((ext.W_ext, ext.Wt_ext, ext.A_cat, ext.sBt), expect(), ("W_ext", "Wt_ext", "A_cat", "sBt")):
+        assert torch.equal(got, want), name
+    for A, Bm, _ in loras:           # what the AdamW kernel does: values change behind autograd's back, the epoch is bumped
+        A.data.mul_(1.5)
+        Bm.data.add_(0.25)
+    ops.bump_adapter_epoch()
+    ext.refresh(W, n_slices, loras)
+    for got, want, name in zip((ext.W_ext, ext.Wt_ext, ext.A_cat, ext.sBt), expect(), ("W_ext", "Wt_ext", "A_cat", "sBt")):
+        assert torch.equal(got, want), name + " after update"
+
+
 @pytest.mark.parametrize("S,split", [(1000, 0), (1000, 4), (100, 0), (2100, 3)])
 def test_attention_output_residual_and_precise_delta(ops, S, split):
     """vgpa_attn_fwd_w1_res / vgpa_attn_bwd_prep_w1_res / vgpa_attn_bwd_delta_res ("precise delta", ops.PRECISE_DELTA): the forward also stores the

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vgpa_lora_grad": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P]),
     "vgpa_lora_grad_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_lora_grad_ws": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P, SZ, P]),
+    "vgpa_lora_ext_refresh": (I32, [P, P, F32, I64, I64, I64, P, P, I64, P, I64, P, P]),
     "vgpa_attn128_fwd_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn128_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
     "vgpa_attn128_fwd_f8_workspace_bytes": (SZ, [I64, I64, I64, I64]),

@@ -563,11 +563,17 @@ class LoraExt:
                     A, Bm, sc = loras[i]
                     if A.shape[0] != r:
                         raise RuntimeError("adapters on one projection must share a rank")
+                    if dt == torch.bfloat16 and W.is_cuda:
+                        # one launch per adapter (csrc/lora.hip lora_ext_refresh_kernel) with PEFT's roundings: a = bf16(A), sB = bf16(float(bf16(B)) * s)
+                        # (the adapter is cast to the activation dtype first) -- the eight strided torch copies this replaces were 1300-1900 tiny kernels per step
+                        _lib.call("vgpa_lora_ext_refresh", A.detach().float().contiguous(), Bm.detach().float().contiguous(), float(sc), r, K, Dn,
+                                  self.A_cat[j * rp:], self.Wt_ext[:, N + j * rp:], N + R, self.W_ext[i * Dn:, K + j * rp:], K + R, self.sBt[j], _stream())
+                        continue
                     self.A_cat[j * rp:j * rp + r] = A.to(dt)
                     sB = (Bm.to(dt).float() * sc).to(dt)                     # PEFT casts the adapter to the activation dtype first
                     self.W_ext[i * Dn:(i + 1) * Dn, K + j * rp:K + j * rp + r] = sB
                     self.sBt[j, :r] = sB.t()
-                self.Wt_ext[:, N:] = self.A_cat.t()
+                    self.Wt_ext[:, N + j * rp:N + j * rp + r] = self.A_cat[j * rp:j * rp + r].t()
             self.akey = akey
         return self
 
