@@ -77,6 +77,46 @@ def build_model(cfg_kw, device, seed):
     return model
 
 
+_RSMI = None
+
+
+def read_joules(device=0):
+    """Accumulated socket energy of GPU `device` in joules (librocm_smi64 rsmi_dev_energy_count_get; None when the library or the counter is not
+    there).  Read around the timed region: J per step and mean W next to ms per step -- every MFMA-bound launch of this step runs at the part's
+    1.4 kW cap, so time IS joules."""
+    global _RSMI
+    import ctypes
+    if _RSMI is None:
+        _RSMI = False
+        for name in ("librocm_smi64.so", "/opt/rocm/lib/librocm_smi64.so", "librocm_smi64.so.1"):
+            try:
+                lib = ctypes.CDLL(name)
+                if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
+                    _RSMI = lib
+                    break
+            except OSError:
+                continue
+    if not _RSMI:
+        return None
+    cnt, res, ts = ctypes.c_uint64(0), ctypes.c_float(0.0), ctypes.c_uint64(0)
+    if _RSMI.rsmi_dev_energy_count_get(ctypes.c_uint32(device), ctypes.byref(cnt), ctypes.byref(res), ctypes.byref(ts)) != 0:
+        return None
+    return cnt.value * float(res.value) * 1e-6
+
+
+def energy_report(e0, e1, dt, steps, flops_algorithmic, flops_executed=None):
+    if e0 is None or e1 is None or e1 <= e0:
+        return None
+    J = (e1 - e0) / steps
+    rep = {"joules_per_step": J, "mean_power_w": (e1 - e0) / dt, "algorithmic_tflop_per_joule": flops_algorithmic / J / 1e12,
+           "source": "rsmi_dev_energy_count_get around the timed region (rank 0's GPU)"}
+    if flops_executed:
+        rep["executed_tflop_per_joule"] = flops_executed / J / 1e12
+        rep["note"] = ("executed = algorithmic + the S / dP recomputes of the split attention backward (6 S^2 d per head and layer); hipBLASLt's GEMM and the "
+                       "attention backward kernels measure 1.02-1.04 executed TFLOP/J stand-alone (profiles/r04_energy_per_launch.txt)")
+    return rep
+
+
 def flops_per_pair_step(S, D, L, r):
     """BASELINE.md section 4 (algorithmic, no recompute counted)."""
     f_lin, f_attn, f_lora = 24.0 * S * D * D, 4.0 * S * S * D, 16.0 * S * D * r
@@ -269,7 +309,7 @@ def run_other_configs(steps=3, warmup=1, timeout_s=420):
                 continue
             j = json.loads(line)
             keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "loss", "max_memory_gb", "step_flops_algorithmic",
-                    "step_mfma_frac", "roofline", "roofline_worst", "attention_bwd_pair")
+                    "step_mfma_frac", "roofline", "roofline_worst", "attention_bwd_pair", "energy")
             rec = {k: j[k] for k in keep if k in j}
             rec["workload"] = j["config"]["workload"]
             rec["wall_s_incl_model_build"] = time.perf_counter() - t0
@@ -345,6 +385,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
     if rank == 0 and not args.no_kernel_timer:
         ops.TIMER = ops.KernelTimer(full_steps=TIMER_FULL_STEPS, always=TIMER_ALWAYS)
     barrier()
+    e0 = read_joules(dev.index or 0) if rank == 0 else None
     t0 = time.perf_counter()
     logs = None
     for _ in range(args.steps):
@@ -353,7 +394,9 @@ def main_wan(args, C, world, rank, dev, force_dist):
             ops.TIMER.next_step()
     logs.update(engine.flush())
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    e1 = read_joules(dev.index or 0) if rank == 0 else None
+    dt = dt_local
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1 or force_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -380,6 +423,8 @@ def main_wan(args, C, world, rank, dev, force_dist):
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
         add_kernel_report(out, ops, args.steps, ms, use_pmc=named)
+        if not ckpt:
+            out["energy"] = energy_report(e0, e1, dt_local, args.steps, F_step)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
@@ -483,6 +528,7 @@ def main():
     if rank == 0 and not args.no_kernel_timer:
         ops.TIMER = ops.KernelTimer(full_steps=TIMER_FULL_STEPS, always=TIMER_ALWAYS)
     barrier()
+    e0 = read_joules(dev.index or 0) if rank == 0 else None
     t0 = time.perf_counter()
     logs = None
     for _ in range(args.steps):
@@ -491,7 +537,9 @@ def main():
             ops.TIMER.next_step()
     logs.update(engine.flush())       # the last optimizer step (applied one micro-step late when the all-reduce is overlapped) is inside the timed region
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    e1 = read_joules(dev.index or 0) if rank == 0 else None
+    dt = dt_local
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1 or force_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -519,6 +567,8 @@ def main():
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
         add_kernel_report(out, ops, args.steps, ms, use_pmc=named and args.config in ("cfg2", "cfg3"))
+        if not ckpt:      # with block recompute the executed count would also carry the recomputed forwards
+            out["energy"] = energy_report(e0, e1, dt_local, args.steps, F_step, F_step + 6.0 * args.layers * 2 * cfg_kw["num_attention_heads"] * 64.0 * S * S)
         others = None
         if world == 1 and not force_dist and named and args.config == "cfg2" and not args.no_other_configs:
             # the secondary configurations run on the (now idle) GPU in child processes WHILE the host cores time the CPU leg: the timed region of the

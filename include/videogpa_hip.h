@@ -278,6 +278,16 @@ int32_t vgpa_wan_ln_mod_fwd_f32(const float* x, const int32_t* gid, const float*
                                 float* out, float* mean, float* rstd, vgpa_stream_t stream);
 int32_t vgpa_wan_ln_mod_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const int32_t* gid, const float* scale, int64_t mod_stride,
                                 int64_t rows, int64_t D, float* dx, vgpa_stream_t stream);
+/* a block's [gated residual add -> LayerNorm] pair in one pass (upstream WanAttentionBlock.forward: `x = x + y * e[2]` followed by norm3 / norm2 of that x):
+ *   gate_ln_mod_fwd : xo(fp32) = x + y(bf16) * gate[g] (gate NULL = 1); then exactly ln_mod_fwd of xo (bf16 and / or e4m3 result)
+ *   ln_mod_bwd_gate : dx = [dres +] LN-backward(...) as ln_mod_bwd, and dy_prev(bf16, row stride ld_dy_prev) = dx * gate_prev[g] (NULL = 1): the gradient of
+ *                     the y of that residual add.  gate / gate_prev index the same table rows as shift / scale (mod_stride). */
+int32_t vgpa_wan_gate_ln_mod_fwd(const float* x, const void* y, const int32_t* gid, const float* gate, const float* ln_w, const float* ln_b, const float* shift,
+                                 const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, float* xo, void* out, int64_t out_ld, void* q8,
+                                 float* q8_scale, float* mean, float* rstd, vgpa_stream_t stream);
+int32_t vgpa_wan_ln_mod_bwd_gate(const void* dy, const float* x, const float* mean, const float* rstd, const int32_t* gid, const float* ln_w, const float* scale,
+                                 int64_t mod_stride, int64_t rows, int64_t D, const float* dres, float* dx, const float* gate_prev, void* dy_prev,
+                                 int64_t ld_dy_prev, vgpa_stream_t stream);
 int32_t vgpa_wan_gate_residual(const float* x, const void* y, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, float* out,
                                vgpa_stream_t stream);
 int32_t vgpa_wan_gate_bwd(const float* dout, const int32_t* gid, const float* gate, int64_t mod_stride, int64_t rows, int64_t D, void* dy, int64_t ld_dy,

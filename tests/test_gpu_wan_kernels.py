@@ -452,3 +452,47 @@ def test_wan_ln_mod_passthrough_adds_the_residual_gradient_in_the_kernel():
     h3, xp3 = ln_mod(c, gid, None, None, tab[:, 3], tab[:, 4], 1e-6, passthrough=True)
     xp3.backward(dxp)                                        # LN output unused: the residual gradient passes through
     assert torch.equal(c.grad, dxp)
+
+
+@pytest.mark.parametrize("mode", ["gate+affine", "plain+mod"])
+def test_wan_gate_ln_is_bit_identical_to_gate_residual_then_ln_mod(mode):
+    """gate_ln (csrc/wan.hip GR / GB forms: a block's [gated residual add -> LayerNorm] pair in one pass each way) against the two-node chain it replaces,
+    in both shapes the block uses: self-attention branch (per-token gate, affine norm3, LoRA tails on both sides) and cross-attention branch (no gate, the
+    feed-forward's modulated LayerNorm).  Forward outputs bit-identical; dx and dy bit-identical to the chain (the same kernel arithmetic), also when only
+    the residual output carries a gradient."""
+    from videogpa_amd.wan_model import gate_ln, gate_residual, ln_mod
+    g = torch.Generator(device="cuda").manual_seed(41)
+    rows, C, G = 133, 3072, 2
+    x = torch.randn(rows, C, device="cuda", generator=g)
+    y = torch.randn(rows, C, device="cuda", generator=g).bfloat16()
+    gid = torch.randint(0, G, (rows,), device="cuda", generator=g).int()
+    tab = _tab(G, 6, C, g)
+    w, b = 1 + 0.1 * torch.randn(C, device="cuda", generator=g), 0.1 * torch.randn(C, device="cuda", generator=g)
+    dh = torch.randn(rows, C, device="cuda", generator=g).bfloat16()
+    dxp = torch.randn(rows, C, device="cuda", generator=g)
+    if mode == "gate+affine":
+        kw = dict(gid=gid, gate=tab[:, 2], ln_w=w, ln_b=b, shift=None, scale=None, pad=64, dy_pad=64)
+    else:
+        kw = dict(gid=gid, gate=None, ln_w=None, ln_b=None, shift=tab[:, 3], scale=tab[:, 4], pad=0, dy_pad=64)
+
+    def chain(xa, ya):
+        xs = gate_residual(xa, ya, kw["gid"] if kw["gate"] is not None else None, kw["gate"], dy_pad=kw["dy_pad"])
+        return ln_mod(xs, kw["gid"] if kw["shift"] is not None else None, kw["ln_w"], kw["ln_b"], kw["shift"], kw["scale"], 1e-6, pad=kw["pad"], passthrough=True)
+
+    xa, ya = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    h, xp = gate_ln(xa, ya, eps=1e-6, **kw)
+    xb, yb = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    h2, xp2 = chain(xb, yb)
+    assert torch.equal(h, h2) and torch.equal(xp, xp2)
+    assert h.stride(0) == C + kw["pad"]
+    torch.autograd.backward([h, xp], [dh, dxp])
+    torch.autograd.backward([h2, xp2], [dh, dxp])
+    # dx: the same fp32 expression compiled in two kernel instantiations (fma contraction may differ): one rounding apart at most; dy = bf16(dx * gate)
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-6 * xb.grad.abs().max().item()
+    assert ((ya.grad.float() - yb.grad.float()).abs() <= 2.0 ** -7 * yb.grad.float().abs() + 1e-30).all() and (ya.grad != yb.grad).float().mean().item() < 1e-3
+    xc, yc = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    _, xp3 = gate_ln(xc, yc, eps=1e-6, **kw)
+    xp3.backward(dxp)                                        # LN output unused
+    xd, yd = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    gate_residual(xd, yd, kw["gid"] if kw["gate"] is not None else None, kw["gate"], dy_pad=kw["dy_pad"]).backward(dxp)
+    assert torch.equal(xc.grad, xd.grad) and torch.equal(yc.grad, yd.grad)

@@ -71,6 +71,8 @@ SIGNATURES = {
     "vgpa_wan_ln_mod_bwd": (I32, [P, P, I32, P, P, P, P, P, I64, I64, I64, P, P, P]),
     "vgpa_wan_ln_mod_fwd_f32": (I32, [P, P, P, P, I64, I64, I64, F32, P, P, P, P]),
     "vgpa_wan_ln_mod_bwd_f32": (I32, [P, P, P, P, P, P, I64, I64, I64, P, P]),
+    "vgpa_wan_gate_ln_mod_fwd": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, F32, P, P, I64, P, P, P, P, P]),
+    "vgpa_wan_ln_mod_bwd_gate": (I32, [P, P, P, P, P, P, P, I64, I64, I64, P, P, P, P, I64, P]),
     "vgpa_wan_gate_residual": (I32, [P, P, P, P, I64, I64, I64, P, P]),
     "vgpa_wan_gate_bwd": (I32, [P, P, P, I64, I64, I64, P, I64, P]),
     "vgpa_wan_gate_bwd_q8": (I32, [P, P, P, I64, I64, I64, P, P, P]),

@@ -49,13 +49,17 @@ __device__ __forceinline__ void wan_quant_row(const float (*v)[8], int D, int la
 
 // y = [round_bf16](LN(x)) * w + b, then * (1 + scale[g]) + shift[g]  ->  bf16 (row stride out_ld) and / or e4m3 + per-row scale   (w, b, scale / shift optional)
 // mod: table row stride `mod_stride` floats, shift at column offset 0 of `shift`, scale of `scale` (pointers into the same table)
-template <int XDT, int ODT = VGPA_DTYPE_BF16>
+// GR: the row is first x + yres(bf16) * gate[g] (the gated residual add that precedes this LayerNorm in the block, gate NULL = 1) and that sum is ALSO
+// stored to xo (fp32): one pass of 12 B per element where wan_gate_residual + wan_ln_mod_fwd moved 16.
+template <int XDT, int ODT = VGPA_DTYPE_BF16, bool GR = false>
 __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const void* __restrict__ x, const int* __restrict__ gid, const float* __restrict__ w,
                                                                           const float* __restrict__ b, const float* __restrict__ shift,
                                                                           const float* __restrict__ scale, int64_t mod_stride, int D, int64_t rows, float eps,
                                                                           int round_xhat, void* __restrict__ out, int64_t out_ld,
                                                                           uint8_t* __restrict__ q8, float* __restrict__ q8_scale,
-                                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                          const bf16_t* __restrict__ yres = nullptr, const float* __restrict__ gate = nullptr,
+                                                                          float* __restrict__ xo = nullptr) {
     const int64_t row = wan_row();
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -66,6 +70,14 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const vo
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
             load8<XDT>(x, (size_t)row * D + i0, v[c]);
+            if (GR) {
+                float a[8], gt[8];
+                load8<VGPA_DTYPE_BF16>(yres, (size_t)row * D + i0, a);
+                if (gate) load8<VGPA_DTYPE_F32>(gate, (gid ? (size_t)gid[row] * mod_stride : 0) + i0, gt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = v[c][j] + a[j] * (gate ? gt[j] : 1.f);       // the arithmetic of wan_gate_residual_kernel
+                store8<VGPA_DTYPE_F32>(xo, (size_t)row * D + i0, v[c]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += v[c][j];
         }
@@ -114,11 +126,14 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const vo
 }
 
 // dx = [dres +] LN-backward(dy * (1 + scale[g]) * w)           fp32 out (may alias dres)
-template <int XDT, int DYDT = VGPA_DTYPE_BF16>
+// GB: the result is also handed to the gated residual add in front of this LayerNorm: dyp(bf16, row stride ld_dyp) = dx * gate_prev[g] (NULL = 1), the
+// arithmetic of wan_gate_bwd_kernel, without reading dx back.
+template <int XDT, int DYDT = VGPA_DTYPE_BF16, bool GB = false>
 __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x, const float* __restrict__ mean,
                                                                           const float* __restrict__ rstd, const int* __restrict__ gid, const float* __restrict__ w,
                                                                           const float* __restrict__ scale, int64_t mod_stride, int D, int64_t rows,
-                                                                          const float* dres, float* dx) {
+                                                                          const float* dres, float* dx, const float* __restrict__ gate_prev = nullptr,
+                                                                          bf16_t* __restrict__ dyp = nullptr, int64_t ld_dyp = 0) {
     const int64_t row = wan_row();
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -161,6 +176,13 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const vo
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (dres ? o[j] : 0.f) + rs * (gy[c][j] - c1 - xh[c][j] * c2);
             store8<VGPA_DTYPE_F32>(dx, (size_t)row * D + i0, o);
+            if (GB) {
+                float gt[8];
+                if (gate_prev) load8<VGPA_DTYPE_F32>(gate_prev, g + i0, gt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = o[j] * (gate_prev ? gt[j] : 1.f);
+                store8<VGPA_DTYPE_BF16>(dyp, (size_t)row * ld_dyp + i0, o);
+            }
         }
     }
 }
@@ -377,6 +399,29 @@ extern "C" int32_t vgpa_wan_ln_mod_bwd_f32(const float* dy, const float* x, cons
     if (!dy || !x || !mean || !rstd || !dx || !wan_dims_ok(rows, D)) return VGPA_ERR_INVALID;
     VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_F32, VGPA_DTYPE_F32>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const void*)dy, (const void*)x, mean, rstd, gid,
                 (const float*)nullptr, scale, mod_stride, (int)D, rows, (const float*)nullptr, dx);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+// Fused forms of a block's [gated residual add -> LayerNorm] pairs (x' = x + y * gate[g]; h = LN(x') ...): see the GR / GB notes at the kernels.
+extern "C" int32_t vgpa_wan_gate_ln_mod_fwd(const float* x, const void* y, const int32_t* gid, const float* gate, const float* ln_w, const float* ln_b, const float* shift,
+                                            const float* scale, int64_t mod_stride, int64_t rows, int64_t D, float eps, float* xo, void* out, int64_t out_ld, void* q8,
+                                            float* q8_scale, float* mean, float* rstd, hipStream_t stream) {
+    if (!x || !y || !xo || (!out && !q8) || !wan_dims_ok(rows, D) || (ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale == nullptr) ||
+        (mean == nullptr) != (rstd == nullptr) || (q8 == nullptr) != (q8_scale == nullptr) || (out && (out_ld < D || out_ld % 8)))
+        return VGPA_ERR_INVALID;
+    VGPA_LAUNCH((wan_ln_mod_fwd_kernel<VGPA_DTYPE_F32, VGPA_DTYPE_BF16, true>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const void*)x, gid, ln_w, ln_b, shift, scale,
+                mod_stride, (int)D, rows, eps, 0, out, out_ld, (uint8_t*)q8, q8_scale, mean, rstd, (const bf16_t*)y, gate, xo);
+    VGPA_CHECK_LAUNCH();
+    return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_wan_ln_mod_bwd_gate(const void* dy, const float* x, const float* mean, const float* rstd, const int32_t* gid, const float* ln_w, const float* scale,
+                                            int64_t mod_stride, int64_t rows, int64_t D, const float* dres, float* dx, const float* gate_prev, void* dy_prev,
+                                            int64_t ld_dy_prev, hipStream_t stream) {
+    if (!dy || !x || !mean || !rstd || !dx || !dy_prev || !wan_dims_ok(rows, D) || ld_dy_prev < D || ld_dy_prev % 8) return VGPA_ERR_INVALID;
+    VGPA_LAUNCH((wan_ln_mod_bwd_kernel<VGPA_DTYPE_F32, VGPA_DTYPE_BF16, true>), wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, dy, (const void*)x, mean, rstd, gid, ln_w,
+                scale, mod_stride, (int)D, rows, dres, dx, gate_prev, (bf16_t*)dy_prev, ld_dy_prev);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }

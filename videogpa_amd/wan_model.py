@@ -120,6 +120,52 @@ class _HeadLnModFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class _GateLnFn(torch.autograd.Function):
+    """A block's [gated residual add -> LayerNorm] pair as one node and one pass each way (csrc/wan.hip, GR / GB forms of the LN kernels):
+         x' = x + y * gate[gid]  (fp32; gate None: 1),   h = bf16( LN_eps(x') * ln_w + ln_b, then * (1 + scale[gid]) + shift[gid] )      -> (h, x')
+    x' feeds the branch's own residual add further down, so the backward gets both gradients, forms dx' = dres + LN-backward(dh) and, in the same kernel,
+    dy = bf16(dx' * gate[gid]) -- written as the head of a buffer `dy_pad` wider (the LoRA tail of the output projection's backward GEMM).  Bit-identical to
+    wan_gate_residual followed by wan_ln_mod (tests/test_gpu_wan_kernels.py); 12 instead of 16 bytes per element forward, 16 instead of 20 backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, gid, gate, ln_w, ln_b, shift, scale, eps, pad, dy_pad):
+        rows, D = y.shape
+        x, y = x.contiguous(), y.contiguous()
+        xo = torch.empty(rows, D, dtype=torch.float32, device=y.device)
+        out = ops._padded_empty((rows,), D, pad, torch.bfloat16, y.device) if pad else torch.empty(rows, D, dtype=torch.bfloat16, device=y.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        ms = gate.stride(0) if gate is not None else (shift.stride(0) if shift is not None else 0)
+        if gate is not None and shift is not None and gate.stride(0) != shift.stride(0):
+            raise ValueError("gate and shift / scale must be columns of one modulation table")
+        ops._timed("wan_gate_ln_fwd", 12.0 * rows * D, lambda: _lib.call(
+            "vgpa_wan_gate_ln_mod_fwd", x, y, gid, gate, ln_w, ln_b, shift, scale, ms, rows, D, float(eps), xo, out, D + pad, None, None, mean, rstd, _stream()), "byte")
+        ctx.save_for_backward(xo, mean, rstd, gid, ln_w, scale, gate)
+        ctx.ms, ctx.dy_pad = ms, dy_pad
+        ctx.set_materialize_grads(False)
+        return out, xo
+
+    @staticmethod
+    def backward(ctx, dh, dres):
+        xo, mean, rstd, gid, ln_w, scale, gate = ctx.saved_tensors
+        rows, D = xo.shape
+        pad = ctx.dy_pad
+        if dh is None:        # the LN output was not used: only the residual path carries a gradient (the arithmetic of _GateResidualFn.backward)
+            if dres is None:
+                return (None,) * 11
+            dres = dres.float().contiguous()
+            dy = ops._padded_empty((rows,), D, pad, torch.bfloat16, xo.device) if pad else torch.empty(rows, D, dtype=torch.bfloat16, device=xo.device)
+            ops._timed("wan_gate_bwd", 6.0 * rows * D, lambda: _lib.call("vgpa_wan_gate_bwd", dres, gid, gate, ctx.ms, rows, D, dy, D + pad, _stream()), "byte")
+            return (dres, dy) + (None,) * 9
+        if dres is not None and (dres.dtype != torch.float32 or not dres.is_contiguous()):
+            dres = dres.float().contiguous()
+        dx = torch.empty(rows, D, dtype=torch.float32, device=xo.device)
+        dy = ops._padded_empty((rows,), D, pad, torch.bfloat16, xo.device) if pad else torch.empty(rows, D, dtype=torch.bfloat16, device=xo.device)
+        ops._timed("wan_ln_gate_bwd", (12.0 if dres is None else 16.0) * rows * D, lambda: _lib.call(
+            "vgpa_wan_ln_mod_bwd_gate", dh.contiguous(), xo, mean, rstd, gid, ln_w, scale, ctx.ms, rows, D, dres, dx, gate, dy, D + pad, _stream()), "byte")
+        return dx, dy, None, None, None, None, None, None, None, None, None
+
+
 class _GateResidualFn(torch.autograd.Function):
     """fp32: x + y(bf16) * gate[gid]      (gate None: 1).  dy_pad: the gradient of y is returned as the head of a buffer that much wider (the
     LoRA tail of the output projection's backward GEMM)."""
@@ -244,7 +290,9 @@ class _FfnFp8Fn(torch.autograd.Function):
     backward adds the residual path's gradient inside the LN backward kernel (dres)."""
 
     @staticmethod
-    def forward(ctx, x, gid, shift, scale, gate, eps, W1, b1, W2, b2):
+    def forward(ctx, x, gid, shift, scale, gate, eps, W1, b1, W2, b2, pre=None, pre_dy_pad=0):
+        """pre (bf16 [rows, D]): the branch input is x + pre -- the ungated residual add of the cross-attention in front of this branch, taken into the
+        LN pass (gate_ln_mod_fwd); the backward then also returns pre's gradient (its head in a buffer pre_dy_pad wider)."""
         rows, D = x.shape
         x = x.contiguous()
         dev = x.device
@@ -254,8 +302,15 @@ class _FfnFp8Fn(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=dev)
         rstd = torch.empty_like(mean)
         ms = shift.stride(0)
-        ops._timed("wan_ln_mod_fwd", (x.element_size() + 1.0) * rows * D, lambda: _lib.call(
-            "vgpa_wan_ln_mod_fwd", x, _ptr_dtype(x), gid, None, None, shift, scale, ms, rows, D, float(eps), 0, None, D, hq, hs, mean, rstd, _stream()), "byte")
+        ctx.pre_dy_pad = None if pre is None else int(pre_dy_pad)
+        if pre is not None:
+            xin, x = x, torch.empty(rows, D, dtype=torch.float32, device=dev)
+            ops._timed("wan_gate_ln_fwd", 11.0 * rows * D, lambda: _lib.call(
+                "vgpa_wan_gate_ln_mod_fwd", xin, pre.contiguous(), gid, None, None, None, shift, scale, ms, rows, D, float(eps), x, None, D, hq, hs, mean, rstd,
+                _stream()), "byte")
+        else:
+            ops._timed("wan_ln_mod_fwd", (x.element_size() + 1.0) * rows * D, lambda: _lib.call(
+                "vgpa_wan_ln_mod_fwd", x, _ptr_dtype(x), gid, None, None, shift, scale, ms, rows, D, float(eps), 0, None, D, hq, hs, mean, rstd, _stream()), "byte")
         u = ops._fp8_gemm(hq, hs, w1.q, w1.s, b1)
         gq, gs = ops.gelu_tanh_fwd_q8(u)
         y = ops._fp8_gemm(gq, gs, w2.q, w2.s, b2)
@@ -279,9 +334,15 @@ class _FfnFp8Fn(torch.autograd.Function):
         duq, dus = ops.gelu_tanh_bwd_q8(u, dg)
         dh = ops._fp8_gemm(duq, dus, w1.qt, w1.st)
         dx = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        if ctx.pre_dy_pad is not None:
+            pad = ctx.pre_dy_pad
+            dpre = ops._padded_empty((rows,), D, pad, torch.bfloat16, dev) if pad else torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
+            ops._timed("wan_ln_gate_bwd", 16.0 * rows * D, lambda: _lib.call(
+                "vgpa_wan_ln_mod_bwd_gate", dh, x, mean, rstd, gid, None, scale, ctx.ms, rows, D, dout, dx, None, dpre, D + pad, _stream()), "byte")
+            return dx, None, None, None, None, None, None, None, None, None, dpre, None
         ops._timed("wan_ln_mod_bwd", (x.element_size() + 10.0) * rows * D, lambda: _lib.call(
             "vgpa_wan_ln_mod_bwd", dh, x, _ptr_dtype(x), mean, rstd, gid, None, scale, ctx.ms, rows, D, dout, dx, _stream()), "byte")
-        return dx, None, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None, None, None
 
 
 def ln_mod(x, gid=None, ln_w=None, ln_b=None, shift=None, scale=None, eps=1e-6, round_xhat=False, pad=0, passthrough=False):
@@ -293,17 +354,22 @@ def gate_residual(x, y, gid=None, gate=None, dy_pad=0):
     return _GateResidualFn.apply(x, y, gid, gate, int(dy_pad))
 
 
+def gate_ln(x, y, gid=None, gate=None, ln_w=None, ln_b=None, shift=None, scale=None, eps=1e-6, pad=0, dy_pad=0):
+    """(LN output of x + y * gate, that sum): gate_residual + ln_mod(passthrough=True) in one pass each way (see _GateLnFn)"""
+    return _GateLnFn.apply(x, y, gid, gate, ln_w, ln_b, shift, scale, eps, int(pad), int(dy_pad))
+
+
 def rms_rope(u, w, cos=None, sin=None, head_dim=128, eps=1e-6, grad_pad=0):
     return _RmsRopeFn.apply(u, w, cos, sin, head_dim, eps, int(grad_pad))
 
 
-def ffn_fp8(x, gid, shift, scale, gate, eps, W1, b1, W2, b2):
-    """x fp32 [rows, D] -> x + gate[g] * FFN(ln_mod(x)) with e4m3 GEMM operands (frozen weights)"""
+def ffn_fp8(x, gid, shift, scale, gate, eps, W1, b1, W2, b2, pre=None, pre_dy_pad=0):
+    """x fp32 [rows, D] (+ pre, bf16: a residual add taken into the LN pass) -> x' + gate[g] * FFN(ln_mod(x')) with e4m3 GEMM operands (frozen weights)"""
     if W1.requires_grad or W2.requires_grad or (b1 is not None and b1.requires_grad) or (b2 is not None and b2.requires_grad):
         raise RuntimeError("videogpa_amd: the fp8 path is for frozen projections only")
     if x.dtype != torch.float32:
         raise TypeError("ffn_fp8: fp32 residual stream")
-    return _FfnFp8Fn.apply(x, gid, shift, scale, gate, eps, W1, b1, W2, b2)
+    return _FfnFp8Fn.apply(x, gid, shift, scale, gate, eps, W1, b1, W2, b2, pre, int(pre_dy_pad))
 
 
 def sinusoidal_embedding_1d(dim, position):
@@ -450,17 +516,19 @@ class WanAttentionBlock(nn.Module):
             x = x.float()
         else:
             h, x = ln_mod(x, gid, None, None, tab[:, 0], tab[:, 1], self.eps, pad=sa_in, passthrough=True)
-        x = gate_residual(x, self.self_attn(h, B, L, rope), gid, tab[:, 2], dy_pad=sa_out)
+        # every gated residual add is followed by a LayerNorm of its result: the two run as one pass (gate_ln) wherever both ends are in this block
+        sa = self.self_attn(h, B, L, rope)
         if isinstance(self.norm3, nn.Identity):
+            x = gate_residual(x, sa, gid, tab[:, 2], dy_pad=sa_out)
             h = x.to(torch.bfloat16)
         else:
-            h, x = ln_mod(x, None, _f32(self.norm3.weight), _f32(self.norm3.bias), None, None, self.eps, pad=ca_in, passthrough=True)
-        x = gate_residual(x, self.cross_attn(h, context, B, L), None, None, dy_pad=ca_out)
+            h, x = gate_ln(x, sa, gid, tab[:, 2], _f32(self.norm3.weight), _f32(self.norm3.bias), None, None, self.eps, pad=ca_in, dy_pad=sa_out)
+        ca = self.cross_attn(h, context, B, L)
         f0, f2 = self.ffn[0], self.ffn[2]
         if self.fp8_ffn and f0.weight.shape[0] <= 16384:       # one feed-forward row per workgroup in the GELU -> e4m3 kernels (csrc/fp8.hip)
-            return ffn_fp8(x, gid, tab[:, 3], tab[:, 4], tab[:, 5], self.eps, f0.weight, f0.bias, f2.weight, f2.bias)
+            return ffn_fp8(x, gid, tab[:, 3], tab[:, 4], tab[:, 5], self.eps, f0.weight, f0.bias, f2.weight, f2.bias, pre=ca, pre_dy_pad=ca_out)
         lin = ops.frozen_linear_fp8 if self.fp8_ffn else ops.frozen_linear
-        h = ln_mod(x, gid, None, None, tab[:, 3], tab[:, 4], self.eps)
+        h, x = gate_ln(x, ca, gid, None, None, None, tab[:, 3], tab[:, 4], self.eps, dy_pad=ca_out)
         y = lin(ops.gelu_tanh(lin(h, f0.weight, f0.bias)), f2.weight, f2.bias)
         return gate_residual(x, y, gid, tab[:, 5])
 
