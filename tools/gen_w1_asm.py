@@ -1221,6 +1221,143 @@ class Dq128Loop:
         return em.text() + "\n"
 
 
+# ------------------------------------------------------------------------------------- dQ, head_dim 128, two q-blocks per wave
+class Dq128x2Loop:
+    """Dq128Loop with TWO 32-row q-blocks j per wave, so that every streamed K / V fragment feeds two MFMAs (the matrix pipe's energy floor is 0.74 J per
+       TFLOP and every 1 KiB fragment read per MFMA adds 0.24: tools/mfma_energy_probe.hip, DESIGN section 4.1 -- one read per MFMA was the price of
+       Dq128Loop).  dQ^T (128) + the Q and dO fragments of both blocks (64 + 64) fill the accumulator half of the register file, so the fragment ring
+       lives in VGPRs and the -lse2 / -delta srcC tuples (64 registers for two blocks) are gone: the score chain starts from the inline constant 0 and
+         B(g): p = exp2(fma(c, S, -lse2[q])),  dS = (DP - delta[q]) * p,  D[g&1][j] = bf16(dS)        144 VALU per half-step (9 per element pair)
+         A(g): S[g&1][j] = K_g Q_j^T,  DP[g&1][j] = V_g dO_j^T                                         32 MFMAs
+         C(g): dQ^T[j][db] += K_g^T D[g&1][j]                                                          16 MFMAs on transpose-read K fragments
+       24 fragment reads per 48 MFMAs.  Pipeline fill / drain and keys past the end as in Dq128Loop: whatever dS such a key gets multiplies a zero K row.
+       register map   a[0:127] dq[j][db]   a[128:191] qf[j][ks]   a[192:255] dof[j][ks]
+                      v[0:127] S / DP [p][j] (s dp)   v[128:159] D[p][j][cc]   v[160:191] fragment ring (8 x 4)
+                      v[192:223] lane LDS offsets [slot pair][16]   v[224:231] LDS-DMA source offsets (K x4, V x4)   v232 v233 -lse2[q_j]   v234 v235 -delta[q_j]"""
+
+    LA = 192
+    VOFF = 224
+    NL = 232
+    ND = 234
+    FR = 160
+    NFR = 8
+    LEAD = KNOB.get("lead", 6)
+
+    def S(self, p, j):
+        return 64 * p + 32 * j
+
+    def DP(self, p, j):
+        return 64 * p + 32 * j + 16
+
+    def D(self, p, j, cc):
+        return 128 + 16 * p + 8 * j + 4 * cc
+
+    def frag_reg(self, f):
+        return self.FR + 4 * (f % self.NFR)
+
+    def issue_frag(self, em, f, slotA, kbA, slotC, kbC, tag=None):
+        """f 0..7: transposed K fragments (cc, db) = (f >> 2, f & 3) of the PREVIOUS half; 8..15: K rows ks; 16..23: V rows ks"""
+        tag = f if tag is None else tag
+        r = self.frag_reg(f)
+        if f < 8:
+            cc, db = f >> 2, f & 3
+            base = self.LA + 16 * (slotC >> 1) + 8 + 2 * db
+            off = (slotC & 1) * 32768 + kbC * 8192 + cc * 4096
+            em.ds(f"ds_read_b64_tr_b16 {vr(r, 2)}, v{base} offset:{off}", tag)
+            em.ds(f"ds_read_b64_tr_b16 {vr(r + 2, 2)}, v{base + 1} offset:{off}", tag)
+        else:
+            isv = f >= 16
+            base = self.LA + 16 * (slotA >> 1) + ((f - 8) & 7)
+            em.ds(f"ds_read_b128 {vr(r, 4)}, v{base} offset:{(slotA & 1) * 32768 + (16384 if isv else 0) + kbA * 8192}", tag)
+
+    def mfmas(self, pa, pc):
+        out = []
+        for c in range(8):
+            cc, db = c >> 2, c & 3
+            for j in range(2):
+                d = ar(64 * j + 16 * db, 16)
+                out.append((f"{MFMA} {d}, {vr(self.frag_reg(c), 4)}, {vr(self.D(pc, j, cc), 4)}, {d}", c))
+        for ks in range(8):
+            for j in range(2):
+                d = vr(self.S(pa, j), 16)
+                out.append((f"{MFMA} {d}, {vr(self.frag_reg(8 + ks), 4)}, {ar(128 + 32 * j + 4 * ks, 4)}, {'0' if ks == 0 else d}", 8 + ks))
+        for ks in range(8):
+            for j in range(2):
+                d = vr(self.DP(pa, j), 16)
+                out.append((f"{MFMA} {d}, {vr(self.frag_reg(16 + ks), 4)}, {ar(192 + 32 * j + 4 * ks, 4)}, {'0' if ks == 0 else d}", 16 + ks))
+        return out
+
+    def valu_ops(self, pb):
+        if "novalu" in ABLATE:
+            return []
+
+        def unit(u):
+            j, p = u >> 3, u & 7
+            s0, d0 = self.S(pb, j) + 2 * p, self.DP(pb, j) + 2 * p
+            w = self.D(pb, j, p >> 2) + (p & 3)
+            return ([f"v_fma_f32 v{s0}, %[cs], v{s0}, v{self.NL + j}", f"v_fma_f32 v{s0 + 1}, %[cs], v{s0 + 1}, v{self.NL + j}",
+                     f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                    [f"v_add_f32 v{d0}, v{self.ND + j}, v{d0}", f"v_add_f32 v{d0 + 1}, v{self.ND + j}, v{d0 + 1}"],
+                    [f"v_mul_f32 v{s0}, v{d0}, v{s0}", f"v_mul_f32 v{s0 + 1}, v{d0 + 1}, v{s0 + 1}"],
+                    f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
+        ops = list(unit(0)[0])
+        for t in range(17):
+            x = unit(t + 1)[0] if t + 1 < 16 else [None] * 4
+            a = unit(t)[1] if t < 16 else [None, None]
+            m = unit(t)[2] if t < 16 else [None, None]
+            c = unit(t - 1)[3] if 1 <= t else None
+            # no instruction directly follows one it depends on; a v_exp result is first used two steps later
+            ops += [o for o in (a[0], x[0], a[1], x[1], m[0], x[2], m[1], x[3], c) if o is not None]
+        return ops
+
+    def half_step(self, em, slotA, kbA, slotC, kbC, pa, nxt, fill_first=()):
+        need = {f: 2 * f for f in range(24)}
+        post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
+        em.retag({("n", f): f for f in range(4)})
+        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+                 pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
+
+    def generate(self):
+        em = Emitter()
+        SAVE_M0, CNT = "%0", "%1"
+        RK, RV, KSTEP, VSTEP, WBASE, NITER = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]"
+        em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        em.raw(f"s_mov_b32 {CNT}, {NITER}")
+        for i in range(128):
+            em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        for r in list(range(64, 128)) + list(range(128, 144)):      # S / DP[1], D[0]
+            em.raw(f"v_mov_b32 v{r}, 0")
+        for f in range(4):
+            self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        em.raw("L_w1dq128x2_loop_%=:")
+        for ph in range(4):
+            em.raw("s_waitcnt vmcnt(8)")
+            if "nosync" not in ABLATE:
+                em.raw("s_barrier")
+            dst = ((ph + 2) & 3) * 32768
+            fill = []
+            for k in range(8):
+                isv = k >= 4
+                fill.append([f"s_add_u32 m0, {WBASE}, {dst + (16384 if isv else 0) + (k & 3) * 1024}"])
+                fill.append([f"buffer_load_dwordx4 v{self.VOFF + k}, {RV if isv else RK}, 0 offen lds",
+                             f"v_add_u32 v{self.VOFF + k}, {VSTEP if isv else KSTEP}, v{self.VOFF + k}"])
+            sp = (ph - 1) & 3
+            self.half_step(em, ph, 0, sp, 0, 0, nxt=(sp, 1), fill_first=fill)
+            self.half_step(em, ph, 1, sp, 1, 1, nxt=(ph, 0))
+            em.raw(f"s_sub_u32 {CNT}, {CNT}, 1")
+            em.raw(f"s_cmp_eq_u32 {CNT}, 0")
+            if ph < 3:
+                em.raw("s_cbranch_scc1 L_w1dq128x2_done_%=")
+            else:
+                em.raw("s_cbranch_scc0 L_w1dq128x2_loop_%=")
+        em.raw("L_w1dq128x2_done_%=:")
+        em.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        em.raw("s_nop 7")
+        em.raw("s_nop 7")
+        em.raw(f"s_mov_b32 m0, {SAVE_M0}")
+        return em.text() + "\n"
+
+
 # --------------------------------------------------------------------------------------------------------------------- GEMM loop
 class GemmLoop:
     """C^T tile = W A^T for a 256 (M) x 128 (N) output tile, operands both K-contiguous (x [M, K], W [N, K]: y = x W^T), BK = 64 per
@@ -1319,6 +1456,8 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_dkv128_clobbers.inc": lambda: clobbers([(0, 127)], [(192, 255)]),
            "w1_dq128_loop.inc": lambda: Dq128Loop().generate(),
            "w1_dq128_clobbers.inc": lambda: clobbers([(0, 79)], [(128, 223)]),
+           "w1_dq128x2_loop.inc": lambda: Dq128x2Loop().generate(),
+           "w1_dq128x2_clobbers.inc": lambda: clobbers([(0, 191)], []),
            "w1_gemm_loop.inc": lambda: GemmLoop().generate(),
            "w1_gemm_clobbers.inc": lambda: clobbers([], [(128, 175)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),

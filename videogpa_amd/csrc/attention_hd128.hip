@@ -739,6 +739,107 @@ __global__ __launch_bounds__(256, 1) void attn128_dq_w1_kernel(const bf16_t* __r
     if (q < Sq) store_col128(dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s), dq, scale, hi);
 }
 
+// ----------------------------------------------------------------------------------------------------- dQ, w1 structure, two q-blocks per wave
+// Two 32-row q-blocks per wave: every streamed K / V fragment feeds two MFMAs (tools/gen_w1_asm.py::Dq128x2Loop has the register map and the reason:
+// one fragment read per MFMA costs a quarter of the matrix pipe's own energy on this part).  256 query rows per workgroup.
+__global__ __launch_bounds__(256, 1) void attn128_dq_w1x2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                                   const bf16_t* __restrict__ dO, const float* __restrict__ STATS, bf16_t* __restrict__ dQ,
+                                                                   TStride sq, TStride sk, TStride sv, TStride sdo, TStride sdq, int Sq, int Skv, int H, int n_qt,
+                                                                   float c, float scale) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[W1H_RING_BYTES];   // slot = [K tile | V tile]
+    const int vid = xcd_remap128(blockIdx.x, gridDim.x);
+    const int bh = vid / n_qt, qt = vid % n_qt;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int q0 = (qt * 4 + wave) * 64;
+
+    bf16x8_t qf[2][8], dof[2][8];
+    u32x4_t st4;        // -lse2[q_0], -lse2[q_1], -delta[q_0], -delta[q_1]   (the statistics plane holds -lse2 / c: the bf16-kernel convention)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        load_row_frags128(Q + ((size_t)b * sq.b + (size_t)h * sq.h), sq.s, q0 + 32 * j, Sq, lane, qf[j]);
+        load_row_frags128(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h), sdo.s, q0 + 32 * j, Sq, lane, dof[j]);
+        int qc = q0 + 32 * j + (lane & 31);
+        qc = qc < Sq ? qc : Sq - 1;
+        st4[j] = __float_as_uint(STATS[(size_t)bh * 2 * Sq + qc] * c);
+        st4[2 + j] = __float_as_uint(STATS[(size_t)bh * 2 * Sq + Sq + qc]);
+    }
+    const int nt = (Skv + 63) / 64;
+    {   // the pipeline's first transposed reads hit the K tile of ring slot 3: make it finite
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(lds + 3 * W1H_SLOT_BYTES + i * 4096 + threadIdx.x * 16) = z;
+    }
+    __syncthreads();
+
+    const W1Rsrc krs = w1_rsrc(K + ((size_t)b * sk.b + (size_t)h * sk.h), ((uint32_t)(Skv - 1) * sk.s + (uint32_t)D128) * 2u);
+    const W1Rsrc vrs = w1_rsrc(V + ((size_t)b * sv.b + (size_t)h * sv.h), ((uint32_t)(Skv - 1) * sv.s + (uint32_t)D128) * 2u);
+    u32x8_t voff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t row = 4u * (uint32_t)(wave * 4 + i) + (uint32_t)(lane >> 4);
+        const uint32_t cl = (uint32_t)(lane & 15) ^ w1h_swz(row);
+        voff[i] = (row * sk.s + cl * 8u) * 2u;
+        voff[4 + i] = (row * sv.s + cl * 8u) * 2u;
+    }
+    const uint32_t kstep = __builtin_amdgcn_readfirstlane(64u * sk.s * 2u), vstep = __builtin_amdgcn_readfirstlane(64u * sv.s * 2u);
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds + (uint32_t)wave * 4096u);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t dst = wbase + (uint32_t)t * W1H_SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w1_dma(dst + 1024u * i, krs, voff[i], 0u);
+            w1_dma(dst + W1H_TILE_BYTES + 1024u * i, vrs, voff[4 + i], 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { voff[i] += kstep; voff[4 + i] += vstep; }
+    }
+    u32x16_t la[2];
+    {
+        const uint32_t m = lane & 31;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) la[st][ks] = st * 65536u + m * 256u + ((((uint32_t)(2 * ks) + (uint32_t)hi) ^ w1h_swz(m)) << 4);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r3 = 0; r3 < 2; ++r3) {
+                    const uint32_t rr = 4u * hi + ((uint32_t)(lane & 15) >> 2) + 8u * r3;
+                    const uint32_t cc = 4u * db + 2u * ((uint32_t)(lane >> 4) & 1u) + (((uint32_t)lane & 3u) >> 1);
+                    la[st][8 + 2 * db + r3] = st * 65536u + rr * 256u + ((cc ^ w1h_swz(rr)) << 4) + ((uint32_t)lane & 1u) * 8u;
+                }
+        }
+    }
+    const u32x16_t q00 = pack4h(qf[0][0], qf[0][1], qf[0][2], qf[0][3]), q01 = pack4h(qf[0][4], qf[0][5], qf[0][6], qf[0][7]);
+    const u32x16_t q10 = pack4h(qf[1][0], qf[1][1], qf[1][2], qf[1][3]), q11 = pack4h(qf[1][4], qf[1][5], qf[1][6], qf[1][7]);
+    const u32x16_t d00 = pack4h(dof[0][0], dof[0][1], dof[0][2], dof[0][3]), d01 = pack4h(dof[0][4], dof[0][5], dof[0][6], dof[0][7]);
+    const u32x16_t d10 = pack4h(dof[1][0], dof[1][1], dof[1][2], dof[1][3]), d11 = pack4h(dof[1][4], dof[1][5], dof[1][6], dof[1][7]);
+    const uint32_t niter = (uint32_t)(nt + 1);
+    const uint32_t cs = __builtin_amdgcn_readfirstlane(__float_as_uint(c));
+    f32x16_t dq[2][4];
+    uint32_t t0, t1;
+    asm volatile(
+#include "w1_dq128x2_loop.inc"
+        : "=&s"(t0), "=&s"(t1), "={a[0:15]}"(dq[0][0]), "={a[16:31]}"(dq[0][1]), "={a[32:47]}"(dq[0][2]), "={a[48:63]}"(dq[0][3]), "={a[64:79]}"(dq[1][0]),
+          "={a[80:95]}"(dq[1][1]), "={a[96:111]}"(dq[1][2]), "={a[112:127]}"(dq[1][3]), "+{v[224:231]}"(voff)
+        : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [cs] "s"(cs),
+          "{a[128:143]}"(q00), "{a[144:159]}"(q01), "{a[160:175]}"(q10), "{a[176:191]}"(q11), "{a[192:207]}"(d00), "{a[208:223]}"(d01), "{a[224:239]}"(d10),
+          "{a[240:255]}"(d11), "{v[192:207]}"(la[0]), "{v[208:223]}"(la[1]), "{v[232:235]}"(st4)
+        : "memory", "scc",
+#include "w1_dq128x2_clobbers.inc"
+    );
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) asm volatile("" : "+v"(dq[j][db]));
+        const int q = q0 + 32 * j + (lane & 31);
+        if (q < Sq) store_col128(dQ + ((size_t)b * sdq.b + (size_t)h * sdq.h + (size_t)q * sdq.s), dq[j], scale, hi);
+    }
+}
+
 // ===================================================================================================== host
 static inline bool sok128(const int64_t* st) { return st && st[0] >= 0 && st[1] >= 0 && st[2] >= D128 && st[0] % 8 == 0 && st[1] % 8 == 0 && st[2] % 8 == 0; }
 static inline bool rok128(const int64_t* st, int64_t B, int64_t H, int64_t S) { return (B - 1) * st[0] + (H - 1) * st[1] + (S - 1) * st[2] + D128 < ((int64_t)1 << 31); }
@@ -1103,6 +1204,12 @@ extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void*
     return VGPA_OK;
 }
 
+// VGPA_ATTN128_DQ_X2=0 selects the one-q-block-per-wave dQ kernel (A/B measurements)
+static bool attn128_dq_x2() {
+    static const bool v = [] { const char* e = getenv("VGPA_ATTN128_DQ_X2"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 // workspace: delta [B*H*Sq] + the statistics planes [B, H, 2, Sq] (fp32)
 extern "C" size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq) {
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;
@@ -1132,7 +1239,12 @@ extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v,
     const bool w1q = dkv_mode == 1 || (dkv_mode < 0 && Skv >= attn128_min_sweep());     // the dQ kernel sweeps the keys
     VGPA_LAUNCH(attn128_delta_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, mk128(do_strides),
                 mk128(o_strides), (int)Sq, (int)H, total, delta, lse2, 1.f / c, (w1 || w1q) ? stats : (float*)nullptr);
-    if (w1q)
+    if (w1q && attn128_dq_x2()) {
+        const int64_t n_q256 = (Sq + 255) / 256;
+        VGPA_LAUNCH(attn128_dq_w1x2_kernel, dim3((unsigned)(B * H * n_q256)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                    (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
+                    mk128(dq_strides), (int)Sq, (int)Skv, (int)H, (int)n_q256, c, scale);
+    } else if (w1q)
         VGPA_LAUNCH(attn128_dq_w1_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                     (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
                     mk128(dq_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, scale);
