@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void probe(const uint32_t* __restrict__ dat
 // What the operand feed costs: the same stationary-operand bf16 stream with, per group of four MFMAs, RD ds_read_b128 fragment reads (conflict-free,
 // lane-linear; the fragments read ARE the A operands of the next group) and VA x {2 v_exp_f32, 1 v_cvt_pk_bf16_f32, 2 v_add_f32} (the softmax mix of the
 // attention forward: 5 VALU per MFMA at VA = 4; the backward kernels carry 3 per MFMA).
-template <int RD, int VA>
+template <int RD, int VA, int DM = 0>
 __global__ __launch_bounds__(256, 1) void probe_mix(const uint32_t* __restrict__ data, float* __restrict__ out, int iters) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[16384];      // 64 KiB of random fragments
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -93,6 +93,22 @@ __global__ __launch_bounds__(256, 1) void probe_mix(const uint32_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = -1.0f - 0.01f * (float)((threadIdx.x + i) & 31);
     uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024;
+    // DM: one LDS-DMA piece (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction) per DM groups of four MFMAs, streamed from an 8 MiB window that every
+    // workgroup walks (L2 / infinity-cache resident, like the K / V tiles all q-tiles of a head re-read) into the upper 32 KiB of the LDS array
+    __shared__ __attribute__((aligned(1024))) uint8_t ring[32768];
+    uint32_t rsrc[4];
+    {
+        const uint64_t a = (uint64_t)data;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+        rsrc[2] = 8u << 20;
+        rsrc[3] = 0x00020000u;
+    }
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    const u4 rs = {rsrc[0], rsrc[1], rsrc[2], rsrc[3]};
+    uint32_t voff = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024 + (blockIdx.x & 7) * 4096;
+    const uint32_t ring0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring + (threadIdx.x >> 6) * 8192);
+    int dmc = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -113,6 +129,12 @@ __global__ __launch_bounds__(256, 1) void probe_mix(const uint32_t* __restrict__
             }
             if (RD >= 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[nxt][0]), "+v"(A[nxt][1]), "+v"(A[nxt][2]), "+v"(A[nxt][3]));
             addr ^= 2048u * (uint32_t)(g + 1);
+            if (DM > 0 && (++dmc % DM) == 0) {
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0\n\ts_waitcnt vmcnt(6)"
+                             : "=&s"(keep) : "s"(ring0 + (uint32_t)((dmc / DM) & 7) * 1024u), "v"(voff), "s"(rs) : "memory");
+                voff = (voff + 32768u) & ((8u << 20) - 1u);
+            }
         }
     }
     float s = v[2] + v[5] + v[6];
@@ -163,16 +185,16 @@ static void run(const char* name, const uint32_t* data, float* out, int waves_pe
            j1 > j0 ? flop / (j1 - j0) / 1e12 : -1.0);
 }
 
-template <int RD, int VA>
+template <int RD, int VA, int DM = 0>
 static void run_mix(const char* name, const uint32_t* data, float* out, double seconds) {
     const int blocks = 256;
     const double flop_per_iter = 16.0 * 2 * 32 * 32 * 16 * 4.0 * blocks;
     int iters = 100000;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    probe_mix<RD, VA><<<blocks, 256>>>(data, out, iters);
+    probe_mix<RD, VA, DM><<<blocks, 256>>>(data, out, iters);
     CHECK(hipEventRecord(e0));
-    probe_mix<RD, VA><<<blocks, 256>>>(data, out, iters);
+    probe_mix<RD, VA, DM><<<blocks, 256>>>(data, out, iters);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms1;
@@ -181,7 +203,7 @@ static void run_mix(const char* name, const uint32_t* data, float* out, double s
     CHECK(hipDeviceSynchronize());
     const double j0 = joules();
     CHECK(hipEventRecord(e0));
-    for (int i = 0; i < n; ++i) probe_mix<RD, VA><<<blocks, 256>>>(data, out, iters);
+    for (int i = 0; i < n; ++i) probe_mix<RD, VA, DM><<<blocks, 256>>>(data, out, iters);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     const double j1 = joules();
@@ -231,6 +253,9 @@ int main() {
         run_mix<0, 4>("  + 7 VALU per MFMA (.. on 4 of 4)", data, out, 1.5);
         run_mix<4, 2>("  + 1 fragment read + 3.5 VALU per MFMA (~ the backward kernels)", data, out, 1.5);
         run_mix<2, 4>("  + 0.5 fragment read + 7 VALU per MFMA (~ the forward)", data, out, 1.5);
+        run_mix<0, 0, 4>("  + 1 KiB LDS-DMA per 16 MFMAs (~ the dK/dV stream)", data, out, 1.5);
+        run_mix<0, 0, 2>("  + 1 KiB LDS-DMA per 8 MFMAs (~ the forward / dQ stream)", data, out, 1.5);
+        run_mix<0, 0, 1>("  + 1 KiB LDS-DMA per 4 MFMAs (~ a 256 x 128 GEMM tile: 12 per 32)", data, out, 1.5);
     }
     return 0;
 }
