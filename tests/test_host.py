@@ -220,3 +220,20 @@ def test_kernel_timer_samples_all_launches_on_the_first_steps_and_the_roofline_k
         full.run("ln", 1.0, lambda: None, "byte")
         full.next_step()
     assert full.summary()["ln"]["launches"] == 3 and full.summary()["ln"]["steps"] == 3
+
+
+def test_bench_energy_report_arithmetic_and_missing_counter():
+    """bench.py::energy_report: joules per step, mean power and TFLOP per joule from two counter readings; None when the counter is not there (no
+    librocm_smi64 in this container) or did not advance -- the JSON line then carries "energy": null instead of a made-up number."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.energy_report(None, 5.0, 1.0, 2, 1e12) is None and bench.energy_report(5.0, None, 1.0, 2, 1e12) is None
+    assert bench.energy_report(10.0, 10.0, 1.0, 2, 1e12) is None
+    r = bench.energy_report(100.0, 6100.0, 4.0, 2, 2.4e15, 3.0e15)
+    assert r["joules_per_step"] == 3000.0 and r["mean_power_w"] == 1500.0
+    assert abs(r["algorithmic_tflop_per_joule"] - 0.8) < 1e-12 and abs(r["executed_tflop_per_joule"] - 1.0) < 1e-12
+    j = bench.read_joules(0)
+    assert j is None or j >= 0.0

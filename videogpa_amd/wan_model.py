@@ -129,6 +129,8 @@ class _GateLnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, gid, gate, ln_w, ln_b, shift, scale, eps, pad, dy_pad):
+        if x.dtype != torch.float32 or y.dtype != torch.bfloat16 or x.shape != y.shape:
+            raise TypeError(f"gate_ln: fp32 residual stream and a bf16 branch output of the same shape, got {x.dtype} {tuple(x.shape)} / {y.dtype} {tuple(y.shape)}")
         rows, D = y.shape
         x, y = x.contiguous(), y.contiguous()
         xo = torch.empty(rows, D, dtype=torch.float32, device=y.device)
@@ -303,6 +305,8 @@ class _FfnFp8Fn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         ms = shift.stride(0)
         ctx.pre_dy_pad = None if pre is None else int(pre_dy_pad)
+        if pre is not None and (pre.dtype != torch.bfloat16 or pre.shape != x.shape):
+            raise TypeError(f"ffn_fp8: `pre` is the bf16 output of the branch in front, shape {tuple(x.shape)}; got {pre.dtype} {tuple(pre.shape)}")
         if pre is not None:
             xin, x = x, torch.empty(rows, D, dtype=torch.float32, device=dev)
             ops._timed("wan_gate_ln_fwd", 11.0 * rows * D, lambda: _lib.call(
