@@ -553,6 +553,10 @@ class FwdLoop:
             s0 = self.S(pb, j) + 2 * p
             w = self.PK(pb, j, p >> 2) + (p & 3)
             l0, l1 = 128 + 4 * j + ((2 * p) & 3), 128 + 4 * j + ((2 * p + 1) & 3)
+            if KNOB.get("pksum"):      # the two row-sum adds as ONE packed add (same fp32 additions in the same order: bit-identical results)
+                return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
+                        [f"v_pk_add_f32 {vr(l0, 2)}, {vr(l0, 2)}, {vr(s0, 2)}", None],
+                        f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
             return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
                     [f"v_add_f32 v{l0}, v{l0}, v{s0}", f"v_add_f32 v{l1}, v{l1}, v{s0 + 1}"],
                     f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
