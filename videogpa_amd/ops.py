@@ -452,12 +452,43 @@ def _transposed(W):
     return c[1]
 
 
-def _gemm(x2, W, bias=None):
+# Rows per vendor-GEMM call (0 = one call).  hipBLASLt's bf16 kernels lose ~10 % at M = 36 960 (two Wan2.2 samples as one batch) against two calls of
+# M = 18 480, also inside the power-limited step: cfg5 bf16 GEMMs 300 -> 272 ms per step, measured A/B in one session (profiles/r04_gemm_split_ab.txt);
+# at the CogVideoX shapes (M = 35 552) the same split changes nothing or costs (feed-forward shapes: +20 ms), and the fp8 GEMMs do not care.  So the
+# split is set by the model that knows its rows per sample (WanModel.forward) and applies only to row counts that are a multiple of it.
+# VGPA_GEMM_SPLIT_M in the environment overrides the models' choice (0 = never split); VGPA_GEMM_SPLIT_EXT_ONLY=1 restricts it to the LoRA-extended GEMMs.
+_GEMM_SPLIT_ENV = _os.environ.get("VGPA_GEMM_SPLIT_M")
+GEMM_SPLIT_M = int(_GEMM_SPLIT_ENV) if _GEMM_SPLIT_ENV is not None else 0
+GEMM_SPLIT_EXT_ONLY = _os.environ.get("VGPA_GEMM_SPLIT_EXT_ONLY", "0") == "1"
+
+
+def set_gemm_rows_per_call(rows):
+    """called by a model's forward with its rows per sample (0: one call per GEMM); the backward of the same step sees the same setting"""
+    global GEMM_SPLIT_M
+    if _GEMM_SPLIT_ENV is None:
+        GEMM_SPLIT_M = int(rows)
+
+
+def _linear_rows(x2, W, bias, ext=False):
+    M = x2.shape[0]
+    if GEMM_SPLIT_M <= 0 or M < 2 * GEMM_SPLIT_M or M % GEMM_SPLIT_M or not x2.is_cuda or (GEMM_SPLIT_EXT_ONLY and not ext):
+        return torch.nn.functional.linear(x2, W, bias)
+    out = torch.empty(M, W.shape[0], dtype=x2.dtype, device=x2.device)
+    for a in range(0, M, GEMM_SPLIT_M):
+        b = a + GEMM_SPLIT_M
+        if bias is None:
+            torch.mm(x2[a:b], W.t(), out=out[a:b])
+        else:
+            torch.addmm(bias, x2[a:b], W.t(), out=out[a:b])
+    return out
+
+
+def _gemm(x2, W, bias=None, ext=False):
     """x2 [M,K] @ W[N,K]^T (+ bias) through hipBLASLt (torch), timed like the hand-written kernels when bench.py asks for it."""
     if TIMER is None:
-        return torch.nn.functional.linear(x2, W, bias)
+        return _linear_rows(x2, W, bias, ext)
     out = []
-    _timed("hipblaslt_gemm (vendor)", 2.0 * x2.shape[0] * W.shape[0] * W.shape[1], lambda: out.append(torch.nn.functional.linear(x2, W, bias)))
+    _timed("hipblaslt_gemm (vendor)", 2.0 * x2.shape[0] * W.shape[0] * W.shape[1], lambda: out.append(_linear_rows(x2, W, bias, ext)))
     return out[0]
 
 
@@ -635,6 +666,7 @@ def _fp8_gemm(xq, sx, wq, sw, bias=None):
     """bf16 [M, N] = (xq * sx) (wq * sw)^T through the vendor fp8 GEMM (hipBLASLt); xq [M, K], wq [N, K] e4m3, sx [M, 1], sw [1, N]"""
     M, N, K = xq.shape[0], wq.shape[0], xq.shape[1]
     out = []
+
     _timed("hipblaslt_gemm_fp8 (vendor)", 2.0 * M * N * K,
            lambda: out.append(torch._scaled_mm(xq, wq.t(), scale_a=sx, scale_b=sw, bias=bias, out_dtype=torch.bfloat16)))
     return out[0]
@@ -689,7 +721,7 @@ class _LinearLoraExtFn(torch.autograd.Function):
         if enabled:
             lora_down(xv, ext.A_cat, out=tv)       # raw kernel write into the tail (no autograd version bump on the producer's buffer)
         # disabled (reference pass): the tail of a `_padded_empty` buffer is zero since its allocation
-        y = _gemm(x_ext, ext.W_ext, bias)
+        y = _gemm(x_ext, ext.W_ext, bias, ext=True)
         if x_recompute is not None and enabled:
             fn, srcs = x_recompute
             ctx.save_for_backward(tv.contiguous(), *srcs)     # the recompute sources go through autograd's saved-tensor checks (in-place version, lifetime)
@@ -714,7 +746,7 @@ class _LinearLoraExtFn(torch.autograd.Function):
         if enabled:
             for j, i in enumerate(act):
                 lora_down(dy_ext[:, i * Dn:(i + 1) * Dn], ext.sBt[j], out=dy_ext[:, N + j * rp:N + (j + 1) * rp])      # dT_i = dy_i (s B_i)
-        dx = _gemm(dy_ext, ext.Wt_ext)                                                                                # dy W + dT A
+        dx = _gemm(dy_ext, ext.Wt_ext, ext=True)                                                                                # dy W + dT A
         out_grads = [None] * len(ctx.needs_input_grad[6:])
         if enabled:
             if ctx.x_fn is not None:

@@ -403,6 +403,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         if not hidden_states.is_cuda:
             raise RuntimeError("videogpa_amd.CogVideoXTransformer3DModel runs on MI355X only (no CPU fallback)")
         B, Fr, C, H, W = hidden_states.shape
+        ops.set_gemm_rows_per_call(0)       # one vendor-GEMM call per projection at these shapes (splitting by sample measured neutral to slower: ops.GEMM_SPLIT_M)
         p = cfg.patch_size
         dt = self.dtype
         if dt != torch.bfloat16:

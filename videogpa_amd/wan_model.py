@@ -559,6 +559,7 @@ class WanModel(nn.Module):
     def __init__(self, model_type="ti2v", patch_size=(1, 2, 2), text_len=512, in_dim=48, dim=3072, ffn_dim=14336, freq_dim=256, text_dim=4096,
                  out_dim=48, num_heads=24, num_layers=30, window_size=(-1, -1), qk_norm=True, cross_attn_norm=True, eps=1e-6):
         super().__init__()
+        self.gemm_rows_per_sample = True      # batched samples go through the bf16 vendor GEMMs one sample per call (ops.GEMM_SPLIT_M)
         assert model_type in ("t2v", "i2v", "ti2v", "s2v")
         self.model_type, self.patch_size, self.text_len, self.in_dim, self.dim, self.ffn_dim = model_type, tuple(patch_size), text_len, in_dim, dim, ffn_dim
         self.freq_dim, self.text_dim, self.out_dim, self.num_heads, self.num_layers, self.eps = freq_dim, text_dim, out_dim, num_heads, num_layers, eps
@@ -718,6 +719,7 @@ class WanModel(nn.Module):
         L = f * h * w
         if seq_len != L:
             raise NotImplementedError(f"seq_len {seq_len} != token count {L}: padded sequences are not on the training path (03_train.py:176-179)")
+        ops.set_gemm_rows_per_call(L if B > 1 and self.gemm_rows_per_sample else 0)      # one vendor-GEMM call per sample: see ops.GEMM_SPLIT_M
         dev = xb.device
         wdt = self.patch_embedding.weight.dtype
         # patch embedding: Conv3d with kernel = stride = patch  ==  one GEMM over the (c, pt, ph, pw) patch vectors
