@@ -301,7 +301,7 @@ class _ResidualLNFn(torch.autograd.Function):
         LoRA down-projections into the tail and runs ONE GEMM over K = D+n_pad); dy_pad: the same for the gradient of y."""
         _req(x, torch.bfloat16), _req(ln_w, torch.float32), _req(ln_b, torch.float32)
         B, S, D = x.shape
-        n = _padded_empty((B, S), D, n_pad, x.dtype, x.device) if n_pad else torch.empty_like(x)
+        n = _padded_empty((B, S), D, n_pad, x.dtype, x.device) if n_pad else _empty_rows(x.shape, x.dtype, x.device)
         mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         sv, s1v, st, s1t, mstride = _mod_ptrs(mod)
@@ -333,7 +333,7 @@ class _ResidualLNFn(torch.autograd.Function):
         _, s1v, _, s1t, mstride = _mod_ptrs(mod)
         dyp = ctx.dy_pad
         if ctx.has_y:
-            dy = _padded_empty((B, S), D, dyp, xs.dtype, xs.device) if dyp else torch.empty_like(xs)
+            dy = _padded_empty((B, S), D, dyp, xs.dtype, xs.device) if dyp else _empty_rows(xs.shape, xs.dtype, xs.device)
             gv, gt, gstride = gates[:, 0], gates[:, 1], gates.stride(0)
         else:
             dy, gv, gt, gstride = None, None, None, 0
@@ -366,7 +366,7 @@ class _GateResidualFn(torch.autograd.Function):
         (gates,) = ctx.saved_tensors
         dout = dout.contiguous()
         B, S, D = dout.shape
-        dy = torch.empty_like(dout)
+        dy = _empty_rows(dout.shape, dout.dtype, dout.device)
         _lib.call("vgpa_gate_residual", None, dout, gates[:, 0], gates[:, 1], gates.stride(0), B, S, D, ctx.text_len, dy, _stream())
         return dout, dy, None, None
 
@@ -379,7 +379,7 @@ class _GeluTanhFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u):
         _req(u, torch.bfloat16)
-        out = torch.empty_like(u)
+        out = _empty_rows(u.shape, u.dtype, u.device, wide=True)      # feeds the long-K down-projection
         _timed("gelu_tanh_fwd", 4.0 * u.numel(), lambda: _lib.call("vgpa_gelu_tanh_fwd", u, u.numel(), out, _stream()), "byte")
         ctx.save_for_backward(u)
         return out
@@ -388,7 +388,7 @@ class _GeluTanhFn(torch.autograd.Function):
     def backward(ctx, dy):
         (u,) = ctx.saved_tensors
         dy = dy.contiguous()
-        du = torch.empty_like(u)
+        du = _empty_rows(u.shape, u.dtype, u.device, wide=True)
         _timed("gelu_tanh_bwd", 6.0 * u.numel(), lambda: _lib.call("vgpa_gelu_tanh_bwd", u, dy, u.numel(), du, _stream()), "byte")
         return du
 
@@ -471,6 +471,14 @@ def set_gemm_rows_per_call(rows):
 
 def _linear_rows(x2, W, bias, ext=False):
     M = x2.shape[0]
+    if GEMM_ROW_SLACK and 16384 <= M <= 65536 and x2.is_cuda and x2.dim() == 2 and x2.stride(1) == 1 and (GEMM_SPLIT_M <= 0 or M % GEMM_SPLIT_M):
+        # the operand was allocated with row slack (_empty_rows): run the GEMM over the padded row count -- rows are independent, the extra output rows are
+        # never read -- because hipBLASLt is 1-17 % faster at M = 35 840 / 36 864 than at 35 552 (tools/gemm_m_probe.py)
+        room = x2.untyped_storage().nbytes() // x2.element_size()
+        for Mp in (gemm_rows(M, W.shape[0], W.shape[1]), gemm_rows(M)):
+            if Mp > M and x2.storage_offset() + (Mp - 1) * x2.stride(0) + x2.shape[1] <= room:
+                xp = torch.as_strided(x2, (Mp, x2.shape[1]), x2.stride(), x2.storage_offset())
+                return torch.nn.functional.linear(xp, W, bias)[:M]
     if GEMM_SPLIT_M <= 0 or M < 2 * GEMM_SPLIT_M or M % GEMM_SPLIT_M or not x2.is_cuda or (GEMM_SPLIT_EXT_ONLY and not ext):
         return torch.nn.functional.linear(x2, W, bias)
     out = torch.empty(M, W.shape[0], dtype=x2.dtype, device=x2.device)
@@ -533,11 +541,46 @@ def bump_adapter_epoch():
     ADAPTER_EPOCH += 1
 
 
+# Row slack for vendor-GEMM operands.  hipBLASLt's bf16 kernels are markedly faster when the row count is a multiple of 1024 (35 840 instead of cfg2's 35 552:
+# fused q/k/v projection -6.7 %, attention-out projection -17 %, FF1 -2 %, for 0.8 % more rows; tools/gemm_m_probe.py, profiles/r04_gemm_m_probe.txt).  GEMM rows are
+# independent, so the activation buffers that feed GEMMs are allocated with that many rows of STORAGE (logical shape unchanged, contents of the slack never read
+# by anything but the GEMM, whose extra output rows nobody reads) and _linear_rows runs over the padded count.  Only when the padding is <= 1.25 % of the rows.
+GEMM_ROW_SLACK = _os.environ.get("VGPA_GEMM_ROW_SLACK", "1") == "1"
+
+
+def gemm_rows(M, N=None, K=None, wide=False):
+    """the row count a vendor GEMM with M real rows is run over.  Multiples of 1024 when that costs <= 1.25 % more rows; the long-K, narrow-N shape
+    (feed-forward down-projection and the dX of the up-projection: N = 3072, K = 12 288) is 5 % faster still at a multiple of 4096 (36 864 for
+    35 552: profiles/r04_gemm_m_probe.txt), taken when it costs <= 4 %.  wide=True: the largest count any shape may ask for (allocation size)."""
+    if not GEMM_ROW_SLACK or M < 16384 or M > 65536:      # measured: gain at 35 552 rows (cfg2 / cfg3), loss at 82 052 (cfg4: 82 944 rows cost +26 ms of GEMM time per step)
+        return M
+    Mp = (M + 1023) // 1024 * 1024
+    Mp = Mp if (Mp - M) * 80 <= M else M
+    if wide or (K is not None and N is not None and K >= 8192 and N <= 4096 and K >= 3 * N):
+        Mw = (M + 4095) // 4096 * 4096
+        if (Mw - M) * 25 <= M:
+            return Mw
+    return Mp
+
+
+def _empty_rows(shape, dtype, device, wide=False):
+    """torch.empty(shape) whose storage has room for gemm_rows(rows) rows of the last dimension (rows = product of the leading dimensions); not a view"""
+    shape = tuple(int(v) for v in shape)
+    rows = 1
+    for v in shape[:-1]:
+        rows *= v
+    Mp = gemm_rows(rows, wide=wide)
+    if Mp == rows or str(device).startswith("cpu"):
+        return torch.empty(shape, dtype=dtype, device=device)
+    t = torch.empty(Mp * shape[-1], dtype=dtype, device=device)
+    return t.resize_(shape)
+
+
 def _padded_empty(shape, D, pad, dtype, device):
     """A fresh [..., D + pad] buffer whose tail is zero, marked as a padded operand buffer; returns its [..., :D] head view.  The
     producers of LoRA-carrying GEMM operands (residual_ln, attention, their backwards) allocate through this; `_padded_base`
     recognises ONLY buffers made here (a caller's slice of some wider tensor is never written into)."""
-    buf = torch.empty(*shape, D + pad, dtype=dtype, device=device)
+    buf = _empty_rows((*shape, D + pad), dtype, device)
     buf[..., D:].zero_()          # fresh tensor, no autograd history: the reference pass's LoRA tail is zero without touching a view later
     buf._vgpa_pad = (D, pad)
     return buf[..., :D]
