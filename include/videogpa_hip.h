@@ -122,10 +122,10 @@ int32_t vgpa_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, f
 size_t vgpa_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t S);
 int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_strides, const int64_t* do_strides, float* delta,
                             int64_t B, int64_t H, int64_t S, int64_t head_dim, vgpa_stream_t stream);
-/* The same with the forward's rounding residual o_res = O_fp32 - bf16(O) (vgpa_attn_fwd_w1_res; bf16 view with its own strides, may be
- * NULL): delta = rowsum(dO o (O + O_res)).  delta stands for rowsum(P o dP), which equals rowsum(dO o O) for the UNROUNDED O only; from the
- * bf16 O alone (what flash-attention backwards, torch's included, do) every row's dS stops summing to zero and dQ picks up a coherent error. */
-int32_t vgpa_attn_bwd_delta_res(const void* o, const void* o_res, const void* d_o, const int64_t* o_strides, const int64_t* ores_strides,
+/* The same from the output as the forward's residual tensor completes it (o_res / res_kind as vgpa_attn_fwd_w1_res wrote them; o_res may be
+ * NULL).  delta stands for rowsum(P o dP), which equals rowsum(dO o O) for the UNROUNDED O only; from the bf16 O alone (what flash-attention
+ * backwards, torch's included, do) every row's dS stops summing to zero and dQ picks up a coherent error. */
+int32_t vgpa_attn_bwd_delta_res(const void* o, const void* o_res, int32_t res_kind, const void* d_o, const int64_t* o_strides, const int64_t* ores_strides,
                                 const int64_t* do_strides, float* delta, int64_t B, int64_t H, int64_t S, int64_t head_dim,
                                 vgpa_stream_t stream);
 int32_t vgpa_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
@@ -151,9 +151,15 @@ size_t vgpa_attn_fwd_w1_workspace_bytes(int64_t B, int64_t H, int64_t S);
 int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
                          const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
                          int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
-/* vgpa_attn_fwd_w1 that also writes o_res = O_fp32 - bf16(O) as bf16 ([B,H,S,64] view, own strides; NULL = plain vgpa_attn_fwd_w1): with it the
- * pair (o, o_res) carries the attention output to ~2^-17 for the backward's delta (vgpa_attn_bwd_prep_w1_res / vgpa_attn_bwd_delta_res). */
-int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* o, void* o_res, float* lse2, const int64_t* q_strides,
+/* vgpa_attn_fwd_w1 that also writes what the bf16 rounding of the output dropped ([B,H,S,64] view o_res with its own ELEMENT strides; NULL = plain
+ * vgpa_attn_fwd_w1), for the backward's delta (vgpa_attn_bwd_prep_w1_res / vgpa_attn_bwd_delta_res).  res_kind:
+ *   VGPA_RES_BF16 (1)  bf16 elements: O_fp32 - bf16(O);
+ *   VGPA_RES_8    (2)  uint8 elements: eight further mantissa bits, 128 + clamp(rint((O_fp32 - bf16(O)) * 2^8 / ulp(bf16(O))), -128, 127).
+ * Either way (o, o_res) carries the output to 2^-17 relative; the 8-bit form costs half the bytes (1 per output element). */
+#define VGPA_RES_NONE 0
+#define VGPA_RES_BF16 1
+#define VGPA_RES_8 2
+int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* o, void* o_res, int32_t res_kind, float* lse2, const int64_t* q_strides,
                              const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* ores_strides,
                              int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace,
                              size_t ws_bytes, vgpa_stream_t stream);
@@ -161,7 +167,7 @@ int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* 
  * planes stats = fp32 [B,H,2,S] = {-lse2, -delta}; vgpa_attn_bwd_dkv_w1 = vgpa_attn_bwd_dkv_ws on the w1 structure, reading `stats`. */
 int32_t vgpa_attn_bwd_prep_w1(const void* o, const void* d_o, const float* lse2, const int64_t* o_strides, const int64_t* do_strides,
                               float* delta, float* stats, int64_t B, int64_t H, int64_t S, int64_t head_dim, vgpa_stream_t stream);
-int32_t vgpa_attn_bwd_prep_w1_res(const void* o, const void* o_res, const void* d_o, const float* lse2, const int64_t* o_strides,
+int32_t vgpa_attn_bwd_prep_w1_res(const void* o, const void* o_res, int32_t res_kind, const void* d_o, const float* lse2, const int64_t* o_strides,
                                   const int64_t* ores_strides, const int64_t* do_strides, float* delta, float* stats, int64_t B, int64_t H,
                                   int64_t S, int64_t head_dim, vgpa_stream_t stream);
 int32_t vgpa_attn_bwd_dkv_w1(const void* q, const void* k, const void* v, const void* d_o, const float* stats, void* dk, void* dv,
@@ -233,9 +239,11 @@ int32_t vgpa_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, c
 /* With a workspace (vgpa_attn128_fwd_workspace_bytes) and Skv >= 1024 the forward runs on the one-wave-per-SIMD / LDS-DMA structure
  * (row-bound softmax shift, flagged strips redone with a running max); workspace NULL: the compiler-scheduled kernel. */
 size_t vgpa_attn128_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq);
+/* o_res8 (optional; uint8 [B, H, Sq, 128] view with its own element strides, NULL = not written): eight further mantissa bits of every output value
+ * (VGPA_RES_8 of vgpa_attn_fwd_w1_res) for the backward's delta = rowsum(dO o O) -- pass the same tensor to vgpa_attn128_bwd. */
 int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
-                         const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
-                         void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+                         const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H,
+                         int64_t Sq, int64_t Skv, float scale, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* The head_dim-128 forward on OCP-e4m3 matrix operands (BASELINE configs[4] "fp8 MFMA path"): q (with scale * log2 e folded in), k and v are quantised
  * with one power-of-two scale per (batch, head) and tensor, v transposed, by two prep kernels; both products run as v_mfma_scale_f32_32x32x64_f8f6f4
  * with the scales -- and a per-tile, per-row power of two for the softmax weights -- on the instruction's E8M0 operands; row sums and lse2 stay fp32.
@@ -243,16 +251,16 @@ int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, f
  * Forward only: the backward (vgpa_attn128_bwd) runs on the bf16 operands with this call's lse2. */
 size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int64_t Sq, int64_t Skv);
 int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
-                            const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
-                            void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+                            const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H,
+                            int64_t Sq, int64_t Skv, float scale, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* workspace (vgpa_attn128_bwd_workspace_bytes): delta + the statistics planes.  dkv_mode -1 = automatic (w1 dK/dV kernel from 1024 queries on),
  * 0 = compiler-scheduled kernel, 1 = w1 kernel */
 size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq);
 int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
                          void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                          const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
-                         const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, int32_t dkv_mode, void* workspace,
-                         size_t ws_bytes, vgpa_stream_t stream);
+                         const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
+                         float scale, int32_t dkv_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 
 /* ---- row kernels of the Wan2.2 denoiser block (WanAttentionBlock / WanRMSNorm / rope_apply of the Wan2.2 checkout imported at
  * train/Wan2.2-TI2V-5B/03_train.py:43-48).  fp32 residual stream, bf16 matmul operands.  Per-token modulation as a table: row

@@ -24,9 +24,10 @@ Tolerances (the HIP path computes in bf16, the oracle in fp32 on the same bf16-r
   the identity delta = rowsum(P o dP) holds for the unrounded O = P V only; each row's dS then stops summing to zero and dQ_i picks up
   -d(delta_i) sum_j P_ij K_j, a coherent term.  The rounded oracle reproduces the HIP gradients to 4-9 % once it does the same
   (test_cfg1_plain_delta_path_matches_the_oracle_that_rounds_the_output_in_delta), and is within 3-4 % of fp32 when delta comes from the
-  unrounded output.  The HIP path therefore now stores the output's rounding residual next to it (ops.PRECISE_DELTA, csrc/attention_w1.hip
-  w1_residual4; + S D 2 bytes per layer) and forms delta from O + O_res: reference (a) is the oracle with exact_delta=True, and the fp32 errors of that
-  family drop from 0.37-0.87 to the level of every other tensor.
+  unrounded output.  The HIP path therefore stores what the output's bf16 rounding dropped next to it (ops.py "Precise delta": eight further mantissa
+  bits per element since round 5, csrc/common.h res8, + S D bytes per layer, kept under lean activations too; round 4's bf16 residual tensor stays
+  selectable) and forms delta from the completed output: reference (a) is the oracle with exact_delta=True, and the fp32 errors of that family drop from
+  0.37-0.87 to the level of every other tensor.  test_cfg1_pair_step_matches_oracle_golden runs all three modes (MODES) against the same bounds.
   attention backward, kernel level (test_cfg1_attention_backward_matches_rounding_injected_recompute): every attention-backward
                         launch of the step is recorded and dQ / dK / dV of six (batch, head) slices each are recomputed in fp32 from
                         the SAME inputs with only the two roundings every bf16 flash attention makes (P -> bf16 for dV, dS -> bf16 for
@@ -57,7 +58,18 @@ REL_FIXED, FLOOR_FACTOR, ABS_CAP = 0.08, 1.25, 0.12    # against fp32: never fur
 ROUNDED_REL, ROUNDED_COS = 0.10, 0.995          # against the activation-rounded oracle
 
 
+_ORACLE_CACHE = {}
+
+
 def _oracle_on_gpu(variant, dtype, round_p_ds=False, **kw):
+    """cached per (variant, mode): the parametrised tests below share the four oracle runs of a variant (results live on the CPU)"""
+    key = (variant, dtype, round_p_ds, tuple(sorted(kw.items())))
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = _oracle_on_gpu_uncached(variant, dtype, round_p_ds, **kw)
+    return _ORACLE_CACHE[key]
+
+
+def _oracle_on_gpu_uncached(variant, dtype, round_p_ds=False, **kw):
     """The oracle's own code on the GPU: fp32 (the reference for whole gradient tensors), fp32 with the P / dS roundings injected, fp32 with EVERY
     bf16-stored tensor rounded (round_activations=True; exact_delta=True forms the attention backward's delta from the unrounded output), or
     bf16 weights / activations (plain torch bf16: the floor)  -> (loss, {name: grad fp32 on the CPU})."""
@@ -77,8 +89,7 @@ def _oracle_on_gpu(variant, dtype, round_p_ds=False, **kw):
     return loss, grads
 
 
-def _hip_step(variant, precise_delta=True):
-    from videogpa_amd import ops as _ops
+def _hip_step(variant, precise_delta="int8", lean=False):
     from videogpa_amd.lora import LoraConfig, get_peft_model
     from videogpa_amd.trainer import CogVideoXDPOTrainer
     from videogpa_amd.transformer import COGVIDEOX_5B, CogVideoXTransformer3DModel
@@ -88,12 +99,14 @@ def _hip_step(variant, precise_delta=True):
     model.load_state_dict(sd, strict=True)
     del sd
     model = model.to(device="cuda", dtype=torch.bfloat16)
+    model.set_precise_delta(precise_delta)         # per-model setting (ops.py "Precise delta"): "int8" (the default), "bf16" or None
+    model.enable_lean_activations(lean)
     lora, r = c1.lora_state_dict(cfg, variant)
     pm = get_peft_model(model, LoraConfig(r=r, lora_alpha=2 * r, target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
     own = pm.state_dict()
     for k, v in lora.items():
         own[k[:-len(".weight")] + ".default.weight"].copy_(v)
-    tr = CogVideoXDPOTrainer({"beta": 1.0}, transformer=pm)
+    tr = CogVideoXDPOTrainer({"beta": 1.0, "lean_activations": bool(lean)}, transformer=pm)
     tr.train()
     x_win, x_lose, prompt, t, noise = c1.inputs()
     captured = {}
@@ -104,16 +117,10 @@ def _hip_step(variant, precise_delta=True):
         captured.setdefault("preds", []).append(out.sample.detach())
         return out
     tr.transformer.forward = spy
-    keep = _ops.PRECISE_DELTA
-    _ops.PRECISE_DELTA = bool(precise_delta)
-    try:
-        out = tr._shared_step({"x_win": x_win.cuda(), "x_lose": x_lose.cuda(), "prompt_emb": prompt.cuda()},
-                              timesteps=t.cuda(), noise=noise.cuda())
-        tr.transformer.forward = orig
-        out.loss.backward()
-        torch.cuda.synchronize()
-    finally:
-        _ops.PRECISE_DELTA = keep
+    out = tr._shared_step({"x_win": x_win.cuda(), "x_lose": x_lose.cuda(), "prompt_emb": prompt.cuda()}, timesteps=t.cuda(), noise=noise.cuda())
+    tr.transformer.forward = orig
+    out.loss.backward()
+    torch.cuda.synchronize()
     v_ref, v_pol = captured["preds"]            # reference pass first (adapter off), then the policy pass; batch = (win, lose)
     grads = {}
     named = dict(pm.named_parameters())
@@ -122,11 +129,18 @@ def _hip_step(variant, precise_delta=True):
     return out, {"v_win": v_pol[0:1], "v_lose": v_pol[1:2], "v_win_ref": v_ref[0:1], "v_lose_ref": v_ref[1:2]}, grads
 
 
+# (precise_delta, lean_activations): the default; the default under lean activations (cfg4's memory policy, and cfg3 at the reference's batch 2); the round-4
+# bf16 residual.  All three must meet the SAME bounds -- gradient accuracy does not depend on a memory switch (VERDICT r4 weak 1 / ADVICE r4).
+MODES = {"int8": ("int8", False), "int8_lean": ("int8", True), "bf16res": ("bf16", False)}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("variant", ["r8", "r64"])
-def test_cfg1_pair_step_matches_oracle_golden(variant):
+def test_cfg1_pair_step_matches_oracle_golden(variant, mode):
     gold = torch.load(os.path.join(HERE, "golden", f"cfg1_{variant}.pt"), weights_only=False)
-    out, preds, grads = _hip_step(variant)
-    report = {"variant": variant, "loss_hip": out.loss.item(), "loss_oracle": float(gold["loss"])}
+    out, preds, grads = _hip_step(variant, *MODES[mode])
+    report = {"variant": variant, "mode": mode, "precise_delta": MODES[mode][0], "lean_activations": MODES[mode][1],
+              "loss_hip": out.loss.item(), "loss_oracle": float(gold["loss"])}
     fails = []      # every comparison is made and written to gpurun_out/ before the first assert fires
 
     def check(ok, what):
@@ -196,7 +210,7 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
     report["lora_grads_per_tensor"] = per_tensor
     report["failed_checks"] = [str(f) for f in fails]
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"cfg1_parity_{variant}.json"), "w") as f:
+    with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"cfg1_parity_{variant}" + ("" if mode == "int8" else "_" + mode) + ".json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
     assert not fails, fails
@@ -204,12 +218,12 @@ def test_cfg1_pair_step_matches_oracle_golden(variant):
 
 @pytest.mark.parametrize("variant", ["r8", "r64"])
 def test_cfg1_plain_delta_path_matches_the_oracle_that_rounds_the_output_in_delta(variant):
-    """ops.PRECISE_DELTA off = the textbook flash-attention backward (delta from the stored bf16 output; what torch's bf16 kernels do): the HIP gradients
+    """precise_delta None = the textbook flash-attention backward (delta from the stored bf16 output; what torch's bf16 kernels do): the HIP gradients
     must then follow the activation-rounded oracle that ALSO forms delta from the rounded output -- every tensor within 12 % / cosine 0.993 (measured
     1.3-9.2 %, cosine >= 0.9958; the last block's to_q / to_k are 35-83 % away from fp32 in BOTH, which is the point: the mechanism is modelled, not
     tolerated) -- and the default path must be at least 3x closer to fp32 than this one on the tensors it was introduced for."""
-    _, _, g_plain = _hip_step(variant, precise_delta=False)
-    _, _, g_prec = _hip_step(variant, precise_delta=True)
+    _, _, g_plain = _hip_step(variant, precise_delta=None)
+    _, _, g_prec = _hip_step(variant, precise_delta="int8")
     _, ro = _oracle_on_gpu(variant, torch.float32, round_activations=True, exact_delta=False)
     _, ref = _oracle_on_gpu(variant, torch.float32)
 
@@ -239,7 +253,8 @@ def test_cfg1_attention_backward_matches_rounding_injected_recompute():
 
     def spy(q, k, v, o, do, lse, dq, dk, dv, **kw):
         orig(q, k, v, o, do, lse, dq, dk, dv, **kw)
-        o_full = o.float() if kw.get("o_res") is None else o.float() + kw["o_res"].float()     # what the kernels' delta is formed from (ops.PRECISE_DELTA)
+        r = kw.get("o_res")      # what the kernels' delta is formed from: the output completed by the forward's residual tensor (ops.py "Precise delta")
+        o_full = o.float() if r is None else (o.float() + r.float() if r.dtype == torch.bfloat16 else ops.res8_decode(o, r))
         rec.append(tuple(t.clone() for t in (q, k, v, o_full, do, dq, dk, dv)))
     ops.attention_bwd_raw = spy
     try:

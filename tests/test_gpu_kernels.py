@@ -597,14 +597,17 @@ def test_lora_ext_refresh_kernel_is_bit_exact_with_pefts_rounding(ops, r, n_slic
         assert torch.equal(got, want), name + " after update"
 
 
+@pytest.mark.parametrize("kind", ["bf16", "int8"])
 @pytest.mark.parametrize("S,split", [(1000, 0), (1000, 4), (100, 0), (2100, 3)])
-def test_attention_output_residual_and_precise_delta(ops, S, split):
-    """vgpa_attn_fwd_w1_res / vgpa_attn_bwd_prep_w1_res / vgpa_attn_bwd_delta_res ("precise delta", ops.PRECISE_DELTA): the forward also stores the
-    rounding residual o_res = O_fp32 - bf16(O) and the backward forms delta = rowsum(dO o (O + O_res)).  Diffuse attention over values with a large
-    mean (|O| ~ 2, so bf16(O) is off by up to 4e-3 while the kernel's fp32 O is good to ~2e-4): (i) o + o_res is >= 4x closer to the fp64 output than
-    o alone, through the main launch, the key-range split + merge (split > 0) and the online-softmax path (S < 128); (ii) both delta kernels reproduce
-    rowsum(dO o (O + O_res)) of the stored tensors to fp32 rounding; (iii) dQ -- whose rows pick up -d(delta) * sum_j P_ij K_j when delta comes from
-    the rounded O -- is >= 3x closer to the fp64 gradient with the residual than without (k carries a mean, so that sum is not small)."""
+def test_attention_output_residual_and_precise_delta(ops, S, split, kind):
+    """vgpa_attn_fwd_w1_res / vgpa_attn_bwd_prep_w1_res / vgpa_attn_bwd_delta_res ("precise delta" in ops.py): the forward also stores what the bf16
+    rounding of its output dropped -- as a bf16 residual o_res = O_fp32 - bf16(O) (VGPA_RES_BF16) or as eight further mantissa bits per element
+    (VGPA_RES_8, csrc/common.h res8; decoded here by ops.res8_decode) -- and the backward forms delta = rowsum(dO o O) from the completed output.
+    Diffuse attention over values with a large mean (|O| ~ 2, so bf16(O) is off by up to 4e-3 while the kernel's fp32 O is good to ~2e-4): (i) the
+    completed output is >= 4x closer to the fp64 output than o alone, through the main launch, the key-range split + merge (split > 0) and the
+    online-softmax path (S < 128); (ii) both delta kernels reproduce rowsum(dO o O_completed) of the stored tensors to fp32 rounding; (iii) dQ -- whose
+    rows pick up -d(delta) * sum_j P_ij K_j when delta comes from the rounded O -- is >= 3x closer to the fp64 gradient with the residual than
+    without (k carries a mean, so that sum is not small)."""
     from videogpa_amd import _lib
     g = torch.Generator().manual_seed(7 * S + split)
     B, H = 1, 2
@@ -613,26 +616,33 @@ def test_attention_output_residual_and_precise_delta(ops, S, split):
     v = (torch.randn(B, H, S, 64, generator=g) + 2.0).to(torch.bfloat16)
     do = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
     qd, kd, vd, dod = dev(q), dev(k), dev(v), dev(do)
-    o_res = torch.full((B, S, H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    if kind == "bf16":
+        o_res = torch.full((B, S, H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    else:
+        o_res = torch.full((B, S, H * 64), 7, dtype=torch.uint8, device="cuda")           # 7 = a residual of -121/256 ulp: never what a written byte looks like on average
+    rk = ops._res_kind(o_res)
     o, lse = ops.attention_fwd_raw(qd, kd, vd, split_mode=split, o_res=o_res)
     o_ref, dq_ref, dk_ref, dv_ref = _attn_ref(q, k, v, do)
     bhsd = lambda t: t.view(B, S, H, 64).permute(0, 2, 1, 3)
-    assert torch.isfinite(o_res.float()).all()
+    o_full = (o.double() + o_res.double()) if kind == "bf16" else ops.res8_decode(o, o_res).double()      # fp32 holds bf16 + 8 bits exactly
+    res = o_full - o.double()
+    assert torch.isfinite(o_full).all()
     e_plain = (bhsd(o).double().cpu() - o_ref).abs().max().item()
-    e_res = ((bhsd(o).double() + bhsd(o_res).double()).cpu() - o_ref).abs().max().item()
+    e_res = (bhsd(o_full).cpu() - o_ref).abs().max().item()
     assert e_plain > 2e-3 and e_res < 0.25 * e_plain, (e_plain, e_res)
-    assert (bhsd(o_res).float().abs() <= 2.0 ** -8 * bhsd(o).float().abs() + 1e-30).all()          # a residual never exceeds half an ulp of o
+    assert (res.abs() <= 2.0 ** -8 * o.double().abs() + 1e-30).all()          # a residual never exceeds half an ulp of o
+    assert res.abs().mean().item() > 2.0 ** -12 * o.double().abs().mean().item()         # and it was written (the fill pattern is gone)
     # (ii) the two delta kernels
-    want = (dod.double() * (bhsd(o).double() + bhsd(o_res).double())).sum(-1)
+    want = (dod.double() * bhsd(o_full)).sum(-1)
     st = lambda t: ops._bhs_strides(t)
     for name in ("prep", "delta"):
         delta = torch.empty(B, H, S, dtype=torch.float32, device="cuda")
         if name == "prep":
             stats = torch.empty(B, H, 2, S, dtype=torch.float32, device="cuda")
-            _lib.call("vgpa_attn_bwd_prep_w1_res", bhsd(o), bhsd(o_res), dod, lse, st(bhsd(o)), st(bhsd(o_res)), st(dod), delta, stats, B, H, S, 64, ops._stream())
+            _lib.call("vgpa_attn_bwd_prep_w1_res", bhsd(o), bhsd(o_res), rk, dod, lse, st(bhsd(o)), st(bhsd(o_res)), st(dod), delta, stats, B, H, S, 64, ops._stream())
             assert torch.equal(stats[:, :, 1], -delta) and torch.equal(stats[:, :, 0], -lse)
         else:
-            _lib.call("vgpa_attn_bwd_delta_res", bhsd(o), bhsd(o_res), dod, st(bhsd(o)), st(bhsd(o_res)), st(dod), delta, B, H, S, 64, ops._stream())
+            _lib.call("vgpa_attn_bwd_delta_res", bhsd(o), bhsd(o_res), rk, dod, st(bhsd(o)), st(bhsd(o_res)), st(dod), delta, B, H, S, 64, ops._stream())
         assert (delta.double() - want).abs().max().item() < 1e-4 * want.abs().max().item() + 1e-5, name
     # (iii) dQ with and without the residual
     errs = {}

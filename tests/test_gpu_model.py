@@ -396,13 +396,10 @@ def test_gradient_checkpointing_gives_same_grads():
 @pytest.mark.parametrize("rope", [True, False])
 def test_lean_activations_give_bit_identical_outputs_and_grads(rope):
     """enable_lean_activations(): the LN output feeding q/k/v and the normalised q / k are made again in the backward instead of being kept;
-    same kernels on the same bf16 inputs -> bit-identical sample and adapter gradients, with and without per-block recompute on top.
-    (Lean activations run the attention backward with delta from the stored bf16 output -- the output's rounding residual of ops.PRECISE_DELTA is one
-    of the tensors a lean block does not keep -- so the full-activation run it is compared with is made with that switch off too.)"""
-    from videogpa_amd import ops as vops
-    monkey = pytest.MonkeyPatch()
-    monkey.setattr(vops, "PRECISE_DELTA", False)
+    same kernels on the same bf16 inputs -> bit-identical sample and adapter gradients, with and without per-block recompute on top -- at the DEFAULT
+    settings: the output's res8 bytes for the backward's delta ("precise delta") are kept by lean blocks too, so both runs form the same delta."""
     cfg, sd64, lora64, pm = _setup(b_std=0.05, rope=rope)
+    assert all(b.attn1.core.precise_delta == "int8" for b in pm.get_base_model().transformer_blocks)
     x, txt, t = _inputs(cfg, B=2, seed=13)
     g = torch.Generator().manual_seed(6)
     dy = torch.randn(x.shape, generator=g).to(torch.bfloat16).cuda()
@@ -417,7 +414,6 @@ def test_lean_activations_give_bit_identical_outputs_and_grads(rope):
         y = pm(x.cuda(), encoder_hidden_states=txt.cuda(), timestep=t.cuda()).sample
         y.backward(dy)
         runs.append((y.detach().clone(), {n: p.grad.clone() for n, p in pm.named_parameters() if p.grad is not None}))
-    monkey.undo()
     assert len(runs[0][1]) == 2 * 4 * cfg.num_layers
     for y, gr in runs[1:]:
         assert torch.equal(y, runs[0][0])

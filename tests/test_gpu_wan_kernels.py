@@ -75,6 +75,54 @@ def test_attention128_w1_forward_long_keys_vs_fp64(B, H, Sq, Skv):
     assert (o.float() - o2.float()).abs().max().item() <= 2 ** -7 * ro.abs().max().item()
 
 
+@pytest.mark.parametrize("Sq,Skv,f8", [(300, 512, False), (1100, 1500, False), (1100, 1500, True), (130, 77, False)])
+def test_attention128_output_res8_and_precise_delta(Sq, Skv, f8):
+    """"Precise delta" at head_dim 128: every forward kernel of csrc/attention_hd128.hip -- the compiler-scheduled one (short key
+    sweeps: the cross-attention), the w1 kernel and the e4m3 kernel -- also writes eight further mantissa bits of its output (uint8 o_res8, csrc/common.h
+    res8), and vgpa_attn128_bwd forms delta = rowsum(dO o O) from the completed output.  Diffuse attention over values with a large mean (|O| ~ 2):
+    (i) bf16 kernels: the completed output is >= 4x closer to the fp64 output than the bf16 one; every kernel: the residual never exceeds half an ulp and
+    was written; (ii) the delta the backward forms (read from its workspace) = rowsum(dO o O_completed) to fp32 rounding, and differs from the plain one;
+    (iii) bf16 kernels: dQ is >= 3x closer to the fp64 gradient with the bytes than without (k carries a mean, so sum_j P_ij K_j is not small)."""
+    from videogpa_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(Sq * 3 + Skv + int(f8))
+    B, H = 1, 2
+    tm = lambda t: t.bfloat16().permute(0, 2, 1, 3)                       # token-major storage, [B, H, S, 128] view -- the model's layout
+    q = tm(0.3 * torch.randn(B, Sq, H, 128, device="cuda", generator=g))
+    k = tm(torch.randn(B, Skv, H, 128, device="cuda", generator=g) + 1.0)
+    v = tm(torch.randn(B, Skv, H, 128, device="cuda", generator=g) + 2.0)
+    do = tm(torch.randn(B, Sq, H, 128, device="cuda", generator=g))
+    scale = 128 ** -0.5
+    o_res8 = torch.full((B, Sq, H * 128), 7, dtype=torch.uint8, device="cuda")
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=f8, o_res8=o_res8)
+    rv = o_res8.unflatten(-1, (H, 128)).permute(0, 2, 1, 3)
+    o_full = ops.res8_decode(o, rv).double()
+    res = o_full - o.double()
+    assert (res.abs() <= 2.0 ** -8 * o.double().abs() + 1e-30).all()
+    assert res.abs().mean().item() > 2.0 ** -12 * o.double().abs().mean().item()
+    ro, rq, rk, rvg = _ref(q, k, v, do, scale)
+    if not f8:
+        e_plain, e_res = (o.double() - ro).abs().max().item(), (o_full - ro).abs().max().item()
+        assert e_plain > 2e-3 and e_res < 0.25 * e_plain, (e_plain, e_res)
+    errs = {}
+    for tag, r8 in (("plain", None), ("res8", o_res8)):
+        dq, dk, dv = (torch.empty(B, S_, H, 128, dtype=torch.bfloat16, device="cuda").permute(0, 2, 1, 3) for S_ in (Sq, Skv, Skv))
+        ws_bytes = _lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, Sq)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        st = ops._bhs_strides
+        _lib.call("vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv),
+                  None if r8 is None else rv, None if r8 is None else st(rv), B, H, Sq, Skv, float(scale), -1, ws, ws_bytes, ops._stream())
+        delta = ws[: B * H * Sq * 4].view(torch.float32).view(B, H, Sq).double()
+        want = (do.double() * (o.double() if r8 is None else o_full)).sum(-1)
+        assert (delta - want).abs().max().item() < 1e-4 * want.abs().max().item() + 1e-5, tag
+        errs[tag] = float((dq.double() - rq).norm() / rq.norm())
+        if not f8:
+            _close(dk, rk, tag + " dk", tol=0.03)
+            _close(dv, rvg, tag + " dv", tol=0.03)
+    if not f8:
+        assert errs["res8"] < 0.05 and errs["res8"] < errs["plain"] / 3, errs
+    print({"Sq": Sq, "Skv": Skv, "f8": f8, "dq_rel_err_plain_then_res8": errs})
+
+
 def _ref_e4m3(q, k, v, scale):
     """fp64 attention on the operands the e4m3 forward really multiplies: q * scale * log2(e), k and v rounded to e4m3 after a power-of-two scale per
     (batch, head) and tensor (csrc/attention_hd128.hip attn128_f8_quant_kernel); P is left unquantised (its e4m3 rounding is the remaining difference)"""

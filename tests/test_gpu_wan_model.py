@@ -193,9 +193,9 @@ def test_wan_model_e4m3_self_attention_stays_close_to_the_oracle():
     seen = []
     orig = ops.attention128_fwd_raw
 
-    def spy(q, k, v, scale, o_pad=0, f8=False):
+    def spy(q, k, v, scale, o_pad=0, f8=False, **kw):
         seen.append((k.shape[2], f8))
-        return orig(q, k, v, scale, o_pad, f8=f8)
+        return orig(q, k, v, scale, o_pad, f8=f8, **kw)
     ops.attention128_fwd_raw = spy
     try:
         out = pm(x, t=t, context=ctx, seq_len=L)

@@ -23,18 +23,18 @@ scale = D ** -0.5
 
 
 def fwd(w1):
-    _lib.call("vgpa_attn128_fwd", q, k, v, o, lse, st(q), st(k), st(v), st(o), B, H, S, S, scale, wsf if w1 else None, wsf.numel() if w1 else 0, stream)
+    _lib.call("vgpa_attn128_fwd", q, k, v, o, lse, st(q), st(k), st(v), st(o), None, None, B, H, S, S, scale, wsf if w1 else None, wsf.numel() if w1 else 0, stream)
 
 
 wsf8 = torch.empty(_lib.query("vgpa_attn128_fwd_f8_workspace_bytes", B, H, S, S), dtype=torch.uint8, device="cuda")
 
 
 def fwd_f8():
-    _lib.call("vgpa_attn128_fwd_f8", q, k, v, o, lse, st(q), st(k), st(v), st(o), B, H, S, S, scale, wsf8, wsf8.numel(), stream)
+    _lib.call("vgpa_attn128_fwd_f8", q, k, v, o, lse, st(q), st(k), st(v), st(o), None, None, B, H, S, S, scale, wsf8, wsf8.numel(), stream)
 
 
 def bwd(mode):
-    _lib.call("vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv), B, H, S, S, scale, mode, wsb, wsb.numel(), stream)
+    _lib.call("vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv), None, None, B, H, S, S, scale, mode, wsb, wsb.numel(), stream)
 
 
 def timeit(fn, n=a_.iters):

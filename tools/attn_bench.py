@@ -69,7 +69,7 @@ if a.energy > 0:
     stats = torch.empty(B, H, 2, S, dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     sb = ops._bhs_strides
-    _lib.call("vgpa_attn_bwd_prep_w1_res", ov, None, dov, lse, sb(ov), None, sb(dov), delta, stats, B, H, S, 64, st)
+    _lib.call("vgpa_attn_bwd_prep_w1_res", ov, None, 0, dov, lse, sb(ov), None, sb(dov), delta, stats, B, H, S, 64, st)
     ws_bytes = _lib.query("vgpa_attn_bwd_split_workspace_bytes", B, H, S) if a.split != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
     wsp = ws if ws_bytes else None

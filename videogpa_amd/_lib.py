@@ -41,15 +41,15 @@ SIGNATURES = {
     "vgpa_grad_norm": (I32, [P, I64, F32, P, P, SZ, P]),
     "vgpa_adamw_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P, P]),
     "vgpa_attn_bwd_delta": (I32, [P, P, P, P, P, I64, I64, I64, I64, P]),
-    "vgpa_attn_bwd_delta_res": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
+    "vgpa_attn_bwd_delta_res": (I32, [P, P, I32, P, P, P, P, P, I64, I64, I64, I64, P]),
     "vgpa_attn_bwd_dkv": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd_dq": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vgpa_attn_bwd_dq_w1": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_fwd_w1_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn_fwd_w1": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_prep_w1": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
-    "vgpa_attn_bwd_prep_w1_res": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
-    "vgpa_attn_fwd_w1_res": (I32, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
+    "vgpa_attn_bwd_prep_w1_res": (I32, [P, P, I32, P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
+    "vgpa_attn_fwd_w1_res": (I32, [P, P, P, P, P, I32, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_dkv_w1": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_split_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn_bwd_dkv_ws": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
@@ -62,11 +62,11 @@ SIGNATURES = {
     "vgpa_lora_grad_ws": (I32, [P, I64, P, I64, P, I64, F32, I64, I64, I64, P, SZ, P]),
     "vgpa_lora_ext_refresh": (I32, [P, P, F32, I64, I64, I64, P, P, I64, P, I64, P, P]),
     "vgpa_attn128_fwd_workspace_bytes": (SZ, [I64, I64, I64]),
-    "vgpa_attn128_fwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
+    "vgpa_attn128_fwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
     "vgpa_attn128_fwd_f8_workspace_bytes": (SZ, [I64, I64, I64, I64]),
-    "vgpa_attn128_fwd_f8": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
+    "vgpa_attn128_fwd_f8": (I32, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P, SZ, P]),
     "vgpa_attn128_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
-    "vgpa_attn128_bwd": (I32, [P] * 17 + [I64, I64, I64, I64, F32, I32, P, SZ, P]),
+    "vgpa_attn128_bwd": (I32, [P] * 19 + [I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_wan_ln_mod_fwd": (I32, [P, I32, P, P, P, P, P, I64, I64, I64, F32, I32, P, I64, P, P, P, P, P]),
     "vgpa_wan_ln_mod_bwd": (I32, [P, P, I32, P, P, P, P, P, I64, I64, I64, P, P, P]),
     "vgpa_wan_ln_mod_fwd_f32": (I32, [P, P, P, P, I64, I64, I64, F32, P, P, P, P]),

@@ -420,8 +420,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : FWD_WPS) void attn_fwd_pip
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
                                                                  int S, int H, int n_qt, int task0, int nsplit, float* __restrict__ part,
-                                                                 const int* __restrict__ only_flagged = nullptr, bf16_t* __restrict__ ORES = nullptr,
-                                                                 TStride sor = TStride{0, 0, 0}) {
+                                                                 const int* __restrict__ only_flagged = nullptr, void* __restrict__ ORES = nullptr,
+                                                                 TStride sor = TStride{0, 0, 0}, int res_kind = VGPA_RES_NONE) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[5 * TILE_ELEMS];  // K ring [3], V ring [2]
     __shared__ int redo_flag;
     const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : FWD_WPS) void attn_fwd_pip
         const int q = q0 + 32 * j + (lane & 31);
         if (q < S) {
             bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
-            bf16_t* rp = ORES ? ORES + ((size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s) : nullptr;   // rounding residual (attention_w1.hip)
+            const size_t ro = (size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s;   // the output's residual for the backward's delta (attention_w1.hip)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -582,11 +582,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : FWD_WPS) void attn_fwd_pip
                     w[0] = pack_bf16x2(x[0], x[1]);
                     w[1] = pack_bf16x2(x[2], x[3]);
                     *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
-                    if (rp) {
+                    if (res_kind == VGPA_RES_8) {
+                        *reinterpret_cast<uint32_t*>((uint8_t*)ORES + ro + db * 32 + 8 * g + 4 * hi) = res8_pack4(x, w);
+                    } else if (res_kind == VGPA_RES_BF16) {
                         u32x2_t r;
                         r[0] = pack_bf16x2(x[0] - __uint_as_float(w[0] << 16), x[1] - __uint_as_float(w[0] & 0xffff0000u));
                         r[1] = pack_bf16x2(x[2] - __uint_as_float(w[1] << 16), x[3] - __uint_as_float(w[1] & 0xffff0000u));
-                        *reinterpret_cast<u32x2_t*>(rp + db * 32 + 8 * g + 4 * hi) = r;
+                        *reinterpret_cast<u32x2_t*>((bf16_t*)ORES + ro + db * 32 + 8 * g + 4 * hi) = r;
                     }
                 }
             if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
@@ -958,7 +960,8 @@ __global__ __launch_bounds__(64 * PP_NW, 2) void attn_fwd_pp_kernel(const bf16_t
 // =====================================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, TStride sdo,
                                                            TStride so, int S, int H, int64_t total /* B*H*S */, float* __restrict__ delta,
-                                                           const bf16_t* __restrict__ ORES = nullptr, TStride sor = TStride{0, 0, 0}) {
+                                                           const void* __restrict__ ORES = nullptr, TStride sor = TStride{0, 0, 0},
+                                                           int res_kind = VGPA_RES_NONE) {
     // 8 lanes per (b,h,q) row, 16 B each
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = gid >> 3;
@@ -970,12 +973,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
         const int h = (int)(bh % H), b = (int)(bh / H);
         float a[8], o[8];
         unpack8(*reinterpret_cast<const u32x4_t*>(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h + (size_t)q * sdo.s + c8 * 8)), a);
-        unpack8(*reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c8 * 8)), o);
-        if (ORES) {   // the forward's rounding residual (attention_w1.hip, w1_residual4)
-            float r[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(ORES + ((size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + c8 * 8)), r);
+        const u32x4_t ob = *reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c8 * 8));
+        const size_t ro = (size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + c8 * 8;
+        if (res_kind == VGPA_RES_8) {   // the forward's 8 further mantissa bits (common.h res8)
+            unpack8_res8(ob, *reinterpret_cast<const u32x2_t*>((const uint8_t*)ORES + ro), o);
+        } else {
+            unpack8(ob, o);
+            if (res_kind == VGPA_RES_BF16) {   // the forward's rounding residual (attention_w1.hip, w1_residual4)
+                float r[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>((const bf16_t*)ORES + ro), r);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += r[j];
+                for (int j = 0; j < 8; ++j) o[j] += r[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
@@ -1591,9 +1600,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
 
 // Redo pass behind the w1 forward (attention_w1.hip): the online-softmax kernel over every 256-row strip whose flag is set.
 int32_t vgpa_internal_attn_fwd_redo(const void* q, const void* k, const void* v, void* o, float* lse2, TStride sq, TStride sk, TStride sv, TStride so,
-                                    int S, int H, int n_qt, int64_t tasks, const int* flags, hipStream_t stream, bf16_t* o_res, TStride sor) {
+                                    int S, int H, int n_qt, int64_t tasks, const int* flags, hipStream_t stream, void* o_res, TStride sor, int res_kind) {
     VGPA_LAUNCH((attn_fwd_pipe_kernel<2, 4, false>), dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                (bf16_t*)o, lse2, sq, sk, sv, so, S, H, n_qt, 0, 1, (float*)nullptr, flags, o_res, sor);
+                (bf16_t*)o, lse2, sq, sk, sv, so, S, H, n_qt, 0, 1, (float*)nullptr, flags, o_res, sor, o_res ? res_kind : VGPA_RES_NONE);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -1699,21 +1708,23 @@ static inline bool bwd_common_ok(int64_t B, int64_t H, int64_t S, int64_t head_d
     return head_dim == HD && B > 0 && H > 0 && S > 0 && S <= (1 << 24) && (int64_t)((S + WG_ROWS - 1) / WG_ROWS) * B * H <= 0x7fffffff;
 }
 
-// step 1 of the backward: delta[b,h,q] = sum_d dO * O  (_res: * (O + O_res), O_res = the forward's rounding residual, vgpa_attn_fwd_w1_res; may be NULL)
-int32_t vgpa_attn_bwd_delta_res(const void* o, const void* o_res, const void* d_o, const int64_t* o_strides, const int64_t* ores_strides,
+// step 1 of the backward: delta[b,h,q] = sum_d dO * O  (_res: of the output as the forward's residual tensor completes it -- vgpa_attn_fwd_w1_res,
+// res_kind VGPA_RES_BF16 / VGPA_RES_8; o_res may be NULL)
+int32_t vgpa_attn_bwd_delta_res(const void* o, const void* o_res, int32_t res_kind, const void* d_o, const int64_t* o_strides, const int64_t* ores_strides,
                                 const int64_t* do_strides, float* delta, int64_t B, int64_t H, int64_t S, int64_t head_dim, hipStream_t stream) {
     if (!o || !d_o || !delta || !bwd_common_ok(B, H, S, head_dim) || !SOK(o_strides) || !SOK(do_strides) || !al16(o) || !al16(d_o))
         return VGPA_ERR_INVALID;
-    if (o_res && (!SOK(ores_strides) || !al16(o_res))) return VGPA_ERR_INVALID;
+    if (o_res && (!SOK(ores_strides) || !al16(o_res) || (res_kind != VGPA_RES_BF16 && res_kind != VGPA_RES_8))) return VGPA_ERR_INVALID;
     const int64_t total = B * H * S;
     VGPA_LAUNCH(attn_delta_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o,
-                       mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta, (const bf16_t*)o_res, o_res ? mk(ores_strides) : mk(o_strides));
+                       mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta, o_res, o_res ? mk(ores_strides) : mk(o_strides),
+                       o_res ? (int)res_kind : VGPA_RES_NONE);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
 int32_t vgpa_attn_bwd_delta(const void* o, const void* d_o, const int64_t* o_strides, const int64_t* do_strides, float* delta, int64_t B,
                             int64_t H, int64_t S, int64_t head_dim, hipStream_t stream) {
-    return vgpa_attn_bwd_delta_res(o, nullptr, d_o, o_strides, nullptr, do_strides, delta, B, H, S, head_dim, stream);
+    return vgpa_attn_bwd_delta_res(o, nullptr, VGPA_RES_NONE, d_o, o_strides, nullptr, do_strides, delta, B, H, S, head_dim, stream);
 }
 
 // step 2: dK, dV (workgroup per 128 keys).  With a workspace the leftover tasks of a mostly empty last scheduling round are

@@ -77,11 +77,30 @@ __device__ __forceinline__ void store_col128(bf16_t* row_ptr, const f32x16_t (&a
             *reinterpret_cast<u32x2_t*>(row_ptr + db * 32 + 8 * g + 4 * hi) = w;
         }
 }
+// the same, and (res_row != NULL) the eight further mantissa bits of every stored value (common.h res8) for the backward's delta
+__device__ __forceinline__ void store_col128_res8(bf16_t* row_ptr, uint8_t* res_row, const f32x16_t (&a)[4], float scale, int hi) {
+    if (!res_row) return store_col128(row_ptr, a, scale, hi);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = a[db][4 * g + i] * scale;
+            u32x2_t w;
+            w[0] = pack_bf16x2(x[0], x[1]);
+            w[1] = pack_bf16x2(x[2], x[3]);
+            *reinterpret_cast<u32x2_t*>(row_ptr + db * 32 + 8 * g + 4 * hi) = w;
+            *reinterpret_cast<uint32_t*>(res_row + db * 32 + 8 * g + 4 * hi) = res8_pack4(x, w);
+        }
+}
+#define RES_ROW(ORES, sor, b, h, q) ((ORES) ? (ORES) + ((size_t)(b) * (sor).b + (size_t)(h) * (sor).h + (size_t)(q) * (sor).s) : (uint8_t*)nullptr)
 
 // ===================================================================================================== forward
 __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                bf16_t* __restrict__ O, float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
-                                                               int Sq, int Skv, int H, int n_qt, float c, const int* __restrict__ only_flagged) {
+                                                               int Sq, int Skv, int H, int n_qt, float c, const int* __restrict__ only_flagged,
+                                                               uint8_t* __restrict__ ORES, TStride sor) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][T128];
     const int bh = blockIdx.x / n_qt, qt = blockIdx.x % n_qt;
     // redo pass of the w1 forward: flags are per 256-row strip (= two of this kernel's 128-row tasks)
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(const bf16_t* __res
     l += other_half(l);
     const int q = q0 + (lane & 31);
     if (q < Sq) {
-        store_col128(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), o, 1.f / l, hi);
+        store_col128_res8(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), RES_ROW(ORES, sor, b, h, q), o, 1.f / l, hi);
         if (hi == 0) LSE2[(size_t)bh * Sq + q] = m + __builtin_amdgcn_logf(l);   // v_log_f32 is log2
     }
 }
@@ -225,7 +244,7 @@ __device__ __forceinline__ u32x16_t pack4h(const bf16x8_t& a, const bf16x8_t& b,
 __global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                   bf16_t* __restrict__ O, float* __restrict__ LSE2, const unsigned* __restrict__ KMAX2,
                                                                   int* __restrict__ flags, TStride sq, TStride sk, TStride sv, TStride so, int Sq, int Skv,
-                                                                  int H, int n_qt, float c) {
+                                                                  int H, int n_qt, float c, uint8_t* __restrict__ ORES, TStride sor) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[W1H_RING_BYTES];   // slot = [K tile | V tile]
     const int vid = blockIdx.x;
     const int bh = vid / n_qt, qt = vid % n_qt;
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __
         const int q = q0 + 32 * j + (lane & 31);
         if (q < Sq) {
             bad = bad || !(l >= W1H_L_MIN && l < INFINITY) || !(M <= W1H_M_MAX);
-            store_col128(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), o[j], 1.f / l, hi);
+            store_col128_res8(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), RES_ROW(ORES, sor, b, h, q), o[j], 1.f / l, hi);
             if (hi == 0) LSE2[(size_t)bh * Sq + q] = M + __builtin_amdgcn_logf(l);
         }
     }
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __
 // takes as the srcC of its score chains
 __global__ __launch_bounds__(256) void attn128_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, TStride sdo, TStride so, int S, int H,
                                                               int64_t total, float* __restrict__ delta, const float* __restrict__ LSE2, float inv_c,
-                                                              float* __restrict__ stats) {
+                                                              float* __restrict__ stats, const uint8_t* __restrict__ ORES, TStride sor) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = gid >> 4;
     const int c16 = (int)(gid & 15);
@@ -363,7 +382,11 @@ __global__ __launch_bounds__(256) void attn128_delta_kernel(const bf16_t* __rest
         const int h = (int)(bh % H), b = (int)(bh / H);
         float a[8], o[8];
         unpack8(*reinterpret_cast<const u32x4_t*>(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h + (size_t)q * sdo.s + c16 * 8)), a);
-        unpack8(*reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c16 * 8)), o);
+        const u32x4_t ob = *reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c16 * 8));
+        if (ORES)     // the forward's 8 further mantissa bits: delta from the output to 2^-17 ("precise delta", csrc/attention_w1.hip w1_residual4 has the why)
+            unpack8_res8(ob, *reinterpret_cast<const u32x2_t*>(ORES + ((size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + c16 * 8)), o);
+        else
+            unpack8(ob, o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
     }
@@ -864,10 +887,18 @@ static int64_t attn128_min_sweep() {
     }();
     return v;
 }
+// o_res8 (optional: uint8 [B, H, Sq, 128] view with its own element strides; NULL = not written): eight further mantissa bits of every output value
+// (common.h res8) for the backward's delta -- "precise delta", see vgpa_attn_fwd_w1_res
+static inline bool res8_ok(const void* o_res8, const int64_t* st, int64_t B, int64_t H, int64_t S) {
+    return !o_res8 || (st && st[0] >= 0 && st[1] >= 0 && st[2] >= D128 && st[0] % 8 == 0 && st[1] % 8 == 0 && st[2] % 8 == 0 && ((uintptr_t)o_res8 & 7) == 0 &&
+                       (B - 1) * st[0] + (H - 1) * st[1] + (S - 1) * st[2] + D128 < ((int64_t)1 << 32));
+}
 extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
-                                    const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
-                                    void* workspace, size_t ws_bytes, hipStream_t stream) {
-    if (!q || !k || !v || !o || !lse2 || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
+                                    const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H,
+                                    int64_t Sq, int64_t Skv, float scale, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !o || !lse2 || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || !res8_ok(o_res8, ores_strides, B, H, Sq)) return VGPA_ERR_INVALID;
+    uint8_t* ores = (uint8_t*)o_res8;
+    const TStride sor = o_res8 ? mk128(ores_strides) : TStride{0, 0, 0};
     if (!sok128(q_strides) || !sok128(k_strides) || !sok128(v_strides) || !sok128(o_strides) || !a16(q) || !a16(k) || !a16(v) || !a16(o)) return VGPA_ERR_INVALID;
     if (!rok128(q_strides, B, H, Sq) || !rok128(k_strides, B, H, Skv) || !rok128(v_strides, B, H, Skv) || !rok128(o_strides, B, H, Sq)) return VGPA_ERR_INVALID;
     const int64_t n_qt = (Sq + 127) / 128, tasks = B * H * n_qt;
@@ -881,15 +912,16 @@ extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v,
         if (hipMemsetAsync(workspace, 0, vgpa_attn128_fwd_workspace_bytes(B, H, Sq), stream) != hipSuccess) return VGPA_ERR_LAUNCH;
         VGPA_LAUNCH(attn128_kmax_kernel, dim3(16, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)k, mk128(k_strides), (int)Skv, (int)H, kmax2);
         VGPA_LAUNCH(attn128_fwd_w1_kernel, dim3((unsigned)tasks256), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
-                    (const unsigned*)kmax2, flags, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_q256, c);
+                    (const unsigned*)kmax2, flags, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_q256, c,
+                    ores, sor);
         // flagged strips again, with the running-max kernel (exits at once for unflagged ones)
         VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
-                    mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags);
+                    mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags, ores, sor);
         VGPA_CHECK_LAUNCH();
         return VGPA_OK;
     }
     VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
-                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)nullptr);
+                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)nullptr, ores, sor);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -1048,7 +1080,7 @@ __global__ __launch_bounds__(256) void attn128_f8_quant_kernel(const bf16_t* __r
 __global__ __launch_bounds__(256, 1) void attn128_fwd_f8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ K8, const uint8_t* __restrict__ V8T,
                                                                   const float* __restrict__ QN2, const unsigned* __restrict__ KMAX2, const unsigned* __restrict__ STATS,
                                                                   bf16_t* __restrict__ O, float* __restrict__ LSE2, int* __restrict__ flags, TStride so, int Sq, int Skv,
-                                                                  int Lp, int H, int n_qt, float c) {
+                                                                  int Lp, int H, int n_qt, float c, uint8_t* __restrict__ ORES, TStride sor) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[F8_RING_BYTES];   // slot = [K8 tile 64 x 128 B | V8^T tile 128 x 64 B]
     const int vid = blockIdx.x;
     const int bh = vid / n_qt, qt = vid % n_qt;
@@ -1154,7 +1186,7 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_f8_kernel(const uint8_t* _
         const int q = q0 + 32 * j + m;
         if (q < Sq) {
             bad = bad || !(l >= W1H_L_MIN && l < INFINITY) || !(M <= W1H_M_MAX);
-            store_col128(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), o[j], 1.f / l, hi);
+            store_col128_res8(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), RES_ROW(ORES, sor, b, h, q), o[j], 1.f / l, hi);
             if (hi == 0) LSE2[(size_t)bh * Sq + q] = M + __builtin_amdgcn_logf(l);
         }
     }
@@ -1172,9 +1204,11 @@ extern "C" size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int6
 // softmax(scale q k^T) v with e4m3 matrix operands (forward only: same arguments and results as vgpa_attn128_fwd; the workspace holds the quantised
 // copies and is scratch).  Strips the kernel flags (row sum near underflow, bound too large) are redone by the bf16 running-max kernel.
 extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
-                                       const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale,
-                                       void* workspace, size_t ws_bytes, hipStream_t stream) {
-    if (!q || !k || !v || !o || !lse2 || !workspace || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
+                                       const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H,
+                                       int64_t Sq, int64_t Skv, float scale, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !o || !lse2 || !workspace || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || !res8_ok(o_res8, ores_strides, B, H, Sq)) return VGPA_ERR_INVALID;
+    uint8_t* ores = (uint8_t*)o_res8;
+    const TStride sor = o_res8 ? mk128(ores_strides) : TStride{0, 0, 0};
     if (!sok128(q_strides) || !sok128(k_strides) || !sok128(v_strides) || !sok128(o_strides) || !a16(q) || !a16(k) || !a16(v) || !a16(o)) return VGPA_ERR_INVALID;
     if (!rok128(q_strides, B, H, Sq) || !rok128(k_strides, B, H, Skv) || !rok128(v_strides, B, H, Skv) || !rok128(o_strides, B, H, Sq)) return VGPA_ERR_INVALID;
     if (ws_bytes < vgpa_attn128_fwd_f8_workspace_bytes(B, H, Sq, Skv) || ((uintptr_t)workspace & 255)) return VGPA_ERR_WORKSPACE;
@@ -1197,9 +1231,9 @@ extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void*
     VGPA_LAUNCH(attn128_f8_quant_kernel, dim3((unsigned)nblk, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                 mk128(q_strides), mk128(k_strides), mk128(v_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, c, (const unsigned*)stats, q8, k8, v8t, qn2, kmax2);
     VGPA_LAUNCH(attn128_fwd_f8_kernel, dim3((unsigned)tasks256), dim3(256), 0, stream, (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)v8t, (const float*)qn2,
-                (const unsigned*)kmax2, (const unsigned*)stats, (bf16_t*)o, lse2, flags, mk128(o_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, (int)n_q256, c);
+                (const unsigned*)kmax2, (const unsigned*)stats, (bf16_t*)o, lse2, flags, mk128(o_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, (int)n_q256, c, ores, sor);
     VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
-                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags);
+                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags, ores, sor);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -1220,9 +1254,10 @@ extern "C" size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t
 extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
                                     void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                     const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
-                                    const int64_t* dv_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv, float scale, int32_t dkv_mode, void* workspace,
-                                    size_t ws_bytes, hipStream_t stream) {
-    if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return VGPA_ERR_INVALID;
+                                    const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
+                                    float scale, int32_t dkv_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || !res8_ok(o_res8, ores_strides, B, H, Sq))
+        return VGPA_ERR_INVALID;
     const int64_t* qs[] = {q_strides, o_strides, do_strides, dq_strides};
     const int64_t* ks[] = {k_strides, v_strides, dk_strides, dv_strides};
     for (const int64_t* s : qs) if (!sok128(s) || !rok128(s, B, H, Sq)) return VGPA_ERR_INVALID;
@@ -1238,7 +1273,8 @@ extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v,
     const bool w1 = dkv_mode == 1 || (dkv_mode < 0 && Sq >= attn128_min_sweep());
     const bool w1q = dkv_mode == 1 || (dkv_mode < 0 && Skv >= attn128_min_sweep());     // the dQ kernel sweeps the keys
     VGPA_LAUNCH(attn128_delta_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, mk128(do_strides),
-                mk128(o_strides), (int)Sq, (int)H, total, delta, lse2, 1.f / c, (w1 || w1q) ? stats : (float*)nullptr);
+                mk128(o_strides), (int)Sq, (int)H, total, delta, lse2, 1.f / c, (w1 || w1q) ? stats : (float*)nullptr, (const uint8_t*)o_res8,
+                o_res8 ? mk128(ores_strides) : TStride{0, 0, 0});
     if (w1q && attn128_dq_x2()) {
         const int64_t n_q256 = (Sq + 255) / 256;
         VGPA_LAUNCH(attn128_dq_w1x2_kernel, dim3((unsigned)(B * H * n_q256)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,

@@ -208,8 +208,8 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                bf16_t* __restrict__ O, float* __restrict__ LSE2, const unsigned* __restrict__ KMAX2,
                                                                int* __restrict__ flags, TStride sq, TStride sk, TStride sv, TStride so, int S, int H,
-                                                               int n_qt, int task0, int nsplit, float* __restrict__ part, bf16_t* __restrict__ ORES,
-                                                               TStride sor) {
+                                                               int n_qt, int task0, int nsplit, float* __restrict__ part, void* __restrict__ ORES,
+                                                               TStride sor, int res_kind) {
     constexpr int QB = 2;
     __shared__ __attribute__((aligned(1024))) uint8_t lds[W1_RING_BYTES];   // slot = [K tile | V tile]
     const int vid = task0 + (SPLIT ? (int)blockIdx.x / nsplit : xcd_remap(blockIdx.x, gridDim.x));
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
             bad = bad || !(l[j] >= W1_L_MIN && l[j] < INFINITY) || !(-nm[j] <= W1_M_MAX);
             const float inv = 1.f / l[j];
             bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
-            bf16_t* rp = ORES ? ORES + ((size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s) : nullptr;
+            const size_t ro = (size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s;      // residual row (elements of either kind)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
                     w[0] = pack_bf16x2(x[0], x[1]);
                     w[1] = pack_bf16x2(x[2], x[3]);
                     *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
-                    if (rp) *reinterpret_cast<u32x2_t*>(rp + db * 32 + 8 * g + 4 * hi) = w1_residual4(x, w);
+                    if (res_kind == VGPA_RES_8) *reinterpret_cast<uint32_t*>((uint8_t*)ORES + ro + db * 32 + 8 * g + 4 * hi) = res8_pack4(x, w);
+                    else if (res_kind == VGPA_RES_BF16) *reinterpret_cast<u32x2_t*>((bf16_t*)ORES + ro + db * 32 + 8 * g + 4 * hi) = w1_residual4(x, w);
                 }
             if (hi == 0) LSE2[(int64_t)bh * S + q] = -nm[j] + __builtin_amdgcn_logf(l[j]);  // v_log_f32 is log2
         }
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
 
 // combine the key-range chunks of the split forward tasks (all chunks share M): one wave per query row, lane = d
 __global__ __launch_bounds__(256) void w1_fwd_merge_kernel(const float* __restrict__ part, int nsplit, int task0, int n_qt, bf16_t* __restrict__ O, TStride so,
-                                                             float* __restrict__ LSE2, int* __restrict__ flags, int S, int H, bf16_t* __restrict__ ORES,
-                                                             TStride sor) {
+                                                             float* __restrict__ LSE2, int* __restrict__ flags, int S, int H, void* __restrict__ ORES,
+                                                             TStride sor, int res_kind) {
     const int lane = threadIdx.x & 63, r = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6), tl = blockIdx.x >> 6;
     const int vid = task0 + tl, bh = vid / n_qt, qt = vid % n_qt;
     const int q = qt * 256 + r;
@@ -368,7 +369,9 @@ __global__ __launch_bounds__(256) void w1_fwd_merge_kernel(const float* __restri
     const float x = acc / L;
     const bf16_t xb = f32_to_bf16(x);
     O[(size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + lane] = xb;
-    if (ORES) ORES[(size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + lane] = f32_to_bf16(x - bf16_to_f32(xb));
+    const size_t ro = (size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + lane;
+    if (res_kind == VGPA_RES_8) ((uint8_t*)ORES)[ro] = (uint8_t)res8_byte(x, xb);
+    else if (res_kind == VGPA_RES_BF16) ((bf16_t*)ORES)[ro] = f32_to_bf16(x - bf16_to_f32(xb));
     if (lane == 0) {
         LSE2[(int64_t)bh * S + q] = pb[256 * HD + r] + __builtin_amdgcn_logf(L);
         if (!(L >= W1_L_MIN && L < INFINITY) || !(pb[256 * HD + r] <= W1_M_MAX)) flags[vid] = 1;
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256) void w1_dkv_merge_kernel(const float* __restri
 // streams: stats[b,h,0,q] = -lse2, stats[b,h,1,q] = -delta
 __global__ __launch_bounds__(256) void w1_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, const float* __restrict__ LSE2,
                                                             TStride sdo, TStride so, int S, int H, int64_t total /* B*H*S */, float* __restrict__ delta,
-                                                            float* __restrict__ stats, const bf16_t* __restrict__ ORES, TStride sor) {
+                                                            float* __restrict__ stats, const void* __restrict__ ORES, TStride sor, int res_kind) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 8 lanes per (b,h,q) row, 16 B each
     const int64_t row = gid >> 3;
     const int c8 = (int)(gid & 7);
@@ -544,12 +547,18 @@ __global__ __launch_bounds__(256) void w1_bwd_prep_kernel(const bf16_t* __restri
         const int h = (int)(bh % H), b = (int)(bh / H);
         float a[8], o[8];
         unpack8(*reinterpret_cast<const u32x4_t*>(dO + ((size_t)b * sdo.b + (size_t)h * sdo.h + (size_t)q * sdo.s + c8 * 8)), a);
-        unpack8(*reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c8 * 8)), o);
-        if (ORES) {   // the forward's rounding residual: delta from O + O_res (see w1_residual4)
-            float r[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(ORES + ((size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + c8 * 8)), r);
+        const u32x4_t ob = *reinterpret_cast<const u32x4_t*>(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s + c8 * 8));
+        const size_t ro = (size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + c8 * 8;
+        if (res_kind == VGPA_RES_8) {          // the forward's 8 further mantissa bits (common.h res8): delta from the output to 2^-17
+            unpack8_res8(ob, *reinterpret_cast<const u32x2_t*>((const uint8_t*)ORES + ro), o);
+        } else {
+            unpack8(ob, o);
+            if (res_kind == VGPA_RES_BF16) {   // the forward's rounding residual: delta from O + O_res (see w1_residual4)
+                float r[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>((const bf16_t*)ORES + ro), r);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += r[j];
+                for (int j = 0; j < 8; ++j) o[j] += r[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
@@ -628,23 +637,24 @@ int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const v
 
 
 // step 1 for the w1 dK/dV kernel: delta (fp32 [B,H,S]) and stats (fp32 [B,H,2,S] = {-lse2, -delta})
-// o_res (optional, with its own strides): the forward's rounding residual (vgpa_attn_fwd_w1_res); delta is then rowsum(dO o (O + O_res))
-int32_t vgpa_attn_bwd_prep_w1_res(const void* o, const void* o_res, const void* d_o, const float* lse2, const int64_t* o_strides,
+// o_res (optional, with its own strides, res_kind as vgpa_attn_fwd_w1_res wrote it): delta is then rowsum(dO o O) of the output as o_res completes it
+int32_t vgpa_attn_bwd_prep_w1_res(const void* o, const void* o_res, int32_t res_kind, const void* d_o, const float* lse2, const int64_t* o_strides,
                                   const int64_t* ores_strides, const int64_t* do_strides, float* delta, float* stats, int64_t B, int64_t H, int64_t S,
                                   int64_t head_dim, hipStream_t stream) {
     if (!o || !d_o || !lse2 || !delta || !stats || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
 #define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
     if (!SOK(o_strides) || !SOK(do_strides) || !al16(o) || !al16(d_o)) return VGPA_ERR_INVALID;
-    if (o_res && (!SOK(ores_strides) || !al16(o_res))) return VGPA_ERR_INVALID;
+    if (o_res && (!SOK(ores_strides) || !al16(o_res) || (res_kind != VGPA_RES_BF16 && res_kind != VGPA_RES_8))) return VGPA_ERR_INVALID;
     const int64_t total = B * H * S;
     VGPA_LAUNCH(w1_bwd_prep_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)d_o, (const bf16_t*)o, lse2,
-                mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta, stats, (const bf16_t*)o_res, o_res ? mk(ores_strides) : mk(o_strides));
+                mk(do_strides), mk(o_strides), (int)S, (int)H, total, delta, stats, o_res, o_res ? mk(ores_strides) : mk(o_strides),
+                o_res ? (int)res_kind : VGPA_RES_NONE);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
 int32_t vgpa_attn_bwd_prep_w1(const void* o, const void* d_o, const float* lse2, const int64_t* o_strides, const int64_t* do_strides, float* delta,
                               float* stats, int64_t B, int64_t H, int64_t S, int64_t head_dim, hipStream_t stream) {
-    return vgpa_attn_bwd_prep_w1_res(o, nullptr, d_o, lse2, o_strides, nullptr, do_strides, delta, stats, B, H, S, head_dim, stream);
+    return vgpa_attn_bwd_prep_w1_res(o, nullptr, VGPA_RES_NONE, d_o, lse2, o_strides, nullptr, do_strides, delta, stats, B, H, S, head_dim, stream);
 }
 
 // dK, dV on the w1 structure: arguments as vgpa_attn_bwd_dkv_ws, with `stats` (vgpa_attn_bwd_prep_w1) in the place of lse2 / delta
@@ -698,9 +708,10 @@ size_t vgpa_attn_fwd_w1_workspace_bytes(int64_t B, int64_t H, int64_t S) {
     const size_t head = (((size_t)(B * H) + (size_t)tasks) * 4 + 255) / 256 * 256;
     return head + (size_t)parts * W1_FWD_PART_FLOATS * sizeof(float);
 }
-// vgpa_attn_fwd_w1 that also leaves the rounding residual o_res = O_fp32 - bf16(O) (bf16 view [B,H,S,64] with its own strides; NULL: not written)
-// for the backward's delta (vgpa_attn_bwd_prep_w1_res / vgpa_attn_bwd_delta_res).
-int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* o, void* o_res, float* lse2, const int64_t* q_strides,
+// vgpa_attn_fwd_w1 that also leaves what the bf16 rounding of the output dropped, for the backward's delta (vgpa_attn_bwd_prep_w1_res /
+// vgpa_attn_bwd_delta_res): o_res = a [B,H,S,64] view with its own element strides (NULL: not written) of
+//   res_kind VGPA_RES_BF16 (1): bf16, O_fp32 - bf16(O);   VGPA_RES_8 (2): uint8, eight further mantissa bits (common.h res8) -- half the bytes, O to 2^-17 either way
+int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* o, void* o_res, int32_t res_kind, float* lse2, const int64_t* q_strides,
                              const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* ores_strides, int64_t B,
                              int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes,
                              hipStream_t stream) {
@@ -709,9 +720,10 @@ int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* 
 #define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides) || !al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(workspace))
         return VGPA_ERR_INVALID;
-    if (o_res && (!SOK(ores_strides) || !al16(o_res))) return VGPA_ERR_INVALID;
+    if (o_res && (!SOK(ores_strides) || !al16(o_res) || (res_kind != VGPA_RES_BF16 && res_kind != VGPA_RES_8))) return VGPA_ERR_INVALID;
 #undef SOK
-    bf16_t* ores = (bf16_t*)o_res;
+    void* ores = o_res;
+    const int rk = o_res ? (int)res_kind : VGPA_RES_NONE;
     const TStride sor = o_res ? mk(ores_strides) : mk(o_strides);
     const int n_qt = (int)((S + 255) / 256);
     const int64_t tasks = (int64_t)n_qt * B * H;
@@ -724,7 +736,7 @@ int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* 
     if (S < W1_FWD_MIN_S) {   // a handful of keys per row: the online-softmax kernel (its top weight is exactly 1; see W1_FWD_MIN_S)
         if (hipMemsetAsync(workspace, 0xff, head, stream) != hipSuccess) return VGPA_ERR_LAUNCH;   // every strip flagged
         return vgpa_internal_attn_fwd_redo(q, k, v, o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, tasks,
-                                           flags, stream, ores, sor);
+                                           flags, stream, ores, sor, rk);
     }
     if (hipMemsetAsync(workspace, 0, head, stream) != hipSuccess) return VGPA_ERR_LAUNCH;
     VGPA_LAUNCH(w1_kmax_kernel, dim3(16, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)k, mk(k_strides), (int)S, (int)H, kmax2);
@@ -740,25 +752,25 @@ int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* 
     if (n_main > 0) {
         VGPA_LAUNCH((attn_fwd_w1_kernel<false>), dim3((unsigned)n_main), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                     (bf16_t*)o, lse2, (const unsigned*)kmax2, flags, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, 0, 1,
-                    (float*)nullptr, ores, sor);
+                    (float*)nullptr, ores, sor, rk);
         VGPA_CHECK_LAUNCH();
     }
     if (n_main < tasks) {
         VGPA_LAUNCH((attn_fwd_w1_kernel<true>), dim3((unsigned)(n_tail * nsplit)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                     (const bf16_t*)v, (bf16_t*)o, lse2, (const unsigned*)kmax2, flags, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S,
-                    (int)H, n_qt, (int)n_main, nsplit, part, ores, sor);
+                    (int)H, n_qt, (int)n_main, nsplit, part, ores, sor, rk);
         VGPA_CHECK_LAUNCH();
         VGPA_LAUNCH(w1_fwd_merge_kernel, dim3((unsigned)(n_tail * 64)), dim3(256), 0, stream, (const float*)part, nsplit, (int)n_main, n_qt, (bf16_t*)o,
-                    mk(o_strides), lse2, flags, (int)S, (int)H, ores, sor);
+                    mk(o_strides), lse2, flags, (int)S, (int)H, ores, sor, rk);
         VGPA_CHECK_LAUNCH();
     }
     return vgpa_internal_attn_fwd_redo(q, k, v, o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, tasks, flags, stream,
-                                       ores, sor);
+                                       ores, sor, rk);
 }
 int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                          const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,
                          int32_t split_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
-    return vgpa_attn_fwd_w1_res(q, k, v, o, nullptr, lse2, q_strides, k_strides, v_strides, o_strides, nullptr, B, H, S, head_dim, scale, split_mode,
+    return vgpa_attn_fwd_w1_res(q, k, v, o, nullptr, VGPA_RES_NONE, lse2, q_strides, k_strides, v_strides, o_strides, nullptr, B, H, S, head_dim, scale, split_mode,
                                 workspace, ws_bytes, stream);
 }
 

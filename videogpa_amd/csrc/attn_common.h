@@ -88,4 +88,5 @@ static inline void split_plan(int64_t tasks, int nt, int split_mode, int max_spl
 
 // attention.hip: the online-softmax forward over the flagged 256-row strips only (redo pass of the w1 forward)
 int32_t vgpa_internal_attn_fwd_redo(const void* q, const void* k, const void* v, void* o, float* lse2, TStride sq, TStride sk, TStride sv, TStride so,
-                                    int S, int H, int n_qt, int64_t tasks, const int* flags, hipStream_t stream, bf16_t* o_res = nullptr, TStride sor = TStride{0, 0, 0});
+                                    int S, int H, int n_qt, int64_t tasks, const int* flags, hipStream_t stream, void* o_res = nullptr, TStride sor = TStride{0, 0, 0},
+                                    int res_kind = VGPA_RES_NONE);

@@ -60,6 +60,42 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
     return v;
 }
 
+// ---- "res8": eight further mantissa bits of a value behind its bf16 rounding -------------------------------------------------------
+// The attention forward stores its output as bf16 (the projection that follows multiplies bf16), but the backward's delta = rowsum(dO o O)
+// wants the UNROUNDED output (csrc/attention_w1.hip, w1_residual4, has the why).  One byte per element carries the difference: with
+// E = the biased exponent of bf16(x), ulp = 2^(E - 134), the residual x - bf16(x) lies in [-ulp / 2, ulp / 2] and is stored as
+//     byte = 128 + clamp(rint((x - bf16(x)) * 2^8 / ulp), -128, 127),
+// so (bf16(x), byte) together hold x to 2^-17 relative -- what a bf16 residual tensor gives (2^-18) at half its bytes.  |x| < 2^-111 stores 128.
+#define VGPA_RES_NONE 0
+#define VGPA_RES_BF16 1   // o_res = bf16(x - bf16(x))
+#define VGPA_RES_8 2      // the byte above
+__device__ __forceinline__ uint32_t res8_byte(float x, uint32_t xb /* bf16 bits of x in the low half */) {
+    const uint32_t E = (xb >> 7) & 0xffu;
+    const float r = x - __uint_as_float(xb << 16);
+    const float t = __builtin_rintf(r * __uint_as_float((269u - E) << 23));          // 2^(142 - E) = 2^8 / ulp
+    const int q = E > 15u ? (int)fminf(fmaxf(t, -128.f), 127.f) : 0;
+    return (uint32_t)(q + 128);
+}
+// four values and their packed bf16 pairs (element 0 in the low half of packed[0]) -> four bytes, element 0 lowest
+__device__ __forceinline__ uint32_t res8_pack4(const float* x, u32x2_t packed) {
+    return res8_byte(x[0], packed[0] & 0xffffu) | (res8_byte(x[1], packed[0] >> 16) << 8) | (res8_byte(x[2], packed[1] & 0xffffu) << 16) |
+           (res8_byte(x[3], packed[1] >> 16) << 24);
+}
+__device__ __forceinline__ float res8_value(uint32_t xb /* bf16 bits in the low half */, uint32_t byte) {
+    const uint32_t E = (xb >> 7) & 0xffu;
+    const float sc = E > 15u ? __uint_as_float((E - 15u) << 23) : 0.f;             // ulp / 2^8
+    return __uint_as_float(xb << 16) + ((float)byte - 128.f) * sc;
+}
+// eight bf16 values (16 bytes) and their eight res8 bytes -> fp32
+__device__ __forceinline__ void unpack8_res8(const u32x4_t v, const u32x2_t r, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t rb = r[i >> 1] >> (16 * (i & 1));
+        f[2 * i] = res8_value(v[i] & 0xffffu, rb & 0xffu);
+        f[2 * i + 1] = res8_value(v[i] >> 16, (rb >> 8) & 0xffu);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -1,5 +1,7 @@
 """torch.autograd wrappers over the C-ABI HIP kernels.  PyTorch here is plumbing (device memory, streams,
 autograd graph); every op below runs a hand-written gfx950 kernel through `_lib.call` and raises if it cannot."""
+import contextlib as _contextlib
+import contextvars as _contextvars
 import ctypes
 import os as _os
 
@@ -458,32 +460,55 @@ def _transposed(W):
 # split is set by the model that knows its rows per sample (WanModel.forward) and applies only to row counts that are a multiple of it.
 # VGPA_GEMM_SPLIT_M in the environment overrides the models' choice (0 = never split); VGPA_GEMM_SPLIT_EXT_ONLY=1 restricts it to the LoRA-extended GEMMs.
 _GEMM_SPLIT_ENV = _os.environ.get("VGPA_GEMM_SPLIT_M")
-GEMM_SPLIT_M = int(_GEMM_SPLIT_ENV) if _GEMM_SPLIT_ENV is not None else 0
 GEMM_SPLIT_EXT_ONLY = _os.environ.get("VGPA_GEMM_SPLIT_EXT_ONLY", "0") == "1"
+# The setting is SCOPED, not process state: a model wraps its forward in `with gemm_rows_per_call(L):` (a contextvar: other models / threads of the process
+# see 0), every autograd node below records the value it ran its forward GEMM with (ctx.rows_per_call) and runs its backward GEMMs with the same one -- the
+# autograd engine's threads never consult the context.  A checkpointed block re-enters the context in its recomputation (WanModel.forward).
+_GEMM_ROWS = _contextvars.ContextVar("vgpa_gemm_rows_per_call", default=0)
 
 
-def set_gemm_rows_per_call(rows):
-    """called by a model's forward with its rows per sample (0: one call per GEMM); the backward of the same step sees the same setting"""
-    global GEMM_SPLIT_M
-    if _GEMM_SPLIT_ENV is None:
-        GEMM_SPLIT_M = int(rows)
+@_contextlib.contextmanager
+def gemm_rows_per_call(rows):
+    """for the duration of a model's forward: vendor GEMMs whose row count is a multiple (>= 2x) of `rows` run one call per `rows` rows (0: one call)"""
+    tok = _GEMM_ROWS.set(int(rows))
+    try:
+        yield
+    finally:
+        _GEMM_ROWS.reset(tok)
 
 
-def _linear_rows(x2, W, bias, ext=False):
+def current_gemm_rows():
+    return int(_GEMM_SPLIT_ENV) if _GEMM_SPLIT_ENV is not None else _GEMM_ROWS.get()
+
+
+def _slack_rows(x2):
+    """rows of [M, K] storage behind x2 that _empty_rows (directly, or under a _padded_empty head view) allocated for the vendor GEMM to run over: the
+    row count it may cover (>= M), or M when x2 is anything else -- a caller's view of some other buffer is never read or written past its shape."""
+    base = x2 if x2._base is None else x2._base
+    tag = getattr(base, "_vgpa_rows", None)
+    if tag is None or x2.dim() != 2 or x2.stride(1) != 1:
+        return x2.shape[0]
+    rows, Mp, width = tag          # logical rows, storage rows, row width of the buffer
+    if x2.shape[0] != rows or x2.stride(0) != width or x2.data_ptr() != base.data_ptr() or x2.shape[1] > width:
+        return x2.shape[0]
+    return Mp
+
+
+def _linear_rows(x2, W, bias, ext=False, split=0):
     M = x2.shape[0]
-    if GEMM_ROW_SLACK and 16384 <= M <= 65536 and x2.is_cuda and x2.dim() == 2 and x2.stride(1) == 1 and (GEMM_SPLIT_M <= 0 or M % GEMM_SPLIT_M):
-        # the operand was allocated with row slack (_empty_rows): run the GEMM over the padded row count -- rows are independent, the extra output rows are
-        # never read -- because hipBLASLt is 1-17 % faster at M = 35 840 / 36 864 than at 35 552 (tools/gemm_m_probe.py)
-        room = x2.untyped_storage().nbytes() // x2.element_size()
+    if GEMM_ROW_SLACK and 16384 <= M <= 65536 and x2.is_cuda and x2.dim() == 2 and x2.stride(1) == 1 and (split <= 0 or M % split):
+        # the operand was allocated with row slack (_empty_rows, recognised by its tag): run the GEMM over the padded row count -- rows are independent, the
+        # extra output rows are never read -- because hipBLASLt is 1-17 % faster at M = 35 840 / 36 864 than at 35 552 (tools/gemm_m_probe.py)
+        room = _slack_rows(x2)
         for Mp in (gemm_rows(M, W.shape[0], W.shape[1]), gemm_rows(M)):
-            if Mp > M and x2.storage_offset() + (Mp - 1) * x2.stride(0) + x2.shape[1] <= room:
+            if M < Mp <= room:
                 xp = torch.as_strided(x2, (Mp, x2.shape[1]), x2.stride(), x2.storage_offset())
                 return torch.nn.functional.linear(xp, W, bias)[:M]
-    if GEMM_SPLIT_M <= 0 or M < 2 * GEMM_SPLIT_M or M % GEMM_SPLIT_M or not x2.is_cuda or (GEMM_SPLIT_EXT_ONLY and not ext):
+    if split <= 0 or M < 2 * split or M % split or not x2.is_cuda or x2.dim() != 2 or (GEMM_SPLIT_EXT_ONLY and not ext):
         return torch.nn.functional.linear(x2, W, bias)
     out = torch.empty(M, W.shape[0], dtype=x2.dtype, device=x2.device)
-    for a in range(0, M, GEMM_SPLIT_M):
-        b = a + GEMM_SPLIT_M
+    for a in range(0, M, split):
+        b = a + split
         if bias is None:
             torch.mm(x2[a:b], W.t(), out=out[a:b])
         else:
@@ -491,18 +516,20 @@ def _linear_rows(x2, W, bias, ext=False):
     return out
 
 
-def _gemm(x2, W, bias=None, ext=False):
-    """x2 [M,K] @ W[N,K]^T (+ bias) through hipBLASLt (torch), timed like the hand-written kernels when bench.py asks for it."""
+def _gemm(x2, W, bias=None, ext=False, split=None):
+    """x2 [M,K] @ W[N,K]^T (+ bias) through hipBLASLt (torch), timed like the hand-written kernels when bench.py asks for it.  split: rows per call
+    (None: the enclosing gemm_rows_per_call context -- forward passes; backward passes hand in what their node recorded)."""
+    split = current_gemm_rows() if split is None else split
     if TIMER is None:
-        return _linear_rows(x2, W, bias, ext)
+        return _linear_rows(x2, W, bias, ext, split)
     out = []
-    _timed("hipblaslt_gemm (vendor)", 2.0 * x2.shape[0] * W.shape[0] * W.shape[1], lambda: out.append(_linear_rows(x2, W, bias, ext)))
+    _timed("hipblaslt_gemm (vendor)", 2.0 * x2.shape[0] * W.shape[0] * W.shape[1], lambda: out.append(_linear_rows(x2, W, bias, ext, split)))
     return out[0]
 
 
-def _frozen_dx(dy2, W):
+def _frozen_dx(dy2, W, split=0):
     Wt = _transposed(W)
-    return dy2 @ W if Wt is None else _gemm(dy2, Wt)
+    return dy2 @ W if Wt is None else _gemm(dy2, Wt, split=split)
 
 
 class _FrozenLinearFn(torch.autograd.Function):
@@ -511,7 +538,8 @@ class _FrozenLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, bias):
         ctx.save_for_backward(W)
-        return _gemm(x.reshape(-1, x.shape[-1]), W, bias).view(*x.shape[:-1], W.shape[0])
+        ctx.rows_per_call = current_gemm_rows()
+        return _gemm(x.reshape(-1, x.shape[-1]), W, bias, split=ctx.rows_per_call).view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -519,7 +547,7 @@ class _FrozenLinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.stride(1) != 1:
             dy2 = dy2.contiguous()
-        return _frozen_dx(dy2, W).view(*dy.shape[:-1], W.shape[1]), None, None
+        return _frozen_dx(dy2, W, ctx.rows_per_call).view(*dy.shape[:-1], W.shape[1]), None, None
 
 
 def frozen_linear(x, W, bias):
@@ -573,7 +601,9 @@ def _empty_rows(shape, dtype, device, wide=False):
     if Mp == rows or str(device).startswith("cpu"):
         return torch.empty(shape, dtype=dtype, device=device)
     t = torch.empty(Mp * shape[-1], dtype=dtype, device=device)
-    return t.resize_(shape)
+    t = t.resize_(shape)
+    t._vgpa_rows = (rows, Mp, shape[-1])      # what _slack_rows recognises: ONLY buffers made here are ever run past their logical row count
+    return t
 
 
 def _padded_empty(shape, D, pad, dtype, device):
@@ -764,7 +794,8 @@ class _LinearLoraExtFn(torch.autograd.Function):
         if enabled:
             lora_down(xv, ext.A_cat, out=tv)       # raw kernel write into the tail (no autograd version bump on the producer's buffer)
         # disabled (reference pass): the tail of a `_padded_empty` buffer is zero since its allocation
-        y = _gemm(x_ext, ext.W_ext, bias, ext=True)
+        ctx.rows_per_call = current_gemm_rows()
+        y = _gemm(x_ext, ext.W_ext, bias, ext=True, split=ctx.rows_per_call)
         if x_recompute is not None and enabled:
             fn, srcs = x_recompute
             ctx.save_for_backward(tv.contiguous(), *srcs)     # the recompute sources go through autograd's saved-tensor checks (in-place version, lifetime)
@@ -789,7 +820,7 @@ class _LinearLoraExtFn(torch.autograd.Function):
         if enabled:
             for j, i in enumerate(act):
                 lora_down(dy_ext[:, i * Dn:(i + 1) * Dn], ext.sBt[j], out=dy_ext[:, N + j * rp:N + (j + 1) * rp])      # dT_i = dy_i (s B_i)
-        dx = _gemm(dy_ext, ext.Wt_ext, ext=True)                                                                                # dy W + dT A
+        dx = _gemm(dy_ext, ext.Wt_ext, ext=True, split=ctx.rows_per_call)                                                       # dy W + dT A
         out_grads = [None] * len(ctx.needs_input_grad[6:])
         if enabled:
             if ctx.x_fn is not None:
@@ -848,12 +879,42 @@ ATTN_SPLIT_MODE = int(_os.environ.get("VGPA_ATTN_SPLIT", "-1"))
 # main loops).  VGPA_ATTN_W1 = comma list out of {fwd, dq, dkv} selects which (default all three; "none" = the 2-waves-per-SIMD
 # kernels of attention.hip, which stay in the library as the redo path of the forward and for A/B runs).
 ATTN_W1 = set(x for x in _os.environ.get("VGPA_ATTN_W1", "fwd,dq,dkv").split(",") if x and x != "none")
-# "Precise delta": the forward also stores the rounding residual of its output, o_res = O_fp32 - bf16(O) (bf16, + S*D*2 bytes per sequence and layer), and
-# the backward forms delta = rowsum(dO o (O + O_res)).  delta stands for rowsum(P o dP); formed from the bf16 O alone (what every flash-attention backward,
-# torch's included, does) each row's dS stops summing to zero and dQ picks up a coherent error -d(delta_i) sum_j P_ij K_j that swamps q / k gradients
-# which are small by cancellation (37-87 % of the last block's to_q / to_k adapter gradients at BASELINE configs[0] width: profiles/r04_cfg1_round_diag_*.json).
-# On by default (+0.1 ms per layer); off under lean activations (S = 41 026 has no room for it) and with VGPA_PRECISE_DELTA=0.
-PRECISE_DELTA = _os.environ.get("VGPA_PRECISE_DELTA", "1") == "1"
+# "Precise delta": the attention forward also stores what the bf16 rounding of its output dropped, and the backward forms delta = rowsum(dO o O) from the
+# completed output.  delta stands for rowsum(P o dP); formed from the bf16 O alone (what every flash-attention backward, torch's included, does) each row's dS
+# stops summing to zero and dQ picks up a coherent error -d(delta_i) sum_j P_ij K_j that swamps q / k gradients which are small by cancellation (37-87 % of
+# the last block's to_q / to_k adapter gradients at BASELINE configs[0] width: profiles/r04_cfg1_round_diag_*.json).  Two forms of the residual tensor:
+#   "int8" (default): one byte per output element = eight further mantissa bits (csrc/common.h res8) -- O to 2^-17; every attention path has it (head_dim 64
+#                     and 128, e4m3 forward, short-key kernel, lean activations);
+#   "bf16"          : bf16(O_fp32 - bf16(O)), twice the bytes, O to 2^-18 (the round-4 form; head_dim 64 only);
+#   None / "off"    : the textbook backward.
+# It is NOT process state: models carry `precise_delta` (constructor default = precise_delta_default(), i.e. VGPA_PRECISE_DELTA in the environment: 0 | off |
+# bf16 | int8) and hand it to qknorm_attention / attention128 per call; the autograd node keeps what its forward used.
+def precise_delta_default():
+    v = _os.environ.get("VGPA_PRECISE_DELTA", "int8").lower()
+    if v in ("0", "off", "none", "false"):
+        return None
+    if v in ("1", "int8", "res8", "true"):
+        return "int8"
+    if v == "bf16":
+        return "bf16"
+    raise ValueError(f"VGPA_PRECISE_DELTA={v!r}: expected 0 | off | int8 | bf16")
+
+
+def _res_kind(o_res):
+    if o_res is None:
+        return 0
+    if o_res.dtype == torch.bfloat16:
+        return 1
+    if o_res.dtype == torch.uint8:
+        return 2
+    raise TypeError(f"o_res: bf16 (rounding residual) or uint8 (eight further mantissa bits), got {o_res.dtype}")
+
+
+def res8_decode(o, o_res8):
+    """fp32 value of a bf16 tensor `o` completed by its res8 bytes (csrc/common.h): o + (byte - 128) * 2^(E - 142), E = biased exponent of o (tests)"""
+    E = (o.contiguous().view(torch.int16).to(torch.int32) >> 7) & 0xFF
+    sc = torch.where(E > 15, torch.ldexp(torch.ones((), device=o.device), E - 142), torch.zeros((), device=o.device))
+    return o.float() + (o_res8.float() - 128.0) * sc
 
 
 def prescale_q(q, scale=None):
@@ -865,7 +926,7 @@ def prescale_q(q, scale=None):
 
 def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o_pad=0, o_res=None):
     """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32.
-    o_res: optional bf16 [B,S,H*64] buffer that receives the output's rounding residual (w1 forward only; see PRECISE_DELTA).
+    o_res: optional [B,S,H*64] buffer, bf16 or uint8, that receives what the output's bf16 rounding dropped (w1 forward only; see "Precise delta").
     split_mode: -1 lets the launcher cut the tasks of a mostly empty last scheduling round into key-range chunks,
     0 forbids it, k >= 2 forces k chunks for every task (tests).  o_pad: o is the head of a [B,S,H*64+o_pad] buffer (the
     output projection's LoRA tail, see LoraExt)."""
@@ -883,7 +944,7 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
         if o_res is not None:
             rv = o_res.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
             _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
-                "vgpa_attn_fwd_w1_res", q, k, v, o, o_res, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), _bhs_strides(rv),
+                "vgpa_attn_fwd_w1_res", q, k, v, o, o_res, _res_kind(o_res), lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), _bhs_strides(rv),
                 B, H, S, Dh, float(scale), int(split_mode), ws, ws_bytes, _stream()))
             return o, lse
         _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
@@ -901,8 +962,8 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
 
 
 def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=False, split_mode=None, o_res=None):
-    """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.  o_res ([B,H,S,64] view): the forward's rounding
-    residual, delta = rowsum(dO o (O + O_res)) (PRECISE_DELTA).
+    """All [B,H,S,64] bf16 views; writes dq, dk, dv in place.  Three launches: delta, dK/dV, dQ.  o_res ([B,H,S,64] view, bf16 or uint8): what the forward
+    kept of the output beyond its bf16 rounding; delta is then formed from the completed output ("Precise delta").
     Algorithmic FLOPs (backward = 2 x forward): dK/dV kernel carries dV, dP, dK = 6 S^2 d; dQ kernel 2 S^2 d
     (the S = QK^T recomputes in both kernels and the second dP are overhead, not counted)."""
     B, H, S, Dh = q.shape
@@ -914,12 +975,12 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
     w1_dkv = "dkv" in ATTN_W1 and not ATTN_BWD_FUSED
     if w1_dkv:     # one pass: delta + the {-lse2, -delta} planes the w1 dK/dV kernel streams
         stats = torch.empty(B, H, 2, S, dtype=torch.float32, device=q.device)
-        _timed("attn_delta_kernel", (4.0 if o_res is None else 6.0) * B * H * S * Dh, lambda: _lib.call(
-            "vgpa_attn_bwd_prep_w1_res", o, o_res, do, lse, _bhs_strides(o), None if o_res is None else _bhs_strides(o_res), _bhs_strides(do), delta, stats,
-            B, H, S, Dh, st), "byte")
+        _timed("attn_delta_kernel", (4.0 + (0 if o_res is None else o_res.element_size())) * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_attn_bwd_prep_w1_res", o, o_res, _res_kind(o_res), do, lse, _bhs_strides(o), None if o_res is None else _bhs_strides(o_res), _bhs_strides(do),
+            delta, stats, B, H, S, Dh, st), "byte")
     else:
-        _timed("attn_delta_kernel", (4.0 if o_res is None else 6.0) * B * H * S * Dh, lambda: _lib.call(
-            "vgpa_attn_bwd_delta_res", o, o_res, do, _bhs_strides(o), None if o_res is None else _bhs_strides(o_res), _bhs_strides(do), delta,
+        _timed("attn_delta_kernel", (4.0 + (0 if o_res is None else o_res.element_size())) * B * H * S * Dh, lambda: _lib.call(
+            "vgpa_attn_bwd_delta_res", o, o_res, _res_kind(o_res), do, _bhs_strides(o), None if o_res is None else _bhs_strides(o_res), _bhs_strides(do), delta,
             B, H, S, Dh, st), "byte")
     if ATTN_BWD_FUSED:
         dq32 = torch.zeros(B, H, S, Dh, dtype=torch.float32, device=q.device)
@@ -951,9 +1012,10 @@ ATTN128_W1 = _os.environ.get("VGPA_ATTN128_W1", "1") == "1"    # 0: the compiler
 ATTN128_F8_MIN_KEYS = 1024      # below this the e4m3 forward's prep passes and pipeline fill do not pay (cross-attention over 512 text tokens stays bf16)
 
 
-def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False):
+def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None):
     """q [B,H,Sq,128], k / v [B,H,Skv,128] bf16 views (any batch / head / token strides, last dim contiguous) -> (o, lse2 [B,H,Sq] fp32).
     f8: the e4m3 forward (csrc/attention_hd128.hip, vgpa_attn128_fwd_f8) for sweeps of at least ATTN128_F8_MIN_KEYS keys.
+    o_res8: optional uint8 [B, Sq, H*128] buffer that receives eight further mantissa bits of every output value ("Precise delta").
     o is a [B,H,Sq,128] view of token-major storage [B, Sq, H*128 (+ o_pad)]: the caller's flatten to [B*Sq, H*128] is free, and with
     o_pad it is the head of a `_padded_empty` buffer (the output projection's LoRA tail, see LoraExt)."""
     B, H, Sq, D = q.shape
@@ -962,60 +1024,74 @@ def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False):
     o2 = _padded_empty((B, Sq), H * D, o_pad, torch.bfloat16, q.device) if o_pad else torch.empty(B, Sq, H * D, dtype=torch.bfloat16, device=q.device)
     o = o2.unflatten(-1, (H, D)).permute(0, 2, 1, 3)
     lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    rv = rs = None
+    if o_res8 is not None:
+        if o_res8.dtype != torch.uint8 or o_res8.shape != (B, Sq, H * D) or not o_res8.is_contiguous():
+            raise TypeError("attention128_fwd_raw: o_res8 is a contiguous uint8 [B, Sq, H*128] buffer")
+        rv = o_res8.unflatten(-1, (H, D)).permute(0, 2, 1, 3)
+        rs = _bhs_strides(rv)
     if f8 and Skv >= ATTN128_F8_MIN_KEYS:
         ws_bytes = _lib.query("vgpa_attn128_fwd_f8_workspace_bytes", B, H, Sq, Skv)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
         _timed("attn128_fwd_f8", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-            "vgpa_attn128_fwd_f8", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale),
+            "vgpa_attn128_fwd_f8", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), rv, rs, B, H, Sq, Skv, float(scale),
             ws, ws_bytes, _stream()))
         return o, lse
     ws_bytes = _lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, Sq) if ATTN128_W1 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
     _timed("attn128_fwd" if Skv >= 1024 else "attn128_fwd (short keys)", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-        "vgpa_attn128_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), B, H, Sq, Skv, float(scale),
+        "vgpa_attn128_fwd", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), rv, rs, B, H, Sq, Skv, float(scale),
         ws, ws_bytes, _stream()))
     return o, lse
 
 
-def attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale):
-    """all [B,H,S,128] bf16 views; writes dq, dk, dv in place (they may be strided slices of a fused gradient buffer)"""
+def attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, o_res8=None):
+    """all [B,H,S,128] bf16 views; writes dq, dk, dv in place (they may be strided slices of a fused gradient buffer).  o_res8 (uint8 [B, Sq, H*128], as the
+    forward wrote it): delta = rowsum(dO o O) is formed from the output completed by those eight further mantissa bits ("Precise delta")."""
     B, H, Sq, D = q.shape
     Skv = k.shape[2]
+    rv = None if o_res8 is None else o_res8.unflatten(-1, (H, D)).permute(0, 2, 1, 3)
     ws_bytes = _lib.query("vgpa_attn128_bwd_workspace_bytes", B, H, Sq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
     # algorithmic work as SURVEY 8d counts it: backward = 2 x forward (dV, dP, dK, dQ); the S = QK^T recomputes of the split kernels are overhead
     _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 8.0 * B * H * Sq * Skv * D, lambda: _lib.call(
         "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
-        _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), B, H, Sq, Skv, float(scale), -1 if ATTN128_W1 else 0, ws, ws_bytes, _stream()))
+        _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), rv, None if rv is None else _bhs_strides(rv), B, H, Sq, Skv, float(scale),
+        -1 if ATTN128_W1 else 0, ws, ws_bytes, _stream()))
 
 
 class _Attention128Fn(torch.autograd.Function):
     """softmax(scale q k^T) v for head_dim 128, query and key lengths free (csrc/attention_hd128.hip): Wan2.2's self- and cross-attention"""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale, o_pad):
+    def forward(ctx, q, k, v, scale, o_pad, precise_delta):
         q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
-        o, lse = attention128_fwd_raw(q, k, v, scale, o_pad)
-        ctx.save_for_backward(q, k, v, o, lse)
+        o_res8 = None
+        if precise_delta and any(ctx.needs_input_grad[:3]):
+            o_res8 = torch.empty(q.shape[0], q.shape[2], q.shape[1] * q.shape[3], dtype=torch.uint8, device=q.device)
+        o, lse = attention128_fwd_raw(q, k, v, scale, o_pad, o_res8=o_res8)
+        ctx.save_for_backward(q, k, v, o, lse, o_res8)
         ctx.scale = float(scale)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
+        q, k, v, o, lse, o_res8 = ctx.saved_tensors
         B, H, Sq, D = q.shape
         Skv = k.shape[2]
         do = do if do.stride(3) == 1 else do.contiguous()
         dq = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)      # token-major, like the projections' outputs
         dk = torch.empty(B, Skv, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
         dv = torch.empty(B, Skv, H, D, dtype=torch.bfloat16, device=q.device).permute(0, 2, 1, 3)
-        attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale)
-        return dq, dk, dv, None, None
+        attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale, o_res8=o_res8)
+        return dq, dk, dv, None, None, None
 
 
-def attention128(q, k, v, scale=None, o_pad=0):
-    """q [B, H, Sq, 128], k / v [B, H, Skv, 128] (bf16, last dim contiguous) -> [B, H, Sq, 128]"""
-    return _Attention128Fn.apply(q, k, v, q.shape[-1] ** -0.5 if scale is None else scale, int(o_pad))
+def attention128(q, k, v, scale=None, o_pad=0, precise_delta="int8"):
+    """q [B, H, Sq, 128], k / v [B, H, Skv, 128] (bf16, last dim contiguous) -> [B, H, Sq, 128].  precise_delta: "int8" (default) / None -- see "Precise delta" above"""
+    if precise_delta not in (None, "int8"):
+        raise ValueError('attention128: precise_delta is "int8" or None (the bf16 residual form exists at head_dim 64 only)')
+    return _Attention128Fn.apply(q, k, v, q.shape[-1] ** -0.5 if scale is None else scale, int(o_pad), precise_delta)
 
 
 class _QKNormAttentionFn(torch.autograd.Function):
@@ -1023,7 +1099,7 @@ class _QKNormAttentionFn(torch.autograd.Function):
     QK-norm (+ optional 3D RoPE on tokens >= text_len) -> flash attention; backward returns dqkv in the same layout."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad, rope_mode=0, recompute_qk=False):
+    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad, rope_mode=0, recompute_qk=False, precise_delta=None):
         """o_pad / grad_pad: the attention output / the gradient of qkv are returned as heads of buffers that much wider (the
         LoRA tails of the projections on either side, see LoraExt).  recompute_qk: the normalised q / k are not kept for the backward
         but made again from qkv (one more pass of the QK-norm kernel, bit-identical) -- a third of this node's saved bytes."""
@@ -1037,13 +1113,14 @@ class _QKNormAttentionFn(torch.autograd.Function):
         _timed("qknorm_rope_fwd", 8.0 * B * H * S * Dh, lambda: _lib.call(
             "vgpa_qknorm_rope_fwd", q_in, k_in, qn, kn, _bhs_strides(q_in), _bhs_strides(k_in), _bhs_strides(qn), _bhs_strides(kn),
             wq, bq, wk, bk, rope_cos, rope_sin, text_len, B, H, S, Dh, float(eps), float(Dh ** -0.5 * LOG2E), int(rope_mode), _stream()), "byte")
-        # the output's rounding residual for the backward's delta -- only where a backward will run, on the w1 forward, and not under lean activations
+        # what the output's bf16 rounding drops, for the backward's delta -- only where a backward will run and on the w1 forward; lean activations keep it too
+        # (1 byte per output element next to the 6 that recompute_qk gives back)
         o_res = None
-        if PRECISE_DELTA and "fwd" in ATTN_W1 and not recompute_qk and ctx.needs_input_grad[0]:
-            o_res = torch.empty(B, S, H * Dh, dtype=torch.bfloat16, device=qkv.device)
+        if precise_delta and "fwd" in ATTN_W1 and ctx.needs_input_grad[0]:
+            o_res = torch.empty(B, S, H * Dh, dtype=torch.uint8 if precise_delta == "int8" else torch.bfloat16, device=qkv.device)
         o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad, o_res=o_res)
         if recompute_qk:
-            ctx.save_for_backward(qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk)
+            ctx.save_for_backward(qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk, o_res)
         else:
             ctx.save_for_backward(qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin, o_res)
         ctx.meta = (text_len, H, eps, grad_pad, int(rope_mode), bool(recompute_qk))
@@ -1053,8 +1130,7 @@ class _QKNormAttentionFn(torch.autograd.Function):
     def backward(ctx, do):
         text_len, H, eps, grad_pad, rope_mode, recompute_qk = ctx.meta
         if recompute_qk:
-            qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk = ctx.saved_tensors
-            o_res = None
+            qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk, o_res = ctx.saved_tensors
         else:
             qkv, qn, kn, o, lse, wq, wk, rope_cos, rope_sin, o_res = ctx.saved_tensors
         B, S, W = qkv.shape
@@ -1081,14 +1157,16 @@ class _QKNormAttentionFn(torch.autograd.Function):
             "vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
             _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
             float(eps), rope_mode, _stream()), "byte")
-        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0, rope_mode=0, recompute_qk=False):
+def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0, rope_mode=0, recompute_qk=False, precise_delta="int8"):
     """rope = (cos, sin) fp32 [S - text_len, 64]; rope_mode 0: interleaved pairs (diffusers' CogVideoX), 1: half-split pairs inside each
-    32-feature half (VGGT's RotaryPositionEmbedding2D, tables from `rope2d_tables`)."""
+    32-feature half (VGGT's RotaryPositionEmbedding2D, tables from `rope2d_tables`).  precise_delta: "int8" | "bf16" | None, see "Precise delta"."""
     cos, sin = (None, None) if rope is None else rope
-    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad, rope_mode, bool(recompute_qk))
+    if precise_delta not in (None, "int8", "bf16"):
+        raise ValueError(f'precise_delta: "int8", "bf16" or None, got {precise_delta!r}')
+    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad, rope_mode, bool(recompute_qk), precise_delta)
 
 
 def rope2d_tables(pos, head_dim=64, frequency=100.0):

@@ -35,7 +35,9 @@ DEFAULT_CONFIG: Dict[str, Any] = {
     "beta": 1.0, "learning_rate": 5e-6, "weight_decay": 0.01, "warmup_steps": 500, "max_steps": 10000,
     "batch_size": 1, "accumulate_grad_batches": 2, "gradient_clip_val": 1.0,
     "enable_gradient_checkpointing": False,   # reference: True (80 GB GPUs); 288 GB keeps activations instead
-    "lean_activations": False,                # keep 23 % less per block (LN output and normalised q / k made again in the backward): for S = 41 026
+    # keep 23 % less per block (LN output and normalised q / k made again in the backward; results bit-identical): True / False, or "auto" = decided from the
+    # first batch's shape against the device's memory (memory_policy below) and logged -- cfg2 runs full, cfg3 at batch 2 and cfg4 (S = 41 026) run lean
+    "lean_activations": "auto",
     "metric_name": "consistency_score", "min_gap": 0.05, "motion_threshold": 1e-3,
     "log_every_n_steps": 10,
     "seed": 0,                                # (t, eps) stream = seed + rank: every rank draws its own
@@ -93,7 +95,8 @@ class CogVideoXDPOTrainer(nn.Module):
                 self.transformer.enable_gradient_checkpointing(stride=stride)
             else:
                 self.transformer.enable_gradient_checkpointing()
-        if cfg.get("lean_activations"):
+        self.memory_policy_log = None     # what "auto" decided, and from which numbers (set at the first step)
+        if cfg.get("lean_activations") is True:
             self.transformer.enable_lean_activations(True)       # this package's transformer only (AttributeError on anything else: say so loudly)
         self.ref_transformer = None
         if separate_ref:  # the reference's layout: a second frozen copy (:110-111)
@@ -134,11 +137,39 @@ class CogVideoXDPOTrainer(nn.Module):
             with self.transformer.disable_adapter():
                 return self.transformer(hs, encoder_hidden_states=prompt, timestep=tt, return_dict=True).sample
 
+    # bytes the backward keeps per token and block (bf16 activations of DESIGN section 3: residual stream x2, LN output + LoRA tail, fused q/k/v, normalised
+    # q and k, attention output + its res8 bytes, FF pre-activation, statistics), full set / lean set, at D = 3072; measured 2.9 / 2.2 GB per block and pair at S = 17 776
+    SAVED_BYTES_PER_TOKEN_BLOCK = {False: 79.0e3, True: 62.5e3}
+
+    def memory_policy(self, n_seq, tokens, device):
+        """lean_activations = "auto": full activations when the estimate (saved activations + 40 GB of weights, caches, optimizer state and workspaces) stays
+        under 80 % of the device's memory -- the caching allocator needs slack (a 269 GB step fragmented into an out-of-memory error in round 4) -- else lean;
+        if lean does not fit either, say so instead of failing somewhere inside the backward.  Decided once per trainer, logged to stderr."""
+        base = self.transformer.get_base_model() if hasattr(self.transformer, "get_base_model") else self.transformer
+        if not hasattr(base, "enable_lean_activations") or getattr(base, "gradient_checkpointing", False):
+            return None
+        total = torch.cuda.get_device_properties(device).total_memory
+        layers, D = len(base.transformer_blocks), base.config.num_attention_heads * base.config.attention_head_dim
+        est = {lean: n_seq * tokens * layers * b * D / 3072 + 40e9 for lean, b in self.SAVED_BYTES_PER_TOKEN_BLOCK.items()}
+        lean = est[False] > 0.80 * total
+        base.enable_lean_activations(lean)
+        self.memory_policy_log = {"lean_activations": lean, "sequences": n_seq, "tokens": tokens, "layers": layers, "estimate_full_gb": est[False] / 1e9,
+                                  "estimate_lean_gb": est[True] / 1e9, "device_gb": total / 1e9}
+        import sys
+        print(f"videogpa_amd: lean_activations=auto -> {lean} ({n_seq} sequences x {tokens} tokens x {layers} blocks: full {est[False] / 1e9:.0f} GB, "
+              f"lean {est[True] / 1e9:.0f} GB, device {total / 1e9:.0f} GB)" +
+              ("" if est[True] <= 0.92 * total else "; even lean is unlikely to fit: enable_gradient_checkpointing with a stride"), file=sys.stderr, flush=True)
+        return lean
+
     def shared_step_paired(self, x_pair, prompt_emb, timesteps=None, noise=None, cond_pair=None) -> LossOutput:
         """x_pair [B,2,F,C,H,W] bf16 (win, lose); prompt_emb [B,L,4096]; optional fixed (timesteps, noise) for parity
         tests; cond_pair [B,2,F,Cc,H,W]: extra conditioning channels concatenated after noising (I2V, :135-136)."""
         B = x_pair.shape[0]
         dev = x_pair.device
+        if self.config.get("lean_activations") == "auto" and self.memory_policy_log is None and x_pair.is_cuda and torch.is_grad_enabled():
+            c = self._base_config()
+            pt = c.patch_size_t or 1
+            self.memory_policy(2 * B, prompt_emb.shape[1] + (x_pair.shape[2] // pt) * (x_pair.shape[4] // c.patch_size) * (x_pair.shape[5] // c.patch_size), dev)
         if timesteps is None:
             timesteps = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=dev, generator=self.rng(dev))
         if noise is None:

@@ -181,6 +181,7 @@ class AttentionCore:
         self.qk_eps = qk_eps if qk_eps is not None else getattr(mod.norm_q, "eps", 1e-6)
         self._fused = None
         self._qkv_ext = self._out_ext = None
+        self.precise_delta = ops.precise_delta_default()     # "int8" | "bf16" | None: what the forward keeps of its output for the backward's delta (ops "Precise delta")
 
     def fused_qkv(self):
         """[3D, D] weight / [3D] bias, cached while the three base weights are unchanged (frozen base)."""
@@ -229,7 +230,8 @@ class AttentionCore:
         else:
             qkv = ops.frozen_linear(n, W, b)
         a = ops.qknorm_attention(qkv, _f32(m.norm_q.weight), _f32(m.norm_q.bias), _f32(m.norm_k.weight), _f32(m.norm_k.bias),
-                                 m.heads, text_len, rope, self.qk_eps, o_pad=out_pad, grad_pad=in_pad, recompute_qk=lean_src is not None)
+                                 m.heads, text_len, rope, self.qk_eps, o_pad=out_pad, grad_pad=in_pad, recompute_qk=lean_src is not None,
+                                 precise_delta=self.precise_delta)
         wo, bo, _ = _parts(m.to_out[0])
         if out_pad:
             if self._out_ext is None:
@@ -339,8 +341,17 @@ class CogVideoXTransformer3DModel(nn.Module):
         """Keep less per block for the backward: the LN output n1 (LoRA dA needs it) and the normalised q / k are made again from tensors that
         are saved anyway (the residual stream, the fused projection output) -- 23 % fewer saved bytes for two more row-kernel passes per block
         (+0.3 % of a step).  What it buys: CogVideoX1.5 at S = 41 026 keeps ALL 42 blocks resident in 288 GB instead of recomputing every
-        fourth block (bench.py --config cfg4).  Results are bit-identical either way."""
+        fourth block (bench.py --config cfg4).  Results are bit-identical either way (the output's res8 bytes for the backward's delta are kept in
+        both modes)."""
         self.lean_activations = bool(enabled)
+
+    def set_precise_delta(self, mode="int8"):
+        """what every attention of THIS model keeps of its output beyond the bf16 rounding for the backward's delta: "int8" (default: one byte per
+        element), "bf16" (the residual as a bf16 tensor) or None (the textbook flash-attention backward) -- ops.py "Precise delta" has the why"""
+        if mode not in (None, "int8", "bf16"):
+            raise ValueError(f'precise_delta: "int8", "bf16" or None, got {mode!r}')
+        for blk in self.transformer_blocks:
+            blk.attn1.core.precise_delta = mode
 
     # ------------------------------------------------------------------ diffusers-style protocol
     @property
@@ -403,7 +414,6 @@ class CogVideoXTransformer3DModel(nn.Module):
         if not hidden_states.is_cuda:
             raise RuntimeError("videogpa_amd.CogVideoXTransformer3DModel runs on MI355X only (no CPU fallback)")
         B, Fr, C, H, W = hidden_states.shape
-        ops.set_gemm_rows_per_call(0)       # one vendor-GEMM call per projection at these shapes (splitting by sample measured neutral to slower: ops.GEMM_SPLIT_M)
         p = cfg.patch_size
         dt = self.dtype
         if dt != torch.bfloat16:

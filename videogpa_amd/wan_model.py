@@ -249,7 +249,7 @@ class _SelfAttnFn(torch.autograd.Function):
     the output projection's forward resp. the q/k/v projection's backward operand (ops.LoraExt)."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, wk, cos, sin, H, eps, o_pad, grad_pad, f8=False):
+    def forward(ctx, qkv, wq, wk, cos, sin, H, eps, o_pad, grad_pad, f8=False, precise_delta=None):
         B, L, W = qkv.shape
         D = W // 3
         hd = D // H
@@ -262,14 +262,16 @@ class _SelfAttnFn(torch.autograd.Function):
         _rms_rope_fwd_raw(q2[:, D:2 * D], ld, wk, cos, sin, L, hd, eps, kn, D, rk)
         heads = lambda t: t.unflatten(-1, (H, hd)).permute(0, 2, 1, 3)
         v = heads(q2.view(B, L, W)[:, :, 2 * D:])
-        o, lse = ops.attention128_fwd_raw(heads(qn), heads(kn), v, hd ** -0.5, o_pad, f8=f8)      # f8: e4m3 matrix operands (enable_fp8(attention=True))
-        ctx.save_for_backward(q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin)
+        # eight further mantissa bits of the output for the backward's delta (ops.py "Precise delta"), where a backward will run
+        o_res8 = torch.empty(B, L, D, dtype=torch.uint8, device=qkv.device) if precise_delta and ctx.needs_input_grad[0] else None
+        o, lse = ops.attention128_fwd_raw(heads(qn), heads(kn), v, hd ** -0.5, o_pad, f8=f8, o_res8=o_res8)      # f8: e4m3 matrix operands (enable_fp8(attention=True))
+        ctx.save_for_backward(q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin, o_res8)
         ctx.meta = (B, L, D, H, hd, grad_pad)
         return o.permute(0, 2, 1, 3).flatten(2)          # [B, L, D]: a view of the token-major storage
 
     @staticmethod
     def backward(ctx, do):
-        q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin = ctx.saved_tensors
+        q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin, o_res8 = ctx.saved_tensors
         B, L, D, H, hd, pad = ctx.meta
         W = 3 * D
         heads = lambda t: t.unflatten(-1, (H, hd)).permute(0, 2, 1, 3)
@@ -278,11 +280,11 @@ class _SelfAttnFn(torch.autograd.Function):
         dqn = torch.empty(B, L, D, dtype=torch.bfloat16, device=q2.device)
         dkn = torch.empty_like(dqn)
         v = heads(q2.view(B, L, W)[:, :, 2 * D:])
-        ops.attention128_bwd_raw(heads(qn), heads(kn), v, o, heads(do), lse, heads(dqn), heads(dkn), heads(dqkv[:, :, 2 * D:]), hd ** -0.5)
+        ops.attention128_bwd_raw(heads(qn), heads(kn), v, o, heads(do), lse, heads(dqn), heads(dkn), heads(dqkv[:, :, 2 * D:]), hd ** -0.5, o_res8=o_res8)
         d2 = dqkv.view(B * L, W)
         _rms_rope_bwd_raw(dqn, D, q2[:, :D], q2.stride(0), rq, wq, cos, sin, L, hd, d2[:, :D], d2.stride(0))
         _rms_rope_bwd_raw(dkn, D, q2[:, D:2 * D], q2.stride(0), rk, wk, cos, sin, L, hd, d2[:, D:2 * D], d2.stride(0))
-        return dqkv, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None
 
 
 class _FfnFp8Fn(torch.autograd.Function):
@@ -426,6 +428,7 @@ class WanSelfAttention(nn.Module):
         self._fused = None
         self._qkv_ext = None
         self.fp8_attn = False
+        self.precise_delta = "int8" if ops.precise_delta_default() else None     # ops.py "Precise delta"; WanModel.set_precise_delta changes it per model
 
     def _heads(self, t, B, S):
         return t.view(B, S, self.num_heads, self.head_dim).permute(0, 2, 1, 3)
@@ -476,7 +479,7 @@ class WanSelfAttention(nn.Module):
         else:
             qkv = ops.frozen_linear(x, W, b)
         o = _SelfAttnFn.apply(qkv.view(B, L, 3 * self.dim), self.norm_q.weight, self.norm_k.weight, rope[0] if rope else None, rope[1] if rope else None,
-                              self.num_heads, self.norm_q.eps, out_pad, in_pad, bool(self.fp8_attn))
+                              self.num_heads, self.norm_q.eps, out_pad, in_pad, bool(self.fp8_attn), self.precise_delta)
         return self.o(o.reshape(B * L, self.dim))
 
 
@@ -492,7 +495,7 @@ class WanCrossAttention(WanSelfAttention):
         q = self._norm(self.norm_q, self.q(x).view(B, L, self.dim), None, grad_pad=in_pad)
         k = self._norm(self.norm_k, self.k(context.reshape(B * T, self.dim)).view(B, T, self.dim), None)
         v = self.v(context.reshape(B * T, self.dim)).view(B, T, self.dim)
-        o = ops.attention128(self._heads(q, B, L), self._heads(k, B, T), self._heads(v, B, T), o_pad=out_pad)
+        o = ops.attention128(self._heads(q, B, L), self._heads(k, B, T), self._heads(v, B, T), o_pad=out_pad, precise_delta=self.precise_delta)
         return self.o(o.permute(0, 2, 1, 3).reshape(B * L, self.dim))
 
 
@@ -559,7 +562,7 @@ class WanModel(nn.Module):
     def __init__(self, model_type="ti2v", patch_size=(1, 2, 2), text_len=512, in_dim=48, dim=3072, ffn_dim=14336, freq_dim=256, text_dim=4096,
                  out_dim=48, num_heads=24, num_layers=30, window_size=(-1, -1), qk_norm=True, cross_attn_norm=True, eps=1e-6):
         super().__init__()
-        self.gemm_rows_per_sample = True      # batched samples go through the bf16 vendor GEMMs one sample per call (ops.GEMM_SPLIT_M)
+        self.gemm_rows_per_sample = True      # batched samples go through the bf16 vendor GEMMs one sample per call (ops.gemm_rows_per_call)
         assert model_type in ("t2v", "i2v", "ti2v", "s2v")
         self.model_type, self.patch_size, self.text_len, self.in_dim, self.dim, self.ffn_dim = model_type, tuple(patch_size), text_len, in_dim, dim, ffn_dim
         self.freq_dim, self.text_dim, self.out_dim, self.num_heads, self.num_layers, self.eps = freq_dim, text_dim, out_dim, num_heads, num_layers, eps
@@ -703,6 +706,14 @@ class WanModel(nn.Module):
             blk.fp8_ffn = enabled
             blk.self_attn.fp8_attn = bool(enabled if attention is None else attention)
 
+    def set_precise_delta(self, mode="int8"):
+        """what both attentions of every block of THIS model keep of their output beyond its bf16 rounding for the backward's delta: "int8" (default, one
+        byte per output element) or None (the textbook flash-attention backward) -- ops.py "Precise delta" has the why"""
+        if mode not in (None, "int8"):
+            raise ValueError(f'precise_delta: "int8" or None, got {mode!r}')
+        for blk in self.blocks:
+            blk.self_attn.precise_delta = blk.cross_attn.precise_delta = mode
+
     def _rope_tables(self, grid, device):
         key = (tuple(grid), str(device))
         if key not in self._rope:
@@ -719,7 +730,7 @@ class WanModel(nn.Module):
         L = f * h * w
         if seq_len != L:
             raise NotImplementedError(f"seq_len {seq_len} != token count {L}: padded sequences are not on the training path (03_train.py:176-179)")
-        ops.set_gemm_rows_per_call(L if B > 1 and self.gemm_rows_per_sample else 0)      # one vendor-GEMM call per sample: see ops.GEMM_SPLIT_M
+        rows_per_call = L if B > 1 and self.gemm_rows_per_sample else 0      # one vendor-GEMM call per sample (ops.gemm_rows_per_call has the measurement)
         dev = xb.device
         wdt = self.patch_embedding.weight.dtype
         # patch embedding: Conv3d with kernel = stride = patch  ==  one GEMM over the (c, pt, ph, pw) patch vectors
@@ -755,12 +766,16 @@ class WanModel(nn.Module):
         ctx = ctx.view(B, self.text_len, self.dim)
         rope = self._rope_tables((f, h, w), dev)
         xs = tok
+
+        def run_block(blk, *a):       # the setting is scoped to this forward; a checkpointed block's recomputation (autograd thread) re-enters it here
+            with ops.gemm_rows_per_call(rows_per_call):
+                return blk(*a)
         for i, blk in enumerate(self.blocks):
             if self.gradient_checkpointing and torch.is_grad_enabled() and i % self.checkpoint_stride == 0:
                 from torch.utils.checkpoint import checkpoint
-                xs = checkpoint(blk, xs, e0, gid, B, L, rope, ctx, use_reentrant=False)
+                xs = checkpoint(run_block, blk, xs, e0, gid, B, L, rope, ctx, use_reentrant=False)
             else:
-                xs = blk(xs, e0, gid, B, L, rope, ctx)
+                xs = run_block(blk, xs, e0, gid, B, L, rope, ctx)
         out = self.head(xs.float(), e, gid)                                                                             # [B*L, out_dim * prod(patch)]
         # unpatchify: [f, h, w, pt, ph, pw, c] -> [c, f pt, h ph, w pw]
         c = self.out_dim
