@@ -248,10 +248,13 @@ int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, f
  * with one power-of-two scale per (batch, head) and tensor, v transposed, by two prep kernels; both products run as v_mfma_scale_f32_32x32x64_f8f6f4
  * with the scales -- and a per-tile, per-row power of two for the softmax weights -- on the instruction's E8M0 operands; row sums and lse2 stay fp32.
  * Arguments and results as vgpa_attn128_fwd; the workspace (>= vgpa_attn128_fwd_f8_workspace_bytes, 256-byte aligned) is REQUIRED and is scratch.
- * Forward only: the backward (vgpa_attn128_bwd) runs on the bf16 operands with this call's lse2. */
+ * Forward only.  q_deq / k_deq / v_deq (optional, all three or none; bf16 [B,H,S,128] views with their stride triples): the operands the products really ran
+ * on, dequantised (q8 2^eq / c rounded to bf16; k8 2^ek and v8 2^ev exactly).  vgpa_attn128_bwd run on THEM with this call's lse2, output and o_res8 is the
+ * straight-through gradient of this forward: its recomputed softmax weights are this call's (rows sum to one) and delta = rowsum(dO o O) matches them. */
 size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int64_t Sq, int64_t Skv);
 int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
-                            const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H,
+                            const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, void* q_deq, void* k_deq,
+                            void* v_deq, const int64_t* qd_strides, const int64_t* kd_strides, const int64_t* vd_strides, int64_t B, int64_t H,
                             int64_t Sq, int64_t Skv, float scale, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* workspace (vgpa_attn128_bwd_workspace_bytes): delta + the statistics planes.  dkv_mode -1 = automatic (w1 dK/dV kernel from 1024 queries on),
  * 0 = compiler-scheduled kernel, 1 = w1 kernel */

@@ -175,6 +175,51 @@ def test_attention128_e4m3_forward_vs_fp64(B, H, Sq, Skv, qmul, vmean):
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
 
 
+def test_attention128_e4m3_forward_hands_its_backward_the_operands_it_used():
+    """the backward of the e4m3 forward is the straight-through gradient of THAT forward.  vgpa_attn128_fwd_f8 also writes the operands its
+    products ran on, dequantised to bf16 (deq); the bf16 backward kernels run on them.  (i) k_deq / v_deq equal the oracle's e4m3 operands bit for bit, q_deq
+    = bf16(q8 / c) to one bf16 ulp (oracle/wan.py f8_operands: the same power-of-two scales, round to nearest even); (ii) softmax weights recomputed from
+    (q_deq, k_deq) against the forward's lse2 sum to one within 8e-3 per row (the bf16 rounding of q8 / c tilts a row's scores by ~1e-3 along the keys' common
+    component; measured 1e-3 typical, 5e-3 worst of 7 800 rows) -- from the bf16 q, k they miss by several percent; (iii) dq / dk / dv of
+    vgpa_attn128_bwd on the dequantised operands follow the fp64 model of forward + backward (oracle/wan.py::_F8Attn): cosine >= 0.999, norm within 2 %."""
+    from oracle import wan as ow
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(91)
+    B, H, S = 2, 3, 1300
+    tm = lambda t: t.bfloat16().permute(0, 2, 1, 3)
+    q = tm(torch.randn(B, S, H, 128, device="cuda", generator=g) + 0.3)
+    k = tm(torch.randn(B, S, H, 128, device="cuda", generator=g) + 0.5)
+    v = tm(torch.randn(B, S, H, 128, device="cuda", generator=g) + 1.0)
+    do = tm(torch.randn(B, S, H, 128, device="cuda", generator=g))
+    scale = 128 ** -0.5
+    deq = tuple(torch.full((B, S, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    o_res8 = torch.empty(B, S, H * 128, dtype=torch.uint8, device="cuda")
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=True, o_res8=o_res8, deq=deq)
+    o_plain, lse_plain = ops.attention128_fwd_raw(q, k, v, scale, f8=True)
+    assert torch.equal(o, o_plain) and torch.equal(lse, lse_plain)                    # the extra outputs change nothing else
+    qd, kd, vd = (t.unflatten(-1, (H, 128)).permute(0, 2, 1, 3) for t in deq)
+    q8, k8, v8, c = ow.f8_operands(q.double(), k.double(), v.double())
+    assert torch.equal(kd.double(), k8) and torch.equal(vd.double(), v8)
+    want_q = (q8 / c).bfloat16().double()
+    assert ((qd.double() - want_q).abs() <= 2.0 ** -7 * want_q.abs() + 1e-30).all() and (qd.double() != want_q).double().mean().item() < 0.01
+    LOG2E = 1.4426950408889634
+    rows_deq = torch.exp2((qd.double() @ kd.double().transpose(-1, -2)) * (scale * LOG2E) - lse.double()[..., None]).sum(-1)
+    rows_bf16 = torch.exp2((q.double() @ k.double().transpose(-1, -2)) * (scale * LOG2E) - lse.double()[..., None]).sum(-1)
+    assert (rows_deq - 1).abs().max().item() <= 8e-3 and (rows_deq - 1).abs().mean().item() <= 1.5e-3, ((rows_deq - 1).abs().max().item(), (rows_deq - 1).abs().mean().item())
+    assert (rows_bf16 - 1).abs().max().item() > 5 * (rows_deq - 1).abs().max().item()
+    dq, dk, dv = (torch.empty(B, S, H, 128, dtype=torch.bfloat16, device="cuda").permute(0, 2, 1, 3) for _ in range(3))
+    ops.attention128_bwd_raw(qd, kd, vd, o, do, lse, dq, dk, dv, scale, o_res8=o_res8)
+    qr, kr, vr = (t.double().detach().requires_grad_(True) for t in (q, k, v))
+    ow._F8Attn.apply(qr, kr, vr, True, True).backward(do.double())
+    worst = {}
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        a, r = got.double().flatten(), ref.flatten()
+        cos, nrm = float(a @ r / (a.norm() * r.norm())), abs(float(a.norm() / r.norm()) - 1)
+        worst[name] = (round(cos, 6), round(nrm, 5))
+        assert cos >= 0.999 and nrm <= 0.02, (name, cos, nrm)
+    print({"e4m3 forward + backward on its dequantised operands vs the fp64 model": worst, "row sum error deq / bf16": ((rows_deq - 1).abs().max().item(), (rows_bf16 - 1).abs().max().item())})
+
+
 def test_attention128_e4m3_outlier_rows_and_short_sweeps():
     """a 40x query row (bound above 160 -> strip flagged, redone in bf16), a 40x key row (every bound loose), and a 512-key sweep (below
     ATTN128_F8_MIN_KEYS: the bf16 kernels serve it -- the Wan2.2 cross-attention over the text tokens)"""
@@ -464,7 +509,7 @@ def test_wan_self_attention_core_on_the_fused_qkv_buffer():
     do = torch.randn(B, L, D, device="cuda", generator=g).bfloat16()
     cos, sin = rope_tables(grid, d, "cuda")
     a = qkv.clone().requires_grad_(True)
-    oa = _SelfAttnFn.apply(a, wq, wk, cos, sin, H, 1e-6, 16, 48)
+    oa = _SelfAttnFn.apply(a, wq, wk, cos, sin, H, 1e-6, 16, 48, False, "int8")      # the same "Precise delta" mode as attention128's default below
     assert ops._padded_base(oa.reshape(B * L, D), D + 16) is not None
     oa.backward(do)
     assert ops._padded_base(a.grad.reshape(B * L, 3 * D), 3 * D + 48) is not None or a.grad.shape == (B, L, 3 * D)

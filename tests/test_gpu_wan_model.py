@@ -54,7 +54,7 @@ def _inputs(B=2, seed=5):
     return x, t, ctx, L, gout
 
 
-def _oracle(state, lora, x, t, ctx, L, gout, enabled=True, fp8_ffn=False):
+def _oracle(state, lora, x, t, ctx, L, gout, enabled=True, fp8_ffn=False, **kw):
     from oracle import wan as ow
     ldict, leaves = {}, {}
     if enabled:
@@ -63,7 +63,7 @@ def _oracle(state, lora, x, t, ctx, L, gout, enabled=True, fp8_ffn=False):
             Bm = mod.lora_B["default"].weight.detach().double().requires_grad_(True)
             ldict[name] = (A, Bm, mod.scaling["default"])
             leaves[name] = (A, Bm)
-    P = ow.Params(state, ldict, dtype=torch.float64, fp8_ffn=fp8_ffn)
+    P = ow.Params(state, ldict, dtype=torch.float64, fp8_ffn=fp8_ffn, **kw)
     out = ow.forward(P, CFG, [u.double() for u in x], t.double(), [c.double() for c in ctx], L)
     if enabled:
         sum((o * g.double()).sum() for o, g in zip(out, gout)).backward()
@@ -171,11 +171,15 @@ def test_wan_model_fp8_feed_forward_stays_close_to_the_oracle():
 
 def test_wan_model_e4m3_self_attention_stays_close_to_the_oracle():
     """enable_fp8(False, attention=True): the self-attention FORWARD on e4m3 operands (csrc/attention_hd128.hip attn128_fwd_f8_kernel) in a model long
-    enough for it (1152 tokens >= ops.ATTN128_F8_MIN_KEYS; the 32-key cross-attention stays bf16), backward on bf16 operands with the e4m3 forward's
-    lse2.  Against the fp64 oracle: outputs cosine >= 0.995 / 6 % of range, every LoRA gradient (lora_A and lora_B, both attentions) cosine >= 0.98 /
-    12 % of range -- e4m3 scores carry ~0.05 of noise each (tests/test_gpu_wan_kernels.py::test_attention128_e4m3_forward_vs_fp64), which the bf16
-    path does not have (its bounds in this file: 0.995 / 4-6 %).  The policy and the adapter-off reference pass use the same kernel, so at B = 0 they
-    agree bit for bit (loss = ln 2: tests/test_gpu_fullmodel.py at full size)."""
+    enough for it (1152 tokens >= ops.ATTN128_F8_MIN_KEYS; the 32-key cross-attention stays bf16), backward = the bf16 kernels on the forward's own
+    dequantised operands (the straight-through gradient of the e4m3 forward).  Two oracles, as for the feed-forward:
+    (a) the fp64 oracle with the attention's roundings INJECTED (oracle/wan.py::_F8Attn inside the activation-rounded mode: e4m3 q c / k / v with one power
+        of two per head, per-tile-and-row scaled e4m3 softmax weights, unquantised row sums; backward on the dequantised operands): the same arithmetic type
+        at the same places, so the bounds are those of the bf16 test of this file -- outputs and EVERY LoRA gradient cosine >= 0.995, max error within 4 % /
+        6 % of the tensor's range;
+    (b) the plain fp64 oracle, as context for what e4m3 itself costs: outputs cosine >= 0.995 / 6 % of range, gradients cosine >= 0.98 / 12 % of range --
+        e4m3 scores carry ~0.05 of noise each (tests/test_gpu_wan_kernels.py::test_attention128_e4m3_forward_vs_fp64).
+    The policy and the adapter-off reference pass use the same kernel, so at B = 0 they agree bit for bit (loss = ln 2: tests/test_gpu_fullmodel.py)."""
     from videogpa_amd import ops
     pm, state, lora = _build()
     base = pm.get_base_model()
@@ -204,12 +208,15 @@ def test_wan_model_e4m3_self_attention_stays_close_to_the_oracle():
     assert (L, True) in seen and all(f8 == (n == L) for n, f8 in seen)          # self-attention e4m3, cross-attention (32 keys) bf16
     sum((o * g_).sum() for o, g_ in zip(out, gout)).backward()
     ref, leaves = _oracle(state, lora, x, t, ctx, L, gout)
+    ref8, leaves8 = _oracle(state, lora, x, t, ctx, L, gout, round_activations=True, exact_delta=True, f8_attn=True)
     worst = {"out_cos": 1.0, "grad_cos": 1.0}
     for b in range(2):
+        _close(out[b], ref8[b], f"out[{b}] vs e4m3-injected oracle")
         _close(out[b], ref[b], f"out[{b}]", tol=0.06, cos_min=0.995)
     for name, mod in lora.items():
         for which, idx in (("A", 0), ("B", 1)):
             got = (mod.lora_A if idx == 0 else mod.lora_B)["default"].weight.grad
+            _close(got, leaves8[name][idx].grad, f"{name}.{which} vs e4m3-injected oracle", tol=0.06)
             _close(got, leaves[name][idx].grad, f"{name}.{which}", tol=0.12, cos_min=0.98)
             a, r = got.double().flatten().cpu(), leaves[name][idx].grad.double().flatten().cpu()
             worst["grad_cos"] = min(worst["grad_cos"], float(a @ r / (a.norm() * r.norm())))

@@ -30,7 +30,7 @@ wsf8 = torch.empty(_lib.query("vgpa_attn128_fwd_f8_workspace_bytes", B, H, S, S)
 
 
 def fwd_f8():
-    _lib.call("vgpa_attn128_fwd_f8", q, k, v, o, lse, st(q), st(k), st(v), st(o), None, None, B, H, S, S, scale, wsf8, wsf8.numel(), stream)
+    _lib.call("vgpa_attn128_fwd_f8", q, k, v, o, lse, st(q), st(k), st(v), st(o), None, None, None, None, None, None, None, None, B, H, S, S, scale, wsf8, wsf8.numel(), stream)
 
 
 def bwd(mode):

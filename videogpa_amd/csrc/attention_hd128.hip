@@ -994,7 +994,8 @@ __global__ __launch_bounds__(256) void attn128_f8_amax_kernel(const bf16_t* __re
 __global__ __launch_bounds__(256) void attn128_f8_quant_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, TStride sq,
                                                                  TStride sk, TStride sv, int Sq, int Skv, int Lp, int H, float c, const unsigned* __restrict__ stats,
                                                                  uint8_t* __restrict__ q8, uint8_t* __restrict__ k8, uint8_t* __restrict__ v8t,
-                                                                 float* __restrict__ qn2, unsigned* __restrict__ kmax2) {
+                                                                 float* __restrict__ qn2, unsigned* __restrict__ kmax2, bf16_t* __restrict__ QD,
+                                                                 bf16_t* __restrict__ KD, bf16_t* __restrict__ VD, TStride sqd, TStride skd, TStride svd) {
     __shared__ __attribute__((aligned(16))) uint32_t vt[32 * 66];
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     const int tl = (int)threadIdx.x >> 2, tok = blockIdx.x * 64 + tl, d0 = 32 * ((int)threadIdx.x & 3);
@@ -1021,6 +1022,27 @@ __global__ __launch_bounds__(256) void attn128_f8_quant_kernel(const bf16_t* __r
             unpack8(raw[which][g], f);
             w[2 * g] = f8_pack4(f[0] * mul, f[1] * mul, f[2] * mul, f[3] * mul);
             w[2 * g + 1] = f8_pack4(f[4] * mul, f[5] * mul, f[6] * mul, f[7] * mul);
+        }
+        // the operands the matrix pipe will multiply, DEquantised to bf16 for the backward (vgpa_attn128_fwd_f8, q_deq / k_deq / v_deq): k8 2^ek and
+        // v8 2^ev exactly (an e4m3 value times a power of two is a bf16 number), q8 2^eq / c rounded to bf16
+        bf16_t* dq_base = which == 0 ? QD : which == 1 ? KD : VD;
+        if (dq_base && tok < S) {
+            const TStride sd = which == 0 ? sqd : which == 1 ? skd : svd;
+            const float inv = which == 0 ? ldexpf(1.f / c, eq) : ldexpf(1.f, which == 1 ? ek : ev);
+            bf16_t* dst = dq_base + ((size_t)b * sd.b + (size_t)h * sd.h + (size_t)tok * sd.s + (size_t)d0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int x = (int)w[2 * g + i];
+                    f[4 * i] = __builtin_amdgcn_cvt_f32_fp8(x, 0) * inv;
+                    f[4 * i + 1] = __builtin_amdgcn_cvt_f32_fp8(x, 1) * inv;
+                    f[4 * i + 2] = __builtin_amdgcn_cvt_f32_fp8(x, 2) * inv;
+                    f[4 * i + 3] = __builtin_amdgcn_cvt_f32_fp8(x, 3) * inv;
+                }
+                *reinterpret_cast<u32x4_t*>(dst + 8 * g) = pack8(f);
+            }
         }
         if (which < 2) {
             float n2 = 0.f;
@@ -1203,10 +1225,20 @@ extern "C" size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int6
 }
 // softmax(scale q k^T) v with e4m3 matrix operands (forward only: same arguments and results as vgpa_attn128_fwd; the workspace holds the quantised
 // copies and is scratch).  Strips the kernel flags (row sum near underflow, bound too large) are redone by the bf16 running-max kernel.
+// q_deq / k_deq / v_deq (optional, all or none): bf16 copies of the operands the products really ran on -- hand THEM to vgpa_attn128_bwd in place of q, k, v
+// and its recomputed P = exp2(c q k^T - lse2) is this forward's p / l (rows sum to one), dP is formed from the v the forward used and delta = rowsum(dO o O)
+// matches both: the backward is then the straight-through gradient of THIS forward instead of the gradient of a neighbouring bf16 one.
 extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
-                                       const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H,
+                                       const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, void* q_deq, void* k_deq,
+                                       void* v_deq, const int64_t* qd_strides, const int64_t* kd_strides, const int64_t* vd_strides, int64_t B, int64_t H,
                                        int64_t Sq, int64_t Skv, float scale, void* workspace, size_t ws_bytes, hipStream_t stream) {
     if (!q || !k || !v || !o || !lse2 || !workspace || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || !res8_ok(o_res8, ores_strides, B, H, Sq)) return VGPA_ERR_INVALID;
+    // the dequantised operands are all there or all absent; each a bf16 [B, H, S, 128] view like its source
+    const bool deq = q_deq || k_deq || v_deq;
+    if (deq && (!q_deq || !k_deq || !v_deq || !qd_strides || !kd_strides || !vd_strides || !sok128(qd_strides) || !sok128(kd_strides) || !sok128(vd_strides) ||
+                !a16(q_deq) || !a16(k_deq) || !a16(v_deq) || !rok128(qd_strides, B, H, Sq) || !rok128(kd_strides, B, H, Skv) || !rok128(vd_strides, B, H, Skv)))
+        return VGPA_ERR_INVALID;
+    const TStride sqd = deq ? mk128(qd_strides) : TStride{0, 0, 0}, skd = deq ? mk128(kd_strides) : TStride{0, 0, 0}, svd = deq ? mk128(vd_strides) : TStride{0, 0, 0};
     uint8_t* ores = (uint8_t*)o_res8;
     const TStride sor = o_res8 ? mk128(ores_strides) : TStride{0, 0, 0};
     if (!sok128(q_strides) || !sok128(k_strides) || !sok128(v_strides) || !sok128(o_strides) || !a16(q) || !a16(k) || !a16(v) || !a16(o)) return VGPA_ERR_INVALID;
@@ -1229,7 +1261,8 @@ extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void*
                 mk128(k_strides), mk128(v_strides), (int)Sq, (int)Skv, (int)H, stats);
     const int64_t nblk = (Sq > Lp ? (Sq + 63) / 64 : Lp / 64);
     VGPA_LAUNCH(attn128_f8_quant_kernel, dim3((unsigned)nblk, (unsigned)(B * H)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                mk128(q_strides), mk128(k_strides), mk128(v_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, c, (const unsigned*)stats, q8, k8, v8t, qn2, kmax2);
+                mk128(q_strides), mk128(k_strides), mk128(v_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, c, (const unsigned*)stats, q8, k8, v8t, qn2, kmax2,
+                (bf16_t*)q_deq, (bf16_t*)k_deq, (bf16_t*)v_deq, sqd, skd, svd);
     VGPA_LAUNCH(attn128_fwd_f8_kernel, dim3((unsigned)tasks256), dim3(256), 0, stream, (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)v8t, (const float*)qn2,
                 (const unsigned*)kmax2, (const unsigned*)stats, (bf16_t*)o, lse2, flags, mk128(o_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, (int)n_q256, c, ores, sor);
     VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,

@@ -1012,9 +1012,16 @@ ATTN128_W1 = _os.environ.get("VGPA_ATTN128_W1", "1") == "1"    # 0: the compiler
 ATTN128_F8_MIN_KEYS = 1024      # below this the e4m3 forward's prep passes and pipeline fill do not pay (cross-attention over 512 text tokens stays bf16)
 
 
-def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None):
+def attention128_uses_f8(f8, Skv):
+    """does attention128_fwd_raw(f8=f8) run the e4m3 kernel for a sweep of Skv keys?"""
+    return bool(f8) and Skv >= ATTN128_F8_MIN_KEYS
+
+
+def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None, deq=None):
     """q [B,H,Sq,128], k / v [B,H,Skv,128] bf16 views (any batch / head / token strides, last dim contiguous) -> (o, lse2 [B,H,Sq] fp32).
     f8: the e4m3 forward (csrc/attention_hd128.hip, vgpa_attn128_fwd_f8) for sweeps of at least ATTN128_F8_MIN_KEYS keys.
+    deq (e4m3 forward only): three bf16 buffers [B, Sq, H*128], [B, Skv, H*128], [B, Skv, H*128] that receive the operands the e4m3 products really ran
+    on, dequantised -- what the backward of THIS forward runs on (attention128_bwd_raw on them recomputes the forward's own softmax weights).
     o_res8: optional uint8 [B, Sq, H*128] buffer that receives eight further mantissa bits of every output value ("Precise delta").
     o is a [B,H,Sq,128] view of token-major storage [B, Sq, H*128 (+ o_pad)]: the caller's flatten to [B*Sq, H*128] is free, and with
     o_pad it is the head of a `_padded_empty` buffer (the output projection's LoRA tail, see LoraExt)."""
@@ -1030,13 +1037,22 @@ def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None):
             raise TypeError("attention128_fwd_raw: o_res8 is a contiguous uint8 [B, Sq, H*128] buffer")
         rv = o_res8.unflatten(-1, (H, D)).permute(0, 2, 1, 3)
         rs = _bhs_strides(rv)
-    if f8 and Skv >= ATTN128_F8_MIN_KEYS:
+    if attention128_uses_f8(f8, Skv):
         ws_bytes = _lib.query("vgpa_attn128_fwd_f8_workspace_bytes", B, H, Sq, Skv)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        dv_ = [None] * 3
+        if deq is not None:
+            for t, S_ in zip(deq, (Sq, Skv, Skv)):
+                if t.dtype != torch.bfloat16 or t.shape != (B, S_, H * D) or not t.is_contiguous():
+                    raise TypeError("attention128_fwd_raw: deq = three contiguous bf16 [B, S, H*128] buffers (q, k, v)")
+            dv_ = [t.unflatten(-1, (H, D)).permute(0, 2, 1, 3) for t in deq]
+        ds_ = [None if t is None else _bhs_strides(t) for t in dv_]
         _timed("attn128_fwd_f8", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-            "vgpa_attn128_fwd_f8", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), rv, rs, B, H, Sq, Skv, float(scale),
-            ws, ws_bytes, _stream()))
+            "vgpa_attn128_fwd_f8", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), rv, rs, dv_[0], dv_[1], dv_[2],
+            ds_[0], ds_[1], ds_[2], B, H, Sq, Skv, float(scale), ws, ws_bytes, _stream()))
         return o, lse
+    if deq is not None:
+        raise ValueError("attention128_fwd_raw: deq buffers are written by the e4m3 forward only (f8=True and at least ATTN128_F8_MIN_KEYS keys)")
     ws_bytes = _lib.query("vgpa_attn128_fwd_workspace_bytes", B, H, Sq) if ATTN128_W1 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
     _timed("attn128_fwd" if Skv >= 1024 else "attn128_fwd (short keys)", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(

@@ -264,14 +264,23 @@ class _SelfAttnFn(torch.autograd.Function):
         v = heads(q2.view(B, L, W)[:, :, 2 * D:])
         # eight further mantissa bits of the output for the backward's delta (ops.py "Precise delta"), where a backward will run
         o_res8 = torch.empty(B, L, D, dtype=torch.uint8, device=qkv.device) if precise_delta and ctx.needs_input_grad[0] else None
-        o, lse = ops.attention128_fwd_raw(heads(qn), heads(kn), v, hd ** -0.5, o_pad, f8=f8, o_res8=o_res8)      # f8: e4m3 matrix operands (enable_fp8(attention=True))
-        ctx.save_for_backward(q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin, o_res8)
+        # e4m3 forward with a backward to come: the backward runs on the operands the forward's products really used (dequantised to bf16 by the forward's
+        # own quantisation pass), so that its recomputed softmax weights ARE the forward's and delta = rowsum(dO o O) matches them -- the straight-through
+        # gradient of this forward.  They replace the normalised q / k among the saved tensors; the dequantised v is the one tensor this adds.
+        deq = None
+        if ops.attention128_uses_f8(f8, L) and ctx.needs_input_grad[0]:
+            deq = tuple(torch.empty(B, L, D, dtype=torch.bfloat16, device=qkv.device) for _ in range(3))
+        o, lse = ops.attention128_fwd_raw(heads(qn), heads(kn), v, hd ** -0.5, o_pad, f8=f8, o_res8=o_res8, deq=deq)      # f8: e4m3 matrix operands (enable_fp8(attention=True))
+        if deq is None:
+            ctx.save_for_backward(q2, qn, kn, None, o, lse, rq, rk, wq, wk, cos, sin, o_res8)
+        else:
+            ctx.save_for_backward(q2, deq[0], deq[1], deq[2], o, lse, rq, rk, wq, wk, cos, sin, o_res8)
         ctx.meta = (B, L, D, H, hd, grad_pad)
         return o.permute(0, 2, 1, 3).flatten(2)          # [B, L, D]: a view of the token-major storage
 
     @staticmethod
     def backward(ctx, do):
-        q2, qn, kn, o, lse, rq, rk, wq, wk, cos, sin, o_res8 = ctx.saved_tensors
+        q2, qn, kn, vd, o, lse, rq, rk, wq, wk, cos, sin, o_res8 = ctx.saved_tensors      # (qn, kn, vd): the e4m3 forward's dequantised operands when it ran
         B, L, D, H, hd, pad = ctx.meta
         W = 3 * D
         heads = lambda t: t.unflatten(-1, (H, hd)).permute(0, 2, 1, 3)
@@ -279,7 +288,7 @@ class _SelfAttnFn(torch.autograd.Function):
         dqkv = ops._padded_empty((B, L), W, pad, torch.bfloat16, q2.device) if pad else torch.empty(B, L, W, dtype=torch.bfloat16, device=q2.device)
         dqn = torch.empty(B, L, D, dtype=torch.bfloat16, device=q2.device)
         dkn = torch.empty_like(dqn)
-        v = heads(q2.view(B, L, W)[:, :, 2 * D:])
+        v = heads(q2.view(B, L, W)[:, :, 2 * D:]) if vd is None else heads(vd)
         ops.attention128_bwd_raw(heads(qn), heads(kn), v, o, heads(do), lse, heads(dqn), heads(dkn), heads(dqkv[:, :, 2 * D:]), hd ** -0.5, o_res8=o_res8)
         d2 = dqkv.view(B * L, W)
         _rms_rope_bwd_raw(dqn, D, q2[:, :D], q2.stride(0), rq, wq, cos, sin, L, hd, d2[:, :D], d2.stride(0))
@@ -700,7 +709,9 @@ class WanModel(nn.Module):
         per-row dynamic activation scales (csrc/fp8.hip), per-output-row weight scales, fp32 accumulation, bf16 out, forward and dX (the vendor's fp8 GEMM).
         (ii) attention (default: as `enabled`): the self-attention FORWARD -- reference pass and policy pass alike, so the Diffusion-DPO identity loss = ln 2
         at B = 0 stays exact -- runs the hand-written e4m3 kernel (csrc/attention_hd128.hip attn128_fwd_f8_kernel: both products as
-        v_mfma_scale_f32_32x32x64_f8f6f4, power-of-two scales on the instruction's E8M0 operands); its backward and the 512-key cross-attention stay bf16.
+        v_mfma_scale_f32_32x32x64_f8f6f4, power-of-two scales on the instruction's E8M0 operands); its backward runs the bf16 kernels on the forward's own operands, dequantised
+        (_SelfAttnFn: the straight-through gradient of the e4m3 forward -- softmax rows that sum to one, delta consistent with them); the 512-key
+        cross-attention stays bf16.
         The LoRA-carrying q/k/v/o projections stay in bf16."""
         for blk in self.blocks:
             blk.fp8_ffn = enabled
