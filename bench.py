@@ -195,7 +195,10 @@ def _pick_cpu_threads():
     """torch's CPU kernels do not scale to every hardware thread of a big host (256 threads ran the oracle 7x slower than 16
     on the MI355X box): time a small matmul + attention probe at a few thread counts and keep the fastest."""
     import torch.nn.functional as F
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))          # the CPU leg may have been fenced off from the cores of the secondary-config children
+    except AttributeError:
+        cores = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
     x, W = torch.randn(2048, 3072, generator=g), torch.randn(3072, 3072, generator=g)
     q = torch.randn(1, 16, 2048, 64, generator=g)
@@ -289,20 +292,64 @@ def add_kernel_report(out, ops, steps, ms, use_pmc=True):
         out["kernels"] = kernels
 
 
+def dist_report(engine, dt_local, steps, dev, world, force_dist):
+    """What a scaling loss would have to be attributed from (every rank calls this; rank 0 prints it): the ranks really in the group, each rank's own time
+    per step (min / max: a straggler shows here, not in the max-over-ranks headline), and the gradient exchange -- message size, which collective, its mean
+    duration on the communication stream and how long the compute stream actually stalled for it at the optimizer step (events, FlatAdamW.comm_report).
+    The reference's only parallelism is DDP (train/CogVideoX-5B/03_train.py:257-266), whose all-reduce this one message replaces."""
+    if not (world > 1 or force_dist):
+        return {}
+    t = torch.tensor([dt_local / steps * 1e3], dtype=torch.float64, device=dev)
+    per = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(per, t)
+    per = [float(x.item()) for x in per]
+    comm = engine.opt.comm_report()
+    if comm is not None:
+        # rank 0's view plus the slowest rank's exposed wait (the one that bounds the step)
+        w = torch.tensor([comm["exposed_wait_ms"], comm["allreduce_ms"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        comm["exposed_wait_ms_max_over_ranks"], comm["allreduce_ms_max_over_ranks"] = float(w[0].item()), float(w[1].item())
+        comm["note"] = ("one exchange per optimizer step, issued on a side stream after the last backward and waited for between the NEXT step's reference "
+                        "and policy passes (trainer.DPOEngine); allreduce_ms is measured from `gradients ready` to `collective done`")
+    return {"ranks_seen": dist.get_world_size(), "ms_per_step_min": min(per), "ms_per_step_max": max(per), "ms_per_step_by_rank": per, "comm": comm}
+
+
 OTHER_CONFIGS = ("cfg3", "cfg4", "cfg5")
 
 
-def run_other_configs(steps=3, warmup=1, timeout_s=420):
+CHILD_CPUS = 16      # host threads fenced off for the secondary-config child processes while the CPU leg is being timed
+
+
+def split_host_cpus():
+    """(cpus for the CPU leg, cpus for the child benches): the children get the CHILD_CPUS highest-numbered hardware threads this process may run on, the
+    CPU leg everything else -- the two overlap in TIME (so that the default run still ends within minutes) but never share a core.  On a host too small
+    to split (<= 2 x CHILD_CPUS threads) both get everything and the report says so."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None, None
+    if len(cpus) <= 2 * CHILD_CPUS:
+        return None, None
+    return cpus[:-CHILD_CPUS], cpus[-CHILD_CPUS:]
+
+
+def run_other_configs(steps=3, warmup=1, timeout_s=420, cpus=None):
     """The secondary BASELINE configurations as driver-witnessed numbers: each runs as its own `python bench.py --config cfgN` process (so the
     memory of one is gone before the next starts -- cfg4 needs 230 GB -- and a failure in one cannot touch the headline line), `steps` timed steps
-    after `warmup`, no CPU leg.  Returns {name: compact record}; a config that fails or times out is recorded as {"error": ...}."""
+    after `warmup`, no CPU leg.  cpus: the hardware threads the children are pinned to (and their OMP / MKL pools sized for), so that they cannot take
+    cores from the CPU leg timed meanwhile.  Returns {name: compact record}; a config that fails or times out is recorded as {"error": ...}."""
     res = {}
+    env = dict(os.environ)
+    pin = None
+    if cpus:
+        env.update(OMP_NUM_THREADS=str(len(cpus)), MKL_NUM_THREADS=str(len(cpus)))
+        pin = lambda: os.sched_setaffinity(0, cpus)          # noqa: E731 -- runs in the child between fork and exec
     for name in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
                "--no-other-configs"]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, preexec_fn=pin)
             line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
             if r.returncode != 0 or line is None:
                 res[name] = {"error": f"exit {r.returncode}", "stderr_tail": r.stderr[-400:]}
@@ -382,6 +429,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
     for _ in range(args.warmup):
         engine.micro_step(batch)
     engine.flush()
+    engine.opt.comm_report()          # drop the warm-up's exchange events: `comm` covers the timed steps only
     if rank == 0 and not args.no_kernel_timer:
         ops.TIMER = ops.KernelTimer(full_steps=TIMER_FULL_STEPS, always=TIMER_ALWAYS)
     barrier()
@@ -401,6 +449,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
     if world > 1 or force_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    drep = dist_report(engine, dt_local, args.steps, dev, world, force_dist)
     if rank == 0:
         named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8, args.no_fp8_attn) == (30, C["frames"], C["height"], C["width"], 64, False, False, False)
         ms = dt / args.steps * 1e3
@@ -422,6 +471,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
+        out.update(drep)
         add_kernel_report(out, ops, args.steps, ms, use_pmc=named)
         if not ckpt:
             out["energy"] = energy_report(e0, e1, dt_local, args.steps, F_step)
@@ -525,6 +575,7 @@ def main():
     for _ in range(args.warmup):
         engine.micro_step(batch)
     engine.flush()
+    engine.opt.comm_report()          # drop the warm-up's exchange events: `comm` covers the timed steps only
     if rank == 0 and not args.no_kernel_timer:
         ops.TIMER = ops.KernelTimer(full_steps=TIMER_FULL_STEPS, always=TIMER_ALWAYS)
     barrier()
@@ -544,6 +595,7 @@ def main():
     if world > 1 or force_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    drep = dist_report(engine, dt_local, args.steps, dev, world, force_dist)
 
     if rank == 0:
         named = (args.layers, F_, H_, W_, args.rank_r, ckpt, lean) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"], bool(C.get("lean", False)))
@@ -566,28 +618,38 @@ def main():
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
+        out.update(drep)
         add_kernel_report(out, ops, args.steps, ms, use_pmc=named and args.config in ("cfg2", "cfg3"))
         if not ckpt:      # with block recompute the executed count would also carry the recomputed forwards
             out["energy"] = energy_report(e0, e1, dt_local, args.steps, F_step, F_step + 6.0 * args.layers * 2 * cfg_kw["num_attention_heads"] * 64.0 * S * S)
         others = None
         if world == 1 and not force_dist and named and args.config == "cfg2" and not args.no_other_configs:
             # the secondary configurations run on the (now idle) GPU in child processes WHILE the host cores time the CPU leg: the timed region of the
-            # headline is over, this process's device memory is released first, and the children use one host thread each
+            # headline is over, this process's device memory is released first, and the two legs are fenced onto DISJOINT host cores (split_host_cpus):
+            # the children (each builds a 5 B-parameter model on the host before its timed steps) cannot slow the CPU baseline down
             import gc
             import threading
             del engine, trainer, model, batch, x_pair, prompt, logs
             gc.collect()
             torch.cuda.empty_cache()
             box = {}
-            others = threading.Thread(target=lambda: box.update(run_other_configs()), daemon=True)
+            leg_cpus, child_cpus = split_host_cpus()
+            others = threading.Thread(target=lambda: box.update(run_other_configs(cpus=child_cpus)), daemon=True)
             others.start()
+            if leg_cpus and not args.no_cpu_baseline:
+                os.sched_setaffinity(0, leg_cpus)          # this process is done with the GPU work that needed its launch threads
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_step)
+            if others is not None:
+                out["cpu_baseline"]["legs_overlapped"] = True
+                out["cpu_baseline"]["host_cpu_fence"] = ({"cpu_leg_threads_available": len(leg_cpus), "child_bench_threads": len(child_cpus)} if leg_cpus else
+                                                         "host too small to split: the CPU leg shared its cores with the secondary-config children")
         if others is not None:
             others.join()
             out["other_configs"] = box
             out["other_configs_note"] = ("cfg3 / cfg4 / cfg5 measured by this same invocation after the headline's timed region (3 timed steps each, "
-                                         "1 warm-up, own process per config, concurrently with the CPU leg); the headline fields above are cfg2 only")
+                                         "1 warm-up, own process per config, concurrently with the CPU leg but pinned to their own host cores); the "
+                                         "headline fields above are cfg2 only")
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -81,14 +81,14 @@ class _CpuStepAdamW(FlatAdamW):
         f.flat.addcdiv_(self.exp_avg / (1 - b1 ** k), denom, value=-lr)
 
 
-def _train_worker(rank, world, port, out_dir):
+def _train_worker(rank, world, port, out_dir, collective="all_reduce", tag="train"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     params = _make_params(seed=rank)
     flat = FlatParams(params)
     dist.broadcast(flat.flat, src=0)
-    opt = _CpuStepAdamW(flat, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=1, total_steps=10)
+    opt = _CpuStepAdamW(flat, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=1, total_steps=10, collective=collective)
     data = _data(8)
     synced = []
     for step in range(3):                                      # three optimizer steps, one pair per rank per step
@@ -100,7 +100,8 @@ def _train_worker(rank, world, port, out_dir):
         flat.tail[3:4].add_(1.0)
         opt.step(opt.all_reduce_grads())
         synced.append((flat.tail[:3] / flat.tail[3:4]).clone())
-    torch.save({"param": flat.flat.clone(), "synced": torch.stack(synced)}, os.path.join(out_dir, f"train{rank}.pt"))
+    torch.save({"param": flat.flat.clone(), "synced": torch.stack(synced), "slack": flat.storage[flat.buf.numel():].clone()},
+               os.path.join(out_dir, f"{tag}{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -297,3 +298,37 @@ def test_engine_never_steps_between_a_policy_forward_and_its_backward():
         assert (tr.after_reference is None) == (mode == "never")
     with pytest.raises(RuntimeError, match="after_reference"):
         _run_engine("stops", overlap=True)
+
+
+def test_reduce_scatter_all_gather_exchange_is_bit_identical_to_the_all_reduce(tmp_path):
+    """VGPA_DP_COLLECTIVE=rs_ag (reduce-scatter + all-gather of the flat [gradient | scalars] message, which on point-to-point xGMI uses every
+    link where a ring all-reduce is bound by one): three optimizer steps on two ranks end in the SAME bits as with the all-reduce -- parameters and the
+    rank-mean scalars -- on both ranks; the message length (odd here: 4-aligned tensors + 4 scalars) is padded to a multiple of the world size with slack
+    that stays zero."""
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), "all_reduce", "ar"), nprocs=world, join=True)
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), "rs_ag", "rs"), nprocs=world, join=True)
+    ar = [torch.load(tmp_path / f"ar{i}.pt") for i in range(world)]
+    rs = [torch.load(tmp_path / f"rs{i}.pt") for i in range(world)]
+    for i in range(world):
+        assert torch.equal(rs[i]["param"], ar[i]["param"]) and torch.equal(rs[i]["synced"], ar[i]["synced"])
+        assert rs[i]["slack"].abs().max().item() == 0.0
+    assert torch.equal(rs[0]["param"], rs[1]["param"])
+
+
+def test_exchange_message_is_padded_for_any_world_size():
+    flat = FlatParams(_make_params(0))
+    n = flat.buf.numel()
+    for w in (1, 2, 3, 7, 8, 64):
+        m = flat.message(w)
+        assert m.numel() % w == 0 and n <= m.numel() < n + w and m.data_ptr() == flat.buf.data_ptr()
+    try:
+        flat.message(65)
+        raise AssertionError("expected a ValueError")
+    except ValueError:
+        pass
+    try:
+        FlatAdamW(flat, collective="ring")
+        raise AssertionError("expected a ValueError")
+    except ValueError:
+        pass

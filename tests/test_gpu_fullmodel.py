@@ -134,9 +134,11 @@ def test_cfg4_full_depth_lean_step_is_ln2_at_b0():
 
 
 def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):
-    """DPOEngine with VGPA_FORCE_DIST=1 on one rank: the flat [gradients | scalars] SUM all-reduce really goes through RCCL (backend
-    "nccl" on ROCm) on the side stream, the optimizer step is applied overlapped (after the next micro-step's reference pass), and the
-    result equals the engine without any communicator bit for bit."""
+    """DPOEngine with VGPA_FORCE_DIST=1 on one rank: the flat [gradients | scalars] SUM exchange really goes through RCCL (backend
+    "nccl" on ROCm) on the side stream -- as ONE all-reduce and as reduce-scatter + all-gather (VGPA_DP_COLLECTIVE=rs_ag) -- the optimizer
+    step is applied overlapped (after the next micro-step's reference pass), and the result equals the engine without any communicator bit for bit.
+    FlatAdamW.comm_report() (what bench.py prints at N > 1) has timed both exchanges: bytes of the message, duration on the communication stream,
+    and the stall of the compute stream at the optimizer step."""
     import torch.distributed as dist
     from oracle import cogvideox as ocv
     from videogpa_amd.lora import LoraConfig, get_peft_model
@@ -150,8 +152,11 @@ def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):
     batches = [{"x_pair": (0.7 * torch.randn(1, 2, 3, 16, 8, 8, generator=g)).to(torch.bfloat16).cuda(),
                 "prompt_emb": (0.5 * torch.randn(1, 6, 48, generator=g)).to(torch.bfloat16).cuda()} for _ in range(4)]
 
-    def run(force):
+    reports = {}
+
+    def run(force, collective="all_reduce"):
         monkeypatch.setenv("VGPA_FORCE_DIST", "1" if force else "0")
+        monkeypatch.setenv("VGPA_DP_COLLECTIVE", collective)
         model = CogVideoXTransformer3DModel(use_rotary_positional_embeddings=True, **kw)
         model.load_state_dict(sd, strict=True)
         torch.manual_seed(11)      # PEFT's kaiming-uniform lora_A
@@ -174,6 +179,11 @@ def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):
         if force:
             seen.append(last["sync"].clone())
         assert tr.global_step == 2 and len(seen) == 2
+        if force:
+            rep = eng.opt.comm_report()
+            assert rep["collective"] == collective and rep["exchanges"] == 2 and rep["bytes"] == (eng.opt.flat.numel + 4) * 4
+            assert rep["allreduce_ms"] > 0 and rep["exposed_wait_ms"] >= 0 and eng.opt.comm_report() is None      # a report drains the events
+            reports[collective] = rep
         return eng.opt.flat.flat.clone(), torch.stack(seen)
 
     plain = run(False)
@@ -183,9 +193,34 @@ def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         rccl = run(True)
+        rsag = run(True, "rs_ag")
     finally:
         dist.destroy_process_group()
     assert torch.equal(plain[0], rccl[0]) and torch.equal(plain[1], rccl[1])
+    assert torch.equal(plain[0], rsag[0]) and torch.equal(plain[1], rsag[1])
+    print({"comm_report": reports})
+
+
+def test_bench_line_under_a_forced_process_group_carries_the_comm_attribution():
+    """`bench.py` with VGPA_FORCE_DIST=1 (the N > 1 code path on the one GPU of this box: RCCL group of one rank, side-stream exchange, deferred optimizer
+    step) on a 2-block debug shape: the JSON line carries what a scaling loss would be attributed from -- ranks_seen, per-rank ms_per_step (min / max) and
+    comm = {collective, bytes, exchanges, allreduce_ms, exposed_wait_ms (+ max over ranks)} -- for both collectives."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for coll in ("all_reduce", "rs_ag"):
+        env = dict(os.environ, VGPA_FORCE_DIST="1", VGPA_DP_COLLECTIVE=coll, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--layers", "2", "--frames", "3", "--height", "16", "--width", "16", "--steps", "3",
+                            "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = json.loads(next(ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")))
+        assert j["ranks_seen"] == 1 and j["n_gpus"] == 1 and len(j["ms_per_step_by_rank"]) == 1
+        assert 0 < j["ms_per_step_min"] <= j["ms_per_step_max"] <= j["ms_per_step"] * 1.001
+        c = j["comm"]
+        assert c["collective"] == coll and c["exchanges"] == 3 and c["bytes"] > 4 * 2 * 4 * 64 * 3072 and c["allreduce_ms"] > 0
+        assert 0 <= c["exposed_wait_ms"] <= c["exposed_wait_ms_max_over_ranks"] + 1e-9
+        print({coll: c})
 
 
 @pytest.mark.parametrize("recompute,mem_gb", [(True, 80), (False, 230)])

@@ -202,8 +202,8 @@ def test_wan_full_width_default_path_is_within_the_cfg1_cap_of_fp32_on_every_ten
     """the default path is within 12 % of the plain fp32 oracle on EVERY tensor (the cfg1 cap of tests/test_gpu_cfg1.py; measured: 0.7 %), and never further
     from it than the textbook backward by more than noise on the tensors "Precise delta" exists for.  MEASURED here, and worth stating: on this model the two
     backwards agree to 1e-4 -- the q / k adapters of the last block are 0.2 % from fp32 either way, where CogVideoX at the same width was 37-87 % off without
-    the completed output.  Wan rotates q and k by position (RoPE on the training path; the CogVideoX reference trains without it), which takes the common
-    component out of sum_j P_ij K_j, the factor the coherent delta error rides on."""
+    the completed output.  A plausible reason, not isolated here: Wan rotates q and k by position (RoPE on the training path; the CogVideoX reference trains
+    without it), which takes the common component out of sum_j P_ij K_j, the factor the coherent delta error rides on."""
     _, g_def, _ = _hip("bf16")
     _, g_plain, _ = _hip("bf16_plain")
     _, p_grads, _ = _oracle()
