@@ -125,6 +125,21 @@ def test_wan_from_pretrained_gives_the_identical_forward(tmp_path):
     assert all(torch.equal(u, v) and torch.isfinite(u).all() for u, v in zip(oa, ob)) and oa[0].abs().max() > 0
 
 
+def test_wan_unfrozen_modulation_raises_instead_of_training_without_its_gradient():
+    """one policy for every modulation consumer (blocks and head): a bare WanModel (parameters require grad) refuses a grad-enabled forward, because the row
+    kernels return no gradient for shift / scale / gate; frozen -- what get_peft_model does -- or under no_grad it runs"""
+    from videogpa_amd.wan_model import WanModel
+    torch.manual_seed(2)
+    m = WanModel(**CFG).to(device="cuda", dtype=torch.bfloat16)
+    x, t, ctx, L, _ = _inputs()
+    with pytest.raises(NotImplementedError, match="modulation table"):
+        m(x, t=t, context=ctx, seq_len=L)
+    with torch.no_grad():
+        assert torch.isfinite(m(x, t=t, context=ctx, seq_len=L)[0]).all()
+    m.requires_grad_(False)
+    assert torch.isfinite(m(x, t=t, context=ctx, seq_len=L)[0]).all()
+
+
 def test_wan_dpo_trainer_step_runs_on_the_hip_model():
     """WanDPOTrainer (train/Wan2.2-TI2V-5B/03_train.py:130-242) driving the HIP WanModel: one pair step, finite loss, every LoRA B gets a gradient"""
     from videogpa_amd.wan import WanDPOTrainer

@@ -115,13 +115,26 @@ def test_from_pretrained_reads_the_upstream_checkpoint_layout(tmp_path):
     assert cfg["_class_name"] == "WanModel" and cfg["dim"] == 128 and cfg["patch_size"] == [1, 2, 2]
     want = m.state_dict()
     for path in (one, many):
-        got = WanModel.from_pretrained(path)
+        got = WanModel.from_pretrained(path, torch_dtype="auto")                       # "auto": every tensor keeps its stored dtype
         assert not got.training and dict(got.config) == dict(m.config) and got.config.num_layers == 2
         sd = got.state_dict()
         assert sd.keys() == want.keys()
         assert all(sd[k].dtype == torch.bfloat16 and sd[k].device.type == "cpu" and torch.equal(sd[k], want[k]) for k in want)
-    f32 = WanModel.from_pretrained(one, torch_dtype=torch.float32)
-    assert all(v.dtype == torch.float32 for v in f32.state_dict().values())
+    # torch_dtype=None is diffusers' default: float32 parameters whatever the file stores (the reference casts to bf16 right after, 03_train.py:141)
+    for f32 in (WanModel.from_pretrained(one), WanModel.from_pretrained(one, torch_dtype=torch.float32)):
+        sd = f32.state_dict()
+        assert all(v.dtype == torch.float32 for v in sd.values()) and all(torch.equal(sd[k], want[k].float()) for k in want)
+    assert all(torch.equal(v, want[k]) for k, v in WanModel.from_pretrained(one).to(torch.bfloat16).state_dict().items())
+    # a checkpoint that mixes dtypes loads (upstream does): fp32 by default, as stored with "auto"
+    from safetensors.torch import load_file, save_file
+    mixed = str(tmp_path / "mixed")
+    m.save_pretrained(mixed)
+    raw = load_file(os.path.join(mixed, "diffusion_pytorch_model.safetensors"))
+    raw["head.modulation"] = raw["head.modulation"].float()
+    save_file(raw, os.path.join(mixed, "diffusion_pytorch_model.safetensors"))
+    auto = WanModel.from_pretrained(mixed, torch_dtype="auto").state_dict()
+    assert auto["head.modulation"].dtype == torch.float32 and auto["head.head.weight"].dtype == torch.bfloat16
+    assert all(v.dtype == torch.float32 for v in WanModel.from_pretrained(mixed).state_dict().values())
     cfg["rope_scaling"] = 2
     json.dump(cfg, open(os.path.join(one, "config.json"), "w"))
     with pytest.raises(ValueError):

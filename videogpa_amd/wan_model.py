@@ -49,6 +49,16 @@ def _ptr_dtype(x):
     raise TypeError(f"videogpa_amd.wan_model: rows must be fp32 or bf16, got {x.dtype}")
 
 
+def _modulation_is_frozen(tab, who):
+    """ONE policy for every consumer of a modulation table (block LN / gate kernels, feed-forward node, output head): the row kernels return no gradient
+    for shift / scale / gate, so a table that would need one -- `modulation`, the time embedding or the time projection left trainable -- raises instead of
+    training with a silently missing gradient.  The DPO path freezes the base model (LoRA targets are q / k / v / o: train/Wan2.2-TI2V-5B/03_train.py:143-148,
+    get_peft_model does the freezing); a bare WanModel needs `.requires_grad_(False)` before a grad-enabled forward."""
+    if tab.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError(f"videogpa_amd.wan_model.{who}: the modulation table requires a gradient, which the HIP row kernels do not produce -- "
+                                  "freeze the base model (model.requires_grad_(False), or wrap it with get_peft_model) before a grad-enabled forward")
+
+
 class _LnModFn(torch.autograd.Function):
     """bf16( LN_eps(x) [rounded to bf16] * ln_w + ln_b, then * (1 + scale[gid]) + shift[gid] );   x [rows, D] fp32 or bf16.
     pad > 0: the result is the head of a [rows, D + pad] buffer (ops._padded_empty) whose tail the consuming projection fills with its LoRA
@@ -91,13 +101,10 @@ class _LnModFn(torch.autograd.Function):
 
 class _HeadLnModFn(torch.autograd.Function):
     """fp32( LN_eps(x) * (1 + scale[gid]) + shift[gid] ),  x [rows, D] fp32: the output head's normalisation (csrc/wan.hip, the fp32-result form of the
-    block kernels).  The modulation table takes no gradient here: the time MLP and the head's `modulation` are frozen on the DPO path (LoRA
-    targets are q / k / v / o), and a table that requires one raises instead of dropping it silently."""
+    block kernels).  The modulation table takes no gradient (see _modulation_is_frozen: checked by the caller, as in the blocks)."""
 
     @staticmethod
     def forward(ctx, x, gid, shift, scale, eps):
-        if shift.requires_grad or scale.requires_grad:
-            raise NotImplementedError("videogpa_amd.wan_model.Head: the head's modulation / time embedding is frozen on this path")
         rows, D = x.shape
         x = x.contiguous()
         out = torch.empty(rows, D, dtype=torch.float32, device=x.device)
@@ -524,6 +531,7 @@ class WanAttentionBlock(nn.Module):
     def forward(self, x, e0, gid, B, L, rope, context):
         """x [B*L, dim]: bf16 in the first block (the patch embedding's output), fp32 afterwards; e0 [G, 6, dim] fp32; -> fp32"""
         tab = (self.modulation.float() + e0).contiguous()          # [G, 6, dim] fp32: upstream adds under autocast(float32)
+        _modulation_is_frozen(tab, "WanAttentionBlock")
         first = x.dtype == torch.bfloat16                           # norm1(x).type_as(x) rounds only while the stream is still bf16
         sa_in, sa_out = self.self_attn.pads()
         ca_in, ca_out = self.cross_attn.pads()
@@ -562,6 +570,7 @@ class Head(nn.Module):
         is the row kernel of the blocks with an fp32 result (the modulation table is indexed inside the kernel: no [L, dim] gather), then one
         fp32 library GEMM."""
         tab = (self.modulation.float() + e[:, None]).contiguous()   # [G, 2, dim]
+        _modulation_is_frozen(tab, "Head")
         h = _HeadLnModFn.apply(x, gid, tab[:, 0], tab[:, 1], self.eps)
         w, b = self.head.weight, self.head.bias
         return F.linear(h, w.float() if w.requires_grad else _f32(w), b.float() if b.requires_grad else _f32(b))
@@ -613,8 +622,9 @@ class WanModel(nn.Module):
         @register_to_config, so a checkpoint directory holds `config.json` (the constructor arguments + `_class_name` / `_diffusers_version`)
         and the weights as `diffusion_pytorch_model.safetensors` or as shards `diffusion_pytorch_model-0000i-of-0000n.safetensors` listed by
         `diffusion_pytorch_model.safetensors.index.json` (`weight_map`: parameter name -> shard file).  Parameter names are the upstream ones
-        (module docstring), loaded strictly; like diffusers the weights keep their stored dtype unless `torch_dtype` is given.  No hub access:
-        `path` must be a local directory."""
+        (module docstring), loaded strictly.  dtype as diffusers' ModelMixin.from_pretrained: torch_dtype=None gives float32 parameters whatever the
+        checkpoint stores (the reference casts right after: `.to(torch.bfloat16)`, 03_train.py:141), a torch.dtype casts to it, and "auto" keeps the stored
+        dtype of every tensor (mixed checkpoints included).  No hub access: `path` must be a local directory."""
         from safetensors.torch import load_file
         root = os.path.join(path, subfolder) if subfolder else path
         if not os.path.isdir(root):
@@ -639,13 +649,11 @@ class WanModel(nn.Module):
             sd.update(load_file(os.path.join(root, fn)))
         with torch.device("meta"):
             model = cls.from_config(cfg, **kw)
-        dtypes = {v.dtype for v in sd.values() if v.is_floating_point()}
+        if torch_dtype != "auto":
+            want = torch.float32 if torch_dtype is None else torch_dtype
+            sd = {k: (v.to(want) if v.is_floating_point() else v) for k, v in sd.items()}      # per tensor, before the assign: never two full copies
         model.load_state_dict(sd, strict=True, assign=True)          # meta skeleton + assign: no second copy of a 5 B-parameter model, no random init
         model._rope = {}
-        if torch_dtype is not None:
-            model = model.to(torch_dtype)
-        elif len(dtypes) > 1:
-            raise ValueError(f"checkpoint mixes dtypes {sorted(map(str, dtypes))}: pass torch_dtype=")
         model.eval()                                                  # diffusers' from_pretrained returns the model in eval mode
         return model
 
@@ -732,6 +740,8 @@ class WanModel(nn.Module):
         return self._rope[key]
 
     def forward(self, x, t, context, seq_len, y=None, timestep_groups=None):
+        """upstream call convention (module docstring).  A grad-enabled forward needs the base model FROZEN: gradients reach the LoRA adapters (and the
+        inputs), not the modulation tables / time embedding (_modulation_is_frozen raises otherwise)."""
         if y is not None:
             x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
         xb = torch.stack(list(x))
