@@ -83,7 +83,7 @@ _RSMI = None
 def read_joules(device=0):
     """Accumulated socket energy of GPU `device` in joules (librocm_smi64 rsmi_dev_energy_count_get; None when the library or the counter is not
     there).  Read around the timed region: J per step and mean W next to ms per step -- every MFMA-bound launch of this step runs at the part's
-    1.4 kW cap, so time IS joules (DESIGN section 4.1)."""
+    1.4 kW cap, so time IS joules (DESIGN section 4.2)."""
     global _RSMI
     import ctypes
     if _RSMI is None:

@@ -7,7 +7,7 @@ the checker the HIP kernels are compared against.  Only `tests/`,
 the product package `videogpa_amd` never does (tests/test_layout.py enforces
 that) and fails loudly when its HIP library is missing.
 
-Pinning status (see DESIGN.md section "Oracle"):
+Pinning status:
   * dpo.py, dataset.py, scorer.{project_points, batch_reproject, motion_score,
     mse (+ resize branch), psnr, pointcloud_filter, mvcs, quat_to_mat,
     pose_encoding_to_extri_intri, affine_inverse, unproject_depth}: PINNED --

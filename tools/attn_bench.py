@@ -17,7 +17,7 @@ ap.add_argument("--H", type=int, default=48)
 ap.add_argument("--which", default="fwd,dkv,dq")
 ap.add_argument("--split", type=int, default=-1, help="forward split_mode: -1 automatic, 0 never")
 ap.add_argument("--data", default="randn", choices=["randn", "zeros", "const"], help="operand values: zeros / one constant toggle almost no datapath bits -> the time of the "
-                "instruction stream without the power throttle that random data brings (DESIGN section 4.0)")
+                "instruction stream without the power throttle that random data brings (DESIGN section 4.2)")
 ap.add_argument("--energy", type=float, default=0.0, help="seconds of back-to-back launches per op bracketed by the socket energy counter (tools/energy.py): "
                 "joules per launch and mean power next to the time, also for the vendor FF1 GEMM of the step as a yardstick")
 a = ap.parse_args()

@@ -3,7 +3,7 @@
     e0 = read_joules(); <work>; torch.cuda.synchronize(); e1 = read_joules()     ->  e1 - e0 joules over the interval
 
 The counter is the accumulated-energy register the driver exposes (resolution 15.26 uJ on MI300-class parts), sampled by the SMU about once per
-millisecond: bracket at least a second of back-to-back launches.  Measurement helper only (DESIGN section 4.0: joules per launch)."""
+millisecond: bracket at least a second of back-to-back launches.  Measurement helper only (DESIGN section 4.2: joules per launch)."""
 import ctypes
 import re
 import subprocess

@@ -1,4 +1,4 @@
-"""hipBLASLt cost of letting the LoRA adapters ride the dense projection as extra K (DESIGN section 8): forward
+"""hipBLASLt cost of letting the LoRA adapters ride the dense projection as extra K (DESIGN section 2 item 8): forward
 [M,3072+192] x [9216,3264]^T vs K = 3072; backward dX [M,9216+192] x [3072,9408]^T vs K = 9216; to_out likewise (+64)."""
 import torch
 import torch.nn.functional as F

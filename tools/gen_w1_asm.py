@@ -1228,7 +1228,7 @@ class Dq128Loop:
 # ------------------------------------------------------------------------------------- dQ, head_dim 128, two q-blocks per wave
 class Dq128x2Loop:
     """Dq128Loop with TWO 32-row q-blocks j per wave, so that every streamed K / V fragment feeds two MFMAs (the matrix pipe's energy floor is 0.74 J per
-       TFLOP and every 1 KiB fragment read per MFMA adds 0.24: tools/mfma_energy_probe.hip, DESIGN section 4.1 -- one read per MFMA was the price of
+       TFLOP and every 1 KiB fragment read per MFMA adds 0.24: tools/mfma_energy_probe.hip, DESIGN section 4.2 -- one read per MFMA was the price of
        Dq128Loop).  dQ^T (128) + the Q and dO fragments of both blocks (64 + 64) fill the accumulator half of the register file, so the fragment ring
        lives in VGPRs and the -lse2 / -delta srcC tuples (64 registers for two blocks) are gone: the score chain starts from the inline constant 0 and
          B(g): p = exp2(fma(c, S, -lse2[q])),  dS = (DP - delta[q]) * p,  D[g&1][j] = bf16(dS)        144 VALU per half-step (9 per element pair)

@@ -1,4 +1,4 @@
-// The matrix pipe's energy floor on this part (DESIGN section 4.1): a register-resident stream of MFMAs -- no LDS, no memory, no VALU -- timed AND
+// The matrix pipe's energy floor on this part (DESIGN section 4.2): a register-resident stream of MFMAs -- no LDS, no memory, no VALU -- timed AND
 // bracketed by the socket energy counter, on random and on all-zero operands.  If the hand-scheduled attention kernels and the vendor's GEMM both cost
 // ~1 J per executed bf16 TFLOP on random data, is that the kernels or the silicon?  This probe gives the silicon's number.
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_energy_probe.hip -o /tmp/mfma_energy_probe -ldl && /tmp/mfma_energy_probe

@@ -1,4 +1,4 @@
-"""Socket power and shader clock while a command runs -- the evidence behind DESIGN section 4.0's "the matrix pipe is power-limited":
+"""Socket power and shader clock while a command runs -- the evidence behind DESIGN section 4.2's "the matrix pipe is power-limited":
     python tools/power_trace.py --out gpurun_out/power_TAG.json -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline
 Polls `rocm-smi --showpower --showclocks --showmaxpower --json` (about 3 samples per second) until the command exits and writes every
 sample plus a summary over the BUSY samples (power above half of the largest one seen): mean / max socket power against the board's power

@@ -40,7 +40,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_a128 -
 fb=$(find $R/gpurun_out/prof_${tag}_a128 -name "*kernel_stats.csv" | head -1)
 [ -n "$fb" ] && cp $fb $R/gpurun_out/${tag}_attn128_kernel_stats.csv
 find $R/gpurun_out/prof_${tag}_a128 -name "*kernel_trace.csv" -delete
-# socket power / shader clock during the default bench command (the power-limit evidence of DESIGN section 4.0)
+# socket power / shader clock during the default bench command (the power-limit evidence of DESIGN section 4.2)
 rocm-smi --showpower --showclocks --showmaxpower --json > $R/gpurun_out/${tag}_rocm_smi_idle.json 2>&1
 timeout 300 python $R/tools/power_trace.py --out $R/gpurun_out/power_${tag}.json -- python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-kernel-timer \
     > $R/gpurun_out/power_${tag}_bench.json 2> $R/gpurun_out/power_${tag}.log

@@ -1,5 +1,5 @@
 """Random operands against all-zero operands for the MFMA-bound launches of the step: the same instruction streams, with and without the
-datapath toggling that drives the part into its 1400 W cap (DESIGN section 4.0).  hipBLASLt's bf16 GEMM at the cfg2 feed-forward shape and the
+datapath toggling that drives the part into its 1400 W cap (DESIGN section 4.2).  hipBLASLt's bf16 GEMM at the cfg2 feed-forward shape and the
 head_dim-128 attention entry points at the cfg5 pair-batch shape; tools/attn_bench.py --data does the head_dim-64 kernels.
     gpurun -- 'PYTHONPATH=. python tools/zero_data_probe.py'"""
 import torch

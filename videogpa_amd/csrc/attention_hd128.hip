@@ -3,7 +3,7 @@
 // video tokens over the 512 text tokens), forward and backward.  Same mathematics and operand conventions as attention.hip
 // (softmax in the exp2 domain, fp32 statistics, lse2 = m + log2(l) kept for the backward, delta = rowsum(dO o O)).  Two kernel
 // families behind the same entry points:
-//   * the w1 kernels (one wave per SIMD, LDS-DMA ring, generated main loops -- DESIGN.md sections 4.0 / 4.5) for long sweeps:
+//   * the w1 kernels (one wave per SIMD, LDS-DMA ring, generated main loops -- DESIGN.md sections 4.1 / 4.4) for long sweeps:
 //     attn128_fwd_w1_kernel, attn128_dkv_w1_kernel, attn128_dq_w1_kernel;
 //   * compiler-scheduled kernels for short sweeps (cross-attention over 512 text tokens), the forward's flagged strips and as the
 //     reference implementation: 4 waves x 32 stationary rows per workgroup, the streamed operand as [64 x 128] tiles through registers
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(const bf16_t* __res
 }
 
 // ----------------------------------------------------------------------------------------------------- forward, w1 structure
-// The forward on the one-wave-per-SIMD structure of attention_w1.hip (DESIGN.md section 4.0) at head_dim 128: 4 waves x 2 q-blocks
+// The forward on the one-wave-per-SIMD structure of attention_w1.hip (DESIGN.md section 4.1) at head_dim 128: 4 waves x 2 q-blocks
 // = 256 query rows per workgroup, K/V tiles [64 x 128] by LDS-DMA into a 4-slot ring of 32 KiB slots, main loop from
 // tools/gen_w1_asm.py::Fwd128Loop (w1_fwd128_loop.inc: pipeline, LDS image and register map in its docstring).  Softmax shift = the
 // row bound M[q] = c |q| max|k| (attn128_kmax_kernel), strips that underflow / overflow / are not finite are flagged and redone by

@@ -4,7 +4,7 @@
 //   * __launch_bounds__(256, 1): accumulators and the stationary operand fragments (MFMA-only values) may live in the
 //     accumulator half of the register file, which leaves the 256 architectural VGPRs to a software pipeline that is one
 //     32-row half-tile deep in every stage:   scores(g+1)  ||  exp / multiply / pack (g)  ||  accumulate (g-1),
-//     the stage the 2-waves-per-SIMD kernels could not hold in 256 registers.
+//     the stage the 2-waves-per-SIMD kernels could not hold in 256 registers (the round-1/2 analysis: profiles/HISTORY.md).
 //   * K/V (Q/dO) tiles never pass through VGPRs: each wave issues `buffer_load_dwordx4 ... lds` pieces two tiles ahead
 //     into a 4-slot ring (attn_w1.h), completion counted by hand (s_waitcnt vmcnt(N)), ONE s_barrier per 64-row tile.
 //   * the LDS image is unpadded and chunk-swizzled: row-fragment reads and transpose reads are both conflict-free.

@@ -628,7 +628,7 @@ def _padded_base(t2, width):
 
 
 class LoraExt:
-    """Operands of one LoRA-carrying projection with the adapters riding the dense GEMM as extra K (DESIGN section 4):
+    """Operands of one LoRA-carrying projection with the adapters riding the dense GEMM as extra K (DESIGN section 2 item 8):
 
         forward :  y  = [x | T] [W | blockdiag(s_i B_i)]^T + b        T  = x A_cat^T            (lora_down)
         backward:  dx = [dy | dT] [W^T | A_cat^T]^T                    dT_i = dy_i (s_i B_i)     (lora_down)

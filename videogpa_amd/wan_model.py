@@ -5,7 +5,7 @@ The Wan2.2 source is NOT in the reference tree (un-vendored), so this module res
 parameter names follow the upstream state dict (patch_embedding, text_embedding.{0,2}, time_embedding.{0,2}, time_projection.1,
 blocks.N.{norm3, self_attn.{q,k,v,o,norm_q,norm_k}, cross_attn.{...}, ffn.{0,2}, modulation}, head.{head, modulation}) so that an
 upstream checkpoint loads with `load_state_dict` and PEFT's target names 'q', 'k', 'v', 'o' hit the same linears.  Parity is against
-oracle/wan.py (a plain torch restatement), which is UNPINNED for the same reason (DESIGN.md section 8).
+oracle/wan.py (a plain torch restatement), which is UNPINNED for the same reason (DESIGN.md section 5).
 
 MI355X-first choices (everything else is the upstream arithmetic):
   * per-token modulation ([B, L, 6, C] fp32 upstream, 1.4 GB per sample at 18480 tokens) is a table over the DISTINCT timesteps of
@@ -708,7 +708,7 @@ class WanModel(nn.Module):
     def enable_gradient_checkpointing(self, enabled=True, stride=1):
         """the reference wraps every block's forward in torch.utils.checkpoint (03_train.py:150-159: sized for 80 GB parts).  `stride` k
         recomputes only every k-th block; 288 GB of HBM3E hold ALL activations of the full-size pair step (30 blocks x 2 samples x
-        18 480 tokens: DESIGN section 4.5), so the MI355X default of the trainer / bench is enabled=False -- one forward in five saved."""
+        18 480 tokens: DESIGN section 4.4), so the MI355X default of the trainer / bench is enabled=False -- one forward in five saved."""
         self.gradient_checkpointing = bool(enabled)
         self.checkpoint_stride = max(1, int(stride))
 
