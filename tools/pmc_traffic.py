@@ -63,10 +63,11 @@ for k, cs in acc.items():
     out[alias.get(k, k)] = e
 # bench.py times the head_dim-128 backward as ONE entry (delta + dK/dV + dQ launches of vgpa_attn128_bwd): bytes add up, occupancy and clock are
 # duration-weighted means of the two matrix kernels
-parts = [out[k] for k in ("attn128_dkv_w1_kernel", "attn128_dq_w1_kernel") if k in out]
+dq_name = "attn128_dq_w1x2_kernel" if "attn128_dq_w1x2_kernel" in out else "attn128_dq_w1_kernel"      # two q-blocks per wave since round 4
+parts = [out[k] for k in ("attn128_dkv_w1_kernel", dq_name) if k in out]
 if len(parts) == 2:
     e = {"hbm_bytes_per_launch": sum(p["hbm_bytes_per_launch"] for p in parts) + out.get("attn128_delta_kernel", {}).get("hbm_bytes_per_launch", 0.0),
-         "note": "attn128_dkv_w1_kernel + attn128_dq_w1_kernel (+ attn128_delta_kernel) of one vgpa_attn128_bwd call"}
+         "note": f"attn128_dkv_w1_kernel + {dq_name} (+ attn128_delta_kernel) of one vgpa_attn128_bwd call"}
     if all("avg_ns_under_rocprof" in p for p in parts):
         w = [p["avg_ns_under_rocprof"] for p in parts]
         for key in ("mfma_busy", "clock_mhz"):
@@ -77,4 +78,6 @@ if len(parts) == 2:
 out["__source__"] = {"profile_round": tag, "made_by": "tools/profile_round.sh -> tools/pmc_traffic.py", "files": f"profiles/{tag}_pmc_traffic.json"}
 json.dump(out, open(f"{root}/pmc_traffic_{tag}.json", "w"), indent=1)
 for k, v in out.items():
+    if "hbm_bytes_per_launch" not in v:
+        continue
     print(f"{k:48s} hbm {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  mfma_busy {v.get('mfma_busy', float('nan')):.3f}  clock {v.get('clock_mhz', float('nan')):7.0f} MHz")
