@@ -220,6 +220,37 @@ def test_attention128_e4m3_forward_hands_its_backward_the_operands_it_used():
     print({"e4m3 forward + backward on its dequantised operands vs the fp64 model": worst, "row sum error deq / bf16": ((rows_deq - 1).abs().max().item(), (rows_bf16 - 1).abs().max().item())})
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv", [(2, 24, 2560, 512), (1, 3, 2100, 77), (1, 2, 4000, 130), (1, 1, 2048, 1), (1, 2, 2049, 500)])
+def test_attention128_many_queries_over_short_key_sweeps_vs_fp64(B, H, Sq, Skv):
+    """Many query rows over a short key sweep (the Wan2.2 cross-attention: 18 480 x 512), at more tasks than CUs, with ragged key tails (77, 130, 500, a single
+    key), a ragged last query tile and token-major views: output, lse2 and the res8 bytes against fp64, and the backward that consumes them (dq / dk / dv through
+    ops.attention128)."""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(Sq * 5 + Skv)
+    tm = lambda t: t.bfloat16().permute(0, 2, 1, 3)
+    q = tm(torch.randn(B, Sq, H, 128, device="cuda", generator=g))
+    k = tm(torch.randn(B, Skv, H, 128, device="cuda", generator=g) + 0.5)
+    v = tm(torch.randn(B, Skv, H, 128, device="cuda", generator=g) + 1.0)
+    do = tm(torch.randn(B, Sq, H, 128, device="cuda", generator=g))
+    scale = 128 ** -0.5
+    o_res8 = torch.full((B, Sq, H * 128), 7, dtype=torch.uint8, device="cuda")
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, o_res8=o_res8)
+    ro, rq, rk, rv = _ref(q, k, v, do, scale)
+    _close(o, ro, "o")
+    want_lse = torch.logsumexp((q.double() @ k.double().transpose(-1, -2)) * scale, dim=-1) / 0.6931471805599453
+    assert (lse.double() - want_lse).abs().max().item() <= 2e-3
+    o_full = ops.res8_decode(o, o_res8.unflatten(-1, (H, 128)).permute(0, 2, 1, 3)).double()
+    assert ((o_full - o.double()).abs() <= 2.0 ** -8 * o.double().abs() + 1e-30).all()
+    assert (o_full - ro).abs().max().item() <= 0.3 * max((o.double() - ro).abs().max().item(), 1e-3)        # the bytes really complete the output
+    o2, lse2 = ops.attention128_fwd_raw(q, k, v, scale)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)                                                      # deterministic; res8 changes nothing else
+    qg, kg, vg = (t.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for t in (q, k, v))
+    ops.attention128(qg, kg, vg, scale).backward(do)
+    _close(qg.grad, rq, "dq", tol=0.03)
+    _close(kg.grad, rk, "dk", tol=0.03)
+    _close(vg.grad, rv, "dv", tol=0.03)
+
+
 def test_attention128_e4m3_outlier_rows_and_short_sweeps():
     """a 40x query row (bound above 160 -> strip flagged, redone in bf16), a 40x key row (every bound loose), and a 512-key sweep (below
     ATTN128_F8_MIN_KEYS: the bf16 kernels serve it -- the Wan2.2 cross-attention over the text tokens)"""

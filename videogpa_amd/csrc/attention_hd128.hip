@@ -920,6 +920,11 @@ extern "C" int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v,
         VGPA_CHECK_LAUNCH();
         return VGPA_OK;
     }
+    // Short key sweeps (the cross-attention over the 512 text tokens) stay on the per-task kernel.  Measured in round 5: a persistent workgroup per CU with
+    // ONE LDS-DMA ring of K / V tiles kept running across (batch-head, q-tile) tasks and the next task's Q fragments loaded a task ahead -- no prologue,
+    // no per-tile round trip -- around the SAME compiler-scheduled loop body ran 0.540-0.554 ms against this kernel's 0.510-0.513 ms at 18 480 x 512 x 48
+    // heads: two independent 4-wave workgroups per CU already hide the latencies, and the loop itself (every MFMA behind its own ds_read + lgkmcnt(0))
+    // is the limit.  What would help is the generated one-wave-per-SIMD loop made persistent; the ring kernel was removed again.
     VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
                 mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)nullptr, ores, sor);
     VGPA_CHECK_LAUNCH();
