@@ -161,3 +161,110 @@ def test_interleaved_rope_matches_installed_third_party_implementation():
     # GPT-J layout: tensor [B, S, H, D]; sin / cos [B, S, D/2] (it repeat-interleaves them itself)
     theirs = gptj.apply_rotary_pos_emb(x.permute(0, 2, 1, 3), sin[None, :, ::2].expand(B, -1, -1), cos[None, :, ::2].expand(B, -1, -1))
     assert torch.allclose(ours, theirs.permute(0, 2, 1, 3), rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ oracle/wan.py: the e4m3 attention model and the rounded mode
+def _wan_toy(seed=0, dim=256, ffn=512, heads=2, layers=2):
+    g = torch.Generator().manual_seed(seed)
+
+    def w(*s, sc=0.05):
+        return (torch.randn(*s, generator=g) * sc).bfloat16().float()
+    st = {"patch_embedding.weight": w(dim, 4, 1, 2, 2), "patch_embedding.bias": w(dim), "head.modulation": w(1, 2, dim)}
+    for n, (i, o) in {"text_embedding.0": (16, dim), "text_embedding.2": (dim, dim), "time_embedding.0": (32, dim), "time_embedding.2": (dim, dim),
+                      "time_projection.1": (dim, 6 * dim), "head.head": (dim, 16)}.items():
+        st[n + ".weight"], st[n + ".bias"] = w(o, i), w(o)
+    for b in range(layers):
+        pre = f"blocks.{b}"
+        st[pre + ".modulation"] = w(1, 6, dim, sc=0.3)
+        st[pre + ".norm3.weight"], st[pre + ".norm3.bias"] = 1 + w(dim), w(dim)
+        for a in ("self_attn", "cross_attn"):
+            for m in "qkvo":
+                st[f"{pre}.{a}.{m}.weight"], st[f"{pre}.{a}.{m}.bias"] = w(dim, dim), w(dim)
+            st[f"{pre}.{a}.norm_q.weight"], st[f"{pre}.{a}.norm_k.weight"] = 1 + w(dim), 1 + w(dim)
+        st[pre + ".ffn.0.weight"], st[pre + ".ffn.0.bias"], st[pre + ".ffn.2.weight"], st[pre + ".ffn.2.bias"] = w(ffn, dim), w(ffn), w(dim, ffn), w(dim)
+    cfg = dict(patch_size=(1, 2, 2), text_len=8, dim=dim, freq_dim=32, out_dim=4, num_heads=heads, num_layers=layers, cross_attn_norm=True, eps=1e-6)
+    return st, cfg, g
+
+
+def test_wan_oracle_e4m3_attention_model_known_answers():
+    """oracle/wan.py::f8_operands / _F8Attn, the restatement of csrc/attention_hd128.hip's e4m3 forward and of the backward that follows it:
+    (i) the dequantised operands lie on the e4m3 grid of their per-head power-of-two scale, within 2^-4 of the inputs, the largest at 224..448 scale units;
+    (ii) the forward is softmax attention over THOSE operands up to the e4m3 rounding of the weights (cos >= 0.999 against it, >= 0.995 against plain attention);
+    (iii) the consistent backward's recomputed weights exp2(c q' k8 - lse2) sum to one per row (1e-2: q' = bf16(q8 / c)), the round-4 form's do not;
+    (iv) with a value tensor that is constant along the keys the true dq, dk vanish (rows of dS sum to zero): the consistent backward is >= 3x closer to that
+        than the round-4 form (what is left is the e4m3 rounding of the weights: sum_j Q(p_ij) / l is 1 only to ~2^-4 / sqrt(keys))."""
+    from oracle import wan as ow
+    g = torch.Generator().manual_seed(5)
+    B, n, L, d = 1, 2, 192, 128
+    q, k, v = (torch.randn(B, n, L, d, generator=g, dtype=torch.float64).bfloat16().double() for _ in range(3))
+    k = k + 0.5
+    q8, k8, v8, c = ow.f8_operands(q, k, v)
+    for t8, t, fold in ((q8, q * c, True), (k8, k, False), (v8, v, False)):
+        amax = t.abs().amax(dim=(2, 3), keepdim=True)
+        e = torch.ceil(torch.log2(amax / 448.0))
+        u = t8 / torch.exp2(e)                                           # in scale units: must be e4m3 numbers, the largest in (224, 448]
+        assert torch.equal(u.float().to(torch.float8_e4m3fn).double(), u)
+        assert 224.0 < u.abs().amax().item() <= 448.0
+        assert ((t8 - t).abs() <= 2.0 ** -4 * t.abs() + 2.0 ** -9 * torch.exp2(e)).all()
+    o = ow._F8Attn.apply(q, k, v, True, True)
+    p8 = torch.softmax(q8 @ k8.transpose(-1, -2) * math.log(2.0), dim=-1)
+    cos = lambda a, b: float((a.flatten() @ b.flatten()) / (a.norm() * b.norm()))
+    assert cos(o, p8 @ v8) >= 0.999
+    assert cos(o, torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v) >= 0.995
+    lse2 = torch.logsumexp(q8 @ k8.transpose(-1, -2) * math.log(2.0), dim=-1, keepdim=True) / math.log(2.0)
+    qd = (q8 / c).bfloat16().double()
+    rows = torch.exp2((qd @ k8.transpose(-1, -2)) * c - lse2).sum(-1)
+    rows_r4 = torch.exp2((q @ k.transpose(-1, -2)) * c - lse2).sum(-1)
+    assert (rows - 1).abs().max().item() <= 1e-2 < (rows_r4 - 1).abs().max().item()
+    vc = torch.randn(B, n, 1, d, generator=g, dtype=torch.float64).bfloat16().double().expand(B, n, L, d).contiguous()
+    do = torch.randn(B, n, L, d, generator=g, dtype=torch.float64)
+    res = {}
+    for tag, consistent in (("consistent", True), ("round4", False)):
+        qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, vc))
+        oc = ow._F8Attn.apply(qr, kr, vr, True, consistent)
+        oc.backward(do)
+        res[tag] = (qr.grad.abs().max().item(), kr.grad.abs().max().item())
+        if consistent:
+            vq = ow.f8_operands(q, k, vc)[2]
+            assert (oc.detach() - vq).abs().max().item() <= 0.07 * vq.abs().max().item()       # a convex combination of equal rows (e4m3 weights: not exactly normalised)
+    assert res["consistent"][0] < res["round4"][0] / 3 and res["consistent"][1] < res["round4"][1] / 3, res
+
+
+def test_wan_oracle_rounded_mode_stays_close_to_plain_and_passes_gradients_to_every_adapter():
+    """Params(round_activations=True [, fp8_ffn, f8_attn]): the activation-rounded modes perturb the plain oracle by bf16 / e4m3 noise only -- outputs cosine
+    >= 0.999 (bf16) / 0.99 (fp8), every LoRA gradient non-zero and at cosine >= 0.98 / 0.9 with the plain one -- and exact_delta only touches the attention
+    backward (identical forward)."""
+    from oracle import wan as ow
+    st, cfg, g = _wan_toy()
+    x = [torch.randn(4, 3, 16, 24, generator=g).bfloat16().float()]
+    L = 3 * 8 * 12
+    t = torch.full((1, L), 500.0)
+    t[:, :96] = 0
+    ctx = [torch.randn(6, 16, generator=g).bfloat16().float()]
+    gout = torch.randn(4, 3, 16, 24, generator=g)
+
+    def run(**kw):
+        gl = torch.Generator().manual_seed(3)
+        lora, leaves = {}, {}
+        for b in range(2):
+            for a in ("self_attn", "cross_attn"):
+                for m in "qkvo":
+                    A = (torch.randn(8, 256, generator=gl) * 0.05).requires_grad_(True)
+                    Bm = (torch.randn(256, 8, generator=gl) * 0.05).requires_grad_(True)
+                    lora[f"blocks.{b}.{a}.{m}"] = (A, Bm, 2.0)
+                    leaves[f"blocks.{b}.{a}.{m}"] = (A, Bm)
+        out = ow.forward(ow.Params(st, lora, dtype=torch.float32, **kw), cfg, x, t, ctx, L)[0]
+        (out * gout).sum().backward()
+        return out.detach(), {k_: (a.grad.clone(), b_.grad.clone()) for k_, (a, b_) in leaves.items()}
+    cos = lambda a, b: float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
+    o0, g0 = run()
+    for kw, co, cg in ((dict(round_activations=True), 0.999, 0.98), (dict(round_activations=True, exact_delta=False), 0.999, 0.98),
+                       (dict(round_activations=True, fp8_ffn=True, f8_attn=True, f8_min_keys=64), 0.99, 0.9)):
+        o, gr = run(**kw)
+        assert cos(o, o0) >= co, (kw, cos(o, o0))
+        for name in g0:
+            for i in range(2):
+                assert gr[name][i].abs().max().item() > 0 and cos(gr[name][i], g0[name][i]) >= cg, (kw, name, i, cos(gr[name][i], g0[name][i]))
+    oa, _ = run(round_activations=True, exact_delta=True)
+    ob, _ = run(round_activations=True, exact_delta=False)
+    assert torch.equal(oa, ob)
