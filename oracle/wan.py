@@ -154,8 +154,9 @@ class _F8Attn(torch.autograd.Function):
     CHUNK = 2
 
     @staticmethod
-    def _fwd_head(q8, k8, v8):
-        """[.., L, d] -> O, lse2 (log2 units), for a chunk of heads"""
+    def _fwd_head(q8, k8, v8, lq_norm=False):
+        """[.., L, d] -> O, lse2 (log2 units), for a chunk of heads.  lq_norm (an experiment, NOT what the device does): normalise by the sum of the
+        QUANTISED weights, which makes O an exact convex combination of the v8 rows"""
         s = q8 @ k8.transpose(-1, -2)
         qn = q8.pow(2).sum(-1, keepdim=True).sqrt()
         kmax = k8.pow(2).sum(-1).amax(dim=-1, keepdim=True).sqrt().unsqueeze(-1)
@@ -170,18 +171,18 @@ class _F8Attn(torch.autograd.Function):
         x = torch.clamp(e - 8, min=-126).to(p.dtype)
         sc = torch.exp2(x)
         p8 = (_e4m3((pt / sc).clamp(max=448.0)) * sc).flatten(-2)[..., :Lk]
-        o = (p8 @ v8) / l
+        o = (p8 @ v8) / (p8.sum(-1, keepdim=True) if lq_norm else l)
         return o, M + torch.log2(l)
 
     @staticmethod
-    def forward(ctx, q, k, v, exact_delta=True, consistent=True):
+    def forward(ctx, q, k, v, exact_delta=True, consistent=True, lq_norm=False):
         """q, k, v [B, n, L, d] (bf16-valued).  -> O [B, n, L, d], unrounded; the caller rounds it to bf16 like every stored activation"""
         q8, k8, v8, c = f8_operands(q, k, v)
         o = torch.empty_like(q)
         lse2 = q.new_empty(q.shape[:-1] + (1,))
         for h0 in range(0, q.shape[1], _F8Attn.CHUNK):
             sl = slice(h0, h0 + _F8Attn.CHUNK)
-            o[:, sl], lse2[:, sl] = _F8Attn._fwd_head(q8[:, sl], k8[:, sl], v8[:, sl])
+            o[:, sl], lse2[:, sl] = _F8Attn._fwd_head(q8[:, sl], k8[:, sl], v8[:, sl], lq_norm)
         o_delta = o if exact_delta else o.bfloat16().to(o.dtype)
         if consistent:
             ctx.save_for_backward((q8 / c).bfloat16().to(q.dtype), k8, v8, o_delta, lse2)
@@ -203,12 +204,13 @@ class _F8Attn(torch.autograd.Function):
             dv[:, sl] = p.bfloat16().to(p.dtype).transpose(-1, -2) @ do[:, sl]
             dq[:, sl] = (ds @ k[:, sl]) * scale
             dk[:, sl] = (ds.transpose(-1, -2) @ q[:, sl]) * scale
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
 class Params:
     """state dict + LoRA lookup.  fp8_ffn: the feed-forward of every block with e4m3 GEMM operands (see _Fp8Ffn).  round_activations / exact_delta / f8_attn:
-    the activation-rounded mode of the module docstring (f8_attn: False, True = the consistent backward, "r4" = the round-4 device backward)."""
+    the activation-rounded mode of the module docstring (f8_attn: False, True = the device's forward + consistent backward, "r4" = the round-4 device backward,
+    "lq" = an experiment: output normalised by the sum of the quantised weights)."""
 
     def __init__(self, state, lora=None, dtype=torch.float32, fp8_ffn=False, round_activations=False, exact_delta=True, f8_attn=False, f8_min_keys=1024):
         self.s = {k: v.detach().to(dtype) for k, v in state.items()}
@@ -250,7 +252,7 @@ def _attend(q, k, v, P=None, self_attn=False):
     q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     if P is not None and P.rnd:
         if self_attn and P.f8_attn and k.shape[2] >= P.f8_min_keys:
-            o = _F8Attn.apply(q, k, v, P.exact_delta, P.f8_attn != "r4")
+            o = _F8Attn.apply(q, k, v, P.exact_delta, P.f8_attn != "r4", P.f8_attn == "lq")
         else:
             o = _RoundedSDPA.apply(q, k, v, not P.exact_delta)
         return _r(o.transpose(1, 2).flatten(2))
