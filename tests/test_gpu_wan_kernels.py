@@ -218,6 +218,18 @@ def test_attention128_e4m3_forward_hands_its_backward_the_operands_it_used():
         worst[name] = (round(cos, 6), round(nrm, 5))
         assert cos >= 0.999 and nrm <= 0.02, (name, cos, nrm)
     print({"e4m3 forward + backward on its dequantised operands vs the fp64 model": worst, "row sum error deq / bf16": ((rows_deq - 1).abs().max().item(), (rows_bf16 - 1).abs().max().item())})
+    # argument errors: the three buffers come together, with the right shapes and dtype, and only the e4m3 kernel writes them
+    from videogpa_amd import _lib
+    st = ops._bhs_strides
+    ws_bytes = _lib.query("vgpa_attn128_fwd_f8_workspace_bytes", B, H, S, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="invalid argument"):           # q_deq without k_deq / v_deq
+        _lib.call("vgpa_attn128_fwd_f8", q, k, v, o, lse, st(q), st(k), st(v), st(o), None, None, qd, None, None, st(qd), None, None, B, H, S, S, float(scale),
+                  ws, ws_bytes, ops._stream())
+    with pytest.raises(TypeError):
+        ops.attention128_fwd_raw(q, k, v, scale, f8=True, deq=(deq[0], deq[1], deq[2].float()))
+    with pytest.raises(ValueError):
+        ops.attention128_fwd_raw(q, k, v, scale, f8=False, deq=deq)
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv", [(2, 24, 2560, 512), (1, 3, 2100, 77), (1, 2, 4000, 130), (1, 1, 2048, 1), (1, 2, 2049, 500)])
