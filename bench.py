@@ -340,16 +340,14 @@ def run_other_configs(steps=3, warmup=1, timeout_s=420, cpus=None):
     cores from the CPU leg timed meanwhile.  Returns {name: compact record}; a config that fails or times out is recorded as {"error": ...}."""
     res = {}
     env = dict(os.environ)
-    pin = None
-    if cpus:
-        env.update(OMP_NUM_THREADS=str(len(cpus)), MKL_NUM_THREADS=str(len(cpus)))
-        pin = lambda: os.sched_setaffinity(0, cpus)          # noqa: E731 -- runs in the child between fork and exec
+    if cpus:        # the child pins ITSELF first thing in main() (no preexec_fn: this is called from a thread while the CPU leg's OpenMP pool is busy)
+        env.update(OMP_NUM_THREADS=str(len(cpus)), MKL_NUM_THREADS=str(len(cpus)), VGPA_BENCH_CPUS=",".join(str(c) for c in cpus))
     for name in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
                "--no-other-configs"]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, preexec_fn=pin)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
             line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
             if r.returncode != 0 or line is None:
                 res[name] = {"error": f"exit {r.returncode}", "stderr_tail": r.stderr[-400:]}
@@ -502,6 +500,11 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="default run (1 GPU, cfg2, no debug flags) also measures cfg3 / cfg4 / cfg5 for 3 steps each "
                     "and attaches them as `other_configs`; this switches that off")
     args = ap.parse_args()
+    if os.environ.get("VGPA_BENCH_CPUS"):        # a secondary-config child of the default run: stay off the cores the parent's CPU leg is being timed on
+        try:
+            os.sched_setaffinity(0, {int(c) for c in os.environ["VGPA_BENCH_CPUS"].split(",")})
+        except (AttributeError, OSError, ValueError):
+            pass
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)

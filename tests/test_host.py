@@ -237,3 +237,20 @@ def test_bench_energy_report_arithmetic_and_missing_counter():
     assert abs(r["algorithmic_tflop_per_joule"] - 0.8) < 1e-12 and abs(r["executed_tflop_per_joule"] - 1.0) < 1e-12
     j = bench.read_joules(0)
     assert j is None or j >= 0.0
+
+
+def test_bench_fences_the_cpu_leg_and_the_secondary_config_children_onto_disjoint_cores(monkeypatch):
+    """bench.py::split_host_cpus (ADVICE r4): the default run times the CPU baseline WHILE child processes build and bench cfg3 / cfg4 / cfg5; the two get
+    disjoint hardware threads -- the children the CHILD_CPUS highest-numbered ones this process may use -- and a host too small to split is reported as such"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    leg, child = bench.split_host_cpus()
+    assert len(child) == bench.CHILD_CPUS and len(leg) == 256 - bench.CHILD_CPUS and not set(leg) & set(child) and min(child) > max(leg)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {3, 5, 7, 9} | set(range(100, 140)), raising=False)
+    leg, child = bench.split_host_cpus()
+    assert sorted(child) == list(range(124, 140)) and set(leg) == {3, 5, 7, 9} | set(range(100, 124))
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(2 * bench.CHILD_CPUS)), raising=False)
+    assert bench.split_host_cpus() == (None, None)
