@@ -65,16 +65,21 @@ __device__ __forceinline__ void load_row_frags128(const bf16_t* base, uint32_t r
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(p + ks * 16);
 }
-// store this lane's column of four transposed accumulator blocks (rows d = 32 db + acc_row(r, hi)) as bf16, scaled
+// store this lane's column of four transposed accumulator blocks (rows d = 32 db + acc_row(r, hi)) as bf16, scaled: eight 16-byte stores per lane
+// (common.h pair_rows8: the lower lane of a pair writes rows 8 g .. 8 g + 7 of the even groups, the upper lane those of the odd groups)
 __device__ __forceinline__ void store_col128(bf16_t* row_ptr, const f32x16_t (&a)[4], float scale, int hi) {
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u32x2_t w;
-            w[0] = pack_bf16x2(a[db][4 * g] * scale, a[db][4 * g + 1] * scale);
-            w[1] = pack_bf16x2(a[db][4 * g + 2] * scale, a[db][4 * g + 3] * scale);
-            *reinterpret_cast<u32x2_t*>(row_ptr + db * 32 + 8 * g + 4 * hi) = w;
+        for (int gp = 0; gp < 2; ++gp) {
+            u32x2_t w[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int g = 2 * gp + e;
+                w[e][0] = pack_bf16x2(a[db][4 * g] * scale, a[db][4 * g + 1] * scale);
+                w[e][1] = pack_bf16x2(a[db][4 * g + 2] * scale, a[db][4 * g + 3] * scale);
+            }
+            *reinterpret_cast<u32x4_t*>(row_ptr + db * 32 + 8 * (2 * gp + hi)) = pair_rows8(w[0], w[1]);
         }
 }
 // the same, and (res_row != NULL) the eight further mantissa bits of every stored value (common.h res8) for the backward's delta
@@ -83,15 +88,21 @@ __device__ __forceinline__ void store_col128_res8(bf16_t* row_ptr, uint8_t* res_
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float x[4];
+        for (int gp = 0; gp < 2; ++gp) {
+            u32x2_t w[2];
+            uint32_t rb[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = a[db][4 * g + i] * scale;
-            u32x2_t w;
-            w[0] = pack_bf16x2(x[0], x[1]);
-            w[1] = pack_bf16x2(x[2], x[3]);
-            *reinterpret_cast<u32x2_t*>(row_ptr + db * 32 + 8 * g + 4 * hi) = w;
-            *reinterpret_cast<uint32_t*>(res_row + db * 32 + 8 * g + 4 * hi) = res8_pack4(x, w);
+            for (int e = 0; e < 2; ++e) {
+                const int g = 2 * gp + e;
+                float x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = a[db][4 * g + i] * scale;
+                w[e][0] = pack_bf16x2(x[0], x[1]);
+                w[e][1] = pack_bf16x2(x[2], x[3]);
+                rb[e] = res8_pack4(x, w[e]);
+            }
+            *reinterpret_cast<u32x4_t*>(row_ptr + db * 32 + 8 * (2 * gp + hi)) = pair_rows8(w[0], w[1]);
+            *reinterpret_cast<u32x2_t*>(res_row + db * 32 + 8 * (2 * gp + hi)) = pair_rows8_dword(rb[0], rb[1]);
         }
 }
 #define RES_ROW(ORES, sor, b, h, q) ((ORES) ? (ORES) + ((size_t)(b) * (sor).b + (size_t)(h) * (sor).h + (size_t)(q) * (sor).s) : (uint8_t*)nullptr)

@@ -144,11 +144,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2_t w;
-                    w[0] = pack_bf16x2(dq[j][db][4 * g] * scale, dq[j][db][4 * g + 1] * scale);
-                    w[1] = pack_bf16x2(dq[j][db][4 * g + 2] * scale, dq[j][db][4 * g + 3] * scale);
-                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
+                for (int gp = 0; gp < 2; ++gp) {          // 16-byte stores: common.h pair_rows8
+                    u32x2_t w[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int g = 2 * gp + e;
+                        w[e][0] = pack_bf16x2(dq[j][db][4 * g] * scale, dq[j][db][4 * g + 1] * scale);
+                        w[e][1] = pack_bf16x2(dq[j][db][4 * g + 2] * scale, dq[j][db][4 * g + 3] * scale);
+                    }
+                    *reinterpret_cast<u32x4_t*>(op + db * 32 + 8 * (2 * gp + hi)) = pair_rows8(w[0], w[1]);
                 }
         }
     }
@@ -328,16 +332,24 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float x[4];
+                for (int gp = 0; gp < 2; ++gp) {          // 16-byte stores of the output (8-byte ones of its res8 bytes): common.h pair_rows8
+                    u32x2_t w[2], rw[2];
+                    uint32_t rb[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] = o[j][db][4 * g + i] * inv;
-                    u32x2_t w;
-                    w[0] = pack_bf16x2(x[0], x[1]);
-                    w[1] = pack_bf16x2(x[2], x[3]);
-                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
-                    if (res_kind == VGPA_RES_8) *reinterpret_cast<uint32_t*>((uint8_t*)ORES + ro + db * 32 + 8 * g + 4 * hi) = res8_pack4(x, w);
-                    else if (res_kind == VGPA_RES_BF16) *reinterpret_cast<u32x2_t*>((bf16_t*)ORES + ro + db * 32 + 8 * g + 4 * hi) = w1_residual4(x, w);
+                    for (int e = 0; e < 2; ++e) {
+                        const int g = 2 * gp + e;
+                        float x[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) x[i] = o[j][db][4 * g + i] * inv;
+                        w[e][0] = pack_bf16x2(x[0], x[1]);
+                        w[e][1] = pack_bf16x2(x[2], x[3]);
+                        if (res_kind == VGPA_RES_8) rb[e] = res8_pack4(x, w[e]);
+                        else if (res_kind == VGPA_RES_BF16) rw[e] = w1_residual4(x, w[e]);
+                    }
+                    const int d0 = db * 32 + 8 * (2 * gp + hi);
+                    *reinterpret_cast<u32x4_t*>(op + d0) = pair_rows8(w[0], w[1]);
+                    if (res_kind == VGPA_RES_8) *reinterpret_cast<u32x2_t*>((uint8_t*)ORES + ro + d0) = pair_rows8_dword(rb[0], rb[1]);
+                    else if (res_kind == VGPA_RES_BF16) *reinterpret_cast<u32x4_t*>((bf16_t*)ORES + ro + d0) = pair_rows8(rw[0], rw[1]);
                 }
             if (hi == 0) LSE2[(int64_t)bh * S + q] = -nm[j] + __builtin_amdgcn_logf(l[j]);  // v_log_f32 is log2
         }
@@ -498,14 +510,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_w1_kernel(const bf16_t* _
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2_t w;
-                    w[0] = pack_bf16x2(dk[j][db][4 * g] * kscale, dk[j][db][4 * g + 1] * kscale);
-                    w[1] = pack_bf16x2(dk[j][db][4 * g + 2] * kscale, dk[j][db][4 * g + 3] * kscale);
-                    *reinterpret_cast<u32x2_t*>(kp + db * 32 + 8 * g + 4 * hi) = w;
-                    w[0] = pack_bf16x2(dv[j][db][4 * g], dv[j][db][4 * g + 1]);
-                    w[1] = pack_bf16x2(dv[j][db][4 * g + 2], dv[j][db][4 * g + 3]);
-                    *reinterpret_cast<u32x2_t*>(vp + db * 32 + 8 * g + 4 * hi) = w;
+                for (int gp = 0; gp < 2; ++gp) {          // 16-byte stores: common.h pair_rows8
+                    u32x2_t wk[2], wv[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int g = 2 * gp + e;
+                        wk[e][0] = pack_bf16x2(dk[j][db][4 * g] * kscale, dk[j][db][4 * g + 1] * kscale);
+                        wk[e][1] = pack_bf16x2(dk[j][db][4 * g + 2] * kscale, dk[j][db][4 * g + 3] * kscale);
+                        wv[e][0] = pack_bf16x2(dv[j][db][4 * g], dv[j][db][4 * g + 1]);
+                        wv[e][1] = pack_bf16x2(dv[j][db][4 * g + 2], dv[j][db][4 * g + 3]);
+                    }
+                    *reinterpret_cast<u32x4_t*>(kp + db * 32 + 8 * (2 * gp + hi)) = pair_rows8(wk[0], wk[1]);
+                    *reinterpret_cast<u32x4_t*>(vp + db * 32 + 8 * (2 * gp + hi)) = pair_rows8(wv[0], wv[1]);
                 }
         }
     }

@@ -96,6 +96,23 @@ __device__ __forceinline__ void unpack8_res8(const u32x4_t v, const u32x2_t r, f
     }
 }
 
+// ---- 16-byte epilogue stores ---------------------------------------------------------------------------------------------------------
+// A column of a 32x32 accumulator block lives in the lane pair (l, l + 32): of every 8-row group g, lane l holds rows 8g + 0..3 and lane l + 32 rows
+// 8g + 4..7 -- 8 bytes of bf16 each, which made every epilogue a string of 8-byte stores.  Given the packed rows of an EVEN group and of the ODD group after
+// it, one v_permlane32_swap per dword leaves the lower lane with all eight rows of the even group and the upper lane with all eight of the odd group: one
+// 16-byte row-contiguous store per lane at row 8 (g_even + hi) instead of two 8-byte ones.  The attention epilogues' store tail is ISSUE-bound
+// (MI355X_MICROARCH.md, "attention epilogue store tail": half as many, twice as wide stores halve it).  Both lanes of a pair must be active.
+__device__ __forceinline__ u32x4_t pair_rows8(u32x2_t even, u32x2_t odd) {
+    const auto a = __builtin_amdgcn_permlane32_swap(even[0], odd[0], false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(even[1], odd[1], false, false);
+    return u32x4_t{a[0], b[0], a[1], b[1]};
+}
+// the same for one dword per group (the four res8 bytes of its rows): 8 bytes per lane
+__device__ __forceinline__ u32x2_t pair_rows8_dword(uint32_t even, uint32_t odd) {
+    const auto a = __builtin_amdgcn_permlane32_swap(even, odd, false, false);
+    return u32x2_t{a[0], a[1]};
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
