@@ -293,6 +293,8 @@ class DqLoop:
         # the first half-step's transposed fragments: tile "-1" = ring slot 3 (zero-filled by the caller), key block 0
         for f in range(4):
             self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1dq_loop_%=:")
         for ph in range(4):
             # tile i (ring slot ph) must have landed for every wave.  Every read of tile i-2's slot has been waited for by its
@@ -452,6 +454,8 @@ class DkvLoop:
             em.raw(f"v_mov_b32 v{r}, 0")
         for f in range(4):
             self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1dkv_loop_%=:")
         for ph in range(4):
             em.raw("s_waitcnt vmcnt(5)")
@@ -606,6 +610,8 @@ class FwdLoop:
         for f in range(4):
             self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
         em.raw("s_memtime %[c0]")
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1fwd_loop_%=:")
         for ph in range(4):
             em.raw("s_waitcnt vmcnt(4)")
@@ -755,6 +761,8 @@ class Fwd128Loop:
                 em.raw(f"v_mov_b32 v{96 + 16 * j + r}, v{136 + j}")
         for f in range(4):
             self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1f128_loop_%=:")
         for ph in range(4):
             em.raw("s_waitcnt vmcnt(8)")
@@ -912,6 +920,8 @@ class Fwd128F8Loop:
                 em.raw(f"v_mov_b32 v{self.T0 + 16 * j + r}, v{self.NEGM + j}")
         for f in range(4):
             self.issue_frag(em, f, 0, 2, tag=("n", f))
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1f8_loop_%=:")
         for ph in range(4):
             em.raw("s_waitcnt vmcnt(0)")
@@ -1068,6 +1078,8 @@ class Dkv128Loop:
             em.raw(f"v_mov_b32 v{r}, 0")
         for f in range(4):
             self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1dkv128_loop_%=:")
         for ph in range(4):
             em.raw("s_waitcnt vmcnt(9)")
@@ -1196,6 +1208,8 @@ class Dq128Loop:
             em.raw(f"v_mov_b32 v{r}, 0")
         for f in range(4):
             self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1dq128_loop_%=:")
         for ph in range(4):
             em.raw("s_waitcnt vmcnt(8)")
@@ -1333,6 +1347,8 @@ class Dq128x2Loop:
             em.raw(f"v_mov_b32 v{r}, 0")
         for f in range(4):
             self.issue_frag(em, f, 0, 0, 3, 0, tag=("n", f))
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1dq128x2_loop_%=:")
         for ph in range(4):
             em.raw("s_waitcnt vmcnt(8)")
@@ -1391,6 +1407,8 @@ class GemmLoop:
         em.raw(f"s_mov_b32 {CNT}, {NITER}")
         for i in range(128):
             em.raw(f"v_accvgpr_write_b32 a{i}, 0")
+        for _ in range(KNOB.get("pad4", 0)):      # placement experiment: shift the loop body by 4 bytes per unit (MI355X_MICROARCH.md "code-placement sensitivity")
+            em.raw("s_nop 0")
         em.raw("L_w1gemm_loop_%=:")
         for st in range(3):
             # stage `st` landed for every wave (this wave's 12 pieces of the NEXT stage may still fly); everyone is past stage st-1
