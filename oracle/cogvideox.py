@@ -381,12 +381,15 @@ def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, 
 
 
 def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta=1.0, lora_scale=2.0, round_p_ds=False, round_activations=False,
-                  exact_delta=False):
+                  exact_delta=False, cond=None):
     """One preference-pair step as train/CogVideoX-5B/03_train.py:116-157 does it.
 
     x_win/x_lose arrive as the dataset stores them, [B,C,F,H,W] (train/dataset.py:228-229), and are
     permuted to [B,F,C,H,W] (:120-121); win and lose share (t, noise) (:125-130); ref = same base
-    weights without the adapter (:110-111,149-151)."""
+    weights without the adapter (:110-111,149-151).
+    cond [B,F,Cc,H,W] (I2V, train/CogVideoX-I2V-5B/03_train.py:127-136): conditioning channels concatenated to BOTH noised latents after the
+    noising (the zero-padded first-frame latent); the v-targets stay those of the 16 video channels.  The CogVideoX1.5 step (:118-186) is this
+    function on a cfg with patch_size_t set and latents already even-cropped."""
     from . import dpo, scheduler
     xw = x_win.permute(0, 2, 1, 3, 4)
     xl = x_lose.permute(0, 2, 1, 3, 4)
@@ -395,6 +398,8 @@ def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta
     kw = dict(round_p_ds=round_p_ds, round_activations=round_activations, exact_delta=exact_delta)
     if round_activations:       # csrc/noise.hip: x_t and the v-target are bf16 tensors
         xw_n, xl_n = _rv(xw_n), _rv(xl_n)
+    if cond is not None:
+        xw_n, xl_n = torch.cat([xw_n, cond.to(xw_n.dtype)], dim=2), torch.cat([xl_n, cond.to(xl_n.dtype)], dim=2)
     v_w = forward(sd, cfg, xw_n, prompt_emb, t, lora, lora_scale, **kw)
     v_l = forward(sd, cfg, xl_n, prompt_emb, t, lora, lora_scale, **kw)
     with torch.no_grad():
