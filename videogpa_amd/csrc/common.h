@@ -160,6 +160,34 @@ __device__ __forceinline__ void store8(void* base, size_t idx, const float* f) {
         p[1] = make_float4(f[4], f[5], f[6], f[7]);
     }
 }
+// Eight consecutive elements AS LOADED (no conversion): `Raw8<DT> r; r.load(base, idx)` for every chunk of a row first, `r.get(f)` when the values are
+// needed.  A row kernel written as `if (in range) { load8(...); use }` per chunk gets an s_waitcnt behind every chunk's loads from hipcc -- one HBM round
+// trip per chunk and wave; with the loads in a loop of their own (and the conversion, which is a USE, kept out of it) they leave back to back.
+template <int DT>
+struct Raw8;
+template <>
+struct Raw8<VGPA_DTYPE_BF16> {
+    u32x4_t a;
+    __device__ __forceinline__ void load(const void* base, size_t idx, bool in) {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        a = in ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(base) + idx) : z;
+    }
+    __device__ __forceinline__ void get(float* f) const { unpack8(a, f); }
+};
+template <>
+struct Raw8<VGPA_DTYPE_F32> {
+    f32x4_t a, b;
+    __device__ __forceinline__ void load(const void* base, size_t idx, bool in) {
+        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t* p = reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(base) + idx);
+        a = in ? p[0] : z;
+        b = in ? p[1] : z;
+    }
+    __device__ __forceinline__ void get(float* f) const {
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+    }
+};
+
 template <int DT>
 __device__ __forceinline__ float load1(const void* base, size_t idx) {
     if (DT == VGPA_DTYPE_BF16) return bf16_to_f32(reinterpret_cast<const bf16_t*>(base)[idx]);

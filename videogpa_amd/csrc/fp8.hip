@@ -87,6 +87,16 @@ __global__ __launch_bounds__(256) void gelu_q8_kernel(const bf16_t* __restrict__
     __shared__ float smem[4];
     const int64_t row = blockIdx.x;
     const bf16_t* ur = u + (size_t)row * K;
+    // all loads of the row first, in a loop of their own: as `if (i0 < K) { load; use }` per chunk the forward's loads each got an s_waitcnt vmcnt(0)
+    // behind them (one HBM round trip per chunk and wave)
+    const u32x4_t z4 = {0u, 0u, 0u, 0u};
+    u32x4_t ua[Q8_NV], ga[BWD ? Q8_NV : 1];
+#pragma unroll
+    for (int c = 0; c < Q8_NV; ++c) {
+        const int i0 = (c * 256 + (int)threadIdx.x) * 8;
+        ua[c] = i0 < K ? *reinterpret_cast<const u32x4_t*>(ur + i0) : z4;
+        if (BWD) ga[c] = i0 < K ? *reinterpret_cast<const u32x4_t*>(dy + ((size_t)row * K + i0)) : z4;
+    }
     float v[Q8_NV][8];
     float amax = 0.f;
 #pragma unroll
@@ -94,8 +104,8 @@ __global__ __launch_bounds__(256) void gelu_q8_kernel(const bf16_t* __restrict__
         const int i0 = (c * 256 + (int)threadIdx.x) * 8;
         if (i0 < K) {
             float a[8], g[8];
-            load8<VGPA_DTYPE_BF16>(ur, (size_t)i0, a);
-            if (BWD) load8<VGPA_DTYPE_BF16>(dy + (size_t)row * K, (size_t)i0, g);
+            unpack8(ua[c], a);
+            if (BWD) unpack8(ga[c], g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float x = a[j], x2 = x * x, sg = q8_gelu_sig(x, x2);

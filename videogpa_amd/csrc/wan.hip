@@ -65,11 +65,24 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_fwd_kernel(const vo
     const int lane = threadIdx.x & 63;
     float v[WAN_NV][8];
     float sum = 0.f;
+    // the row's HBM loads first, in a loop of their own (common.h Raw8); the modulation / affine tables further down are L2 hits shared by every row.
+    // Measured per form (tools/wan_row_bench.py, one session): the plain form 145 -> 136 us at 36 960 x 3072; the GR form, which also holds the branch output
+    // and writes x', LOSES (286 -> 297 us: 174 registers, two waves per SIMD) and keeps its loads next to their use.
+    constexpr bool HOIST = !GR;
+    Raw8<XDT> xr[HOIST ? WAN_NV : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int c = 0; c < WAN_NV; ++c) {
+            const int i0 = (c * 64 + lane) * 8;
+            xr[c].load(x, (size_t)row * D + i0, i0 < D);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
-            load8<XDT>(x, (size_t)row * D + i0, v[c]);
+            if constexpr (HOIST) xr[c].get(v[c]);
+            else load8<XDT>(x, (size_t)row * D + i0, v[c]);
             if (GR) {
                 float a[8], gt[8];
                 load8<VGPA_DTYPE_BF16>(yres, (size_t)row * D + i0, a);
@@ -141,6 +154,7 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_ln_mod_bwd_kernel(const vo
     const size_t g = gid ? (size_t)gid[row] * mod_stride : 0;
     float gy[WAN_NV][8], xh[WAN_NV][8];
     float s1 = 0.f, s2 = 0.f;
+    // (loads next to their use: hoisting both operands of the row -- common.h Raw8 -- measured SLOWER here, 359 -> 379 us at 36 960 x 3072: 178 registers)
 #pragma unroll
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
@@ -235,11 +249,14 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_gate_bwd_q8_kernel(const f
     const int lane = threadIdx.x & 63;
     const float* gp = gate ? gate + (gid ? (size_t)gid[row] * mod_stride : 0) : nullptr;
     float v[WAN_NV][8];
+    Raw8<VGPA_DTYPE_F32> dr[WAN_NV];          // the row's HBM loads first (common.h Raw8)
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) dr[c].load(dout, (size_t)row * D + (c * 64 + lane) * 8, (c * 64 + lane) * 8 < D);
 #pragma unroll
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
-            load8<VGPA_DTYPE_F32>(dout, (size_t)row * D + i0, v[c]);
+            dr[c].get(v[c]);
             float gt[8];
             if (gp) load8<VGPA_DTYPE_F32>(gp, (size_t)i0, gt);
 #pragma unroll
@@ -258,33 +275,48 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_fwd_kernel(const 
     const int64_t row = wan_row();
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    float v[WAN_NV][8];
+    // Every load of the row is issued before anything is used.  Written as `if (i0 < D) { load; use }` per chunk, hipcc put an s_waitcnt vmcnt(0) behind
+    // each load (one HBM round trip per 1 KiB chunk and wave: 3.1 TB/s at 36 960 x 3072); with the loads in a loop of their own they leave back to back.
+    const u32x4_t z4 = {0u, 0u, 0u, 0u};
+    u32x4_t raw[WAN_NV];
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        raw[c] = i0 < D ? *reinterpret_cast<const u32x4_t*>(u + ((size_t)row * ld_u + i0)) : z4;
+    }
+    const size_t tr = (size_t)(row % L) * half;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
-            load8<VGPA_DTYPE_BF16>(u, (size_t)row * ld_u + i0, v[c]);
+            float v[8];
+            unpack8(raw[c], v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sq += v[c][j] * v[c][j];
+            for (int j = 0; j < 8; ++j) sq += v[j] * v[j];
         }
     }
     const float rs = rsqrtf(wave_sum(sq) / (float)D + eps);
     if (lane == 0 && rstd_out) rstd_out[row] = rs;
-    const size_t tr = (size_t)(row % L) * half;
 #pragma unroll
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
-            float wv[8], o[8];
-            load8<VGPA_DTYPE_BF16>(w, (size_t)i0, wv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = round_bf16(round_bf16(v[c][j] * rs) * wv[j]);
+            float v[8], wv[8], o[8];
+            unpack8(raw[c], v);
+            load8<VGPA_DTYPE_BF16>(w, (size_t)i0, wv);          // the weight and the table rows are L2 hits, shared by every row
+            f32x4_t cs4, sn4;
             if (rope_cos) {
-                const int p0 = (i0 % (2 * half)) / 2;     // first pair of these 8 elements inside its head
+                const int p0 = (i0 % (2 * half)) / 2;     // first pair of these 8 elements inside its head: a multiple of 4 -> 16-byte aligned table reads
+                cs4 = *reinterpret_cast<const f32x4_t*>(rope_cos + tr + p0);
+                sn4 = *reinterpret_cast<const f32x4_t*>(rope_sin + tr + p0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = round_bf16(round_bf16(v[j] * rs) * wv[j]);
+            if (rope_cos) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    const float cs = rope_cos[tr + p0 + j / 2], sn = rope_sin[tr + p0 + j / 2];
+                    const float cs = cs4[j / 2], sn = sn4[j / 2];
                     const float a = o[j], bb = o[j + 1];
                     o[j] = a * cs - bb * sn;
                     o[j + 1] = a * sn + bb * cs;
@@ -306,13 +338,20 @@ __global__ __launch_bounds__(64 * WAN_WAVES) void wan_rms_rope_bwd_kernel(const 
     const size_t tr = (size_t)(row % L) * half;
     float dn[WAN_NV][8], n[WAN_NV][8];
     float s = 0.f;
+    Raw8<VGPA_DTYPE_BF16> dr[WAN_NV], ur[WAN_NV];          // the row's HBM loads first (common.h Raw8)
+#pragma unroll
+    for (int c = 0; c < WAN_NV; ++c) {
+        const int i0 = (c * 64 + lane) * 8;
+        dr[c].load(dout, (size_t)row * ld_dout + i0, i0 < D);
+        ur[c].load(u, (size_t)row * ld_u + i0, i0 < D);
+    }
 #pragma unroll
     for (int c = 0; c < WAN_NV; ++c) {
         const int i0 = (c * 64 + lane) * 8;
         if (i0 < D) {
             float wv[8];
-            load8<VGPA_DTYPE_BF16>(dout, (size_t)row * ld_dout + i0, dn[c]);
-            load8<VGPA_DTYPE_BF16>(u, (size_t)row * ld_u + i0, n[c]);
+            dr[c].get(dn[c]);
+            ur[c].get(n[c]);
             load8<VGPA_DTYPE_BF16>(w, (size_t)i0, wv);
             if (rope_cos) {
                 const int p0 = (i0 % (2 * half)) / 2;
