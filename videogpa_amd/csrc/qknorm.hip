@@ -35,10 +35,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
     const int c8 = (int)(gid & 7);
     if (vid >= 2 * nvec) return;  // whole 8-lane groups exit together (2*nvec*8 is a multiple of 8)
     const int which = vid >= nvec;
-    int64_t r = which ? vid - nvec : vid;
-    const int h = (int)(r % H); r /= H;
-    const int s = (int)(r % S);
-    const int b = (int)(r / S);
+    // (token, head) index split in 32-bit arithmetic (the launcher guarantees 2 * nvec < 2^31): a 64-bit divide is ~100 VALU instructions per thread.
+    // Measured (tools/qknorm_bench.py, one session): backward 243 -> 238 us at the cfg2 shape, forward unchanged -- the kernels are bandwidth-bound
+    uint32_t r = (uint32_t)(which ? vid - nvec : vid);
+    const int h = (int)(r % (uint32_t)H); r /= (uint32_t)H;
+    const int s = (int)(r % (uint32_t)S);
+    const int b = (int)(r / (uint32_t)S);
     const bf16_t* ip = which ? (k_in + b * si_k.b + h * si_k.h + (int64_t)s * si_k.s) : (q_in + b * si_q.b + h * si_q.h + (int64_t)s * si_q.s);
     bf16_t* op = which ? (k_out + b * so_k.b + h * so_k.h + (int64_t)s * so_k.s) : (q_out + b * so_q.b + h * so_q.h + (int64_t)s * so_q.s);
     const float* w = which ? wk : wq;
@@ -96,10 +98,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
     const int c8 = (int)(gid & 7);
     if (vid >= 2 * nvec) return;
     const int which = vid >= nvec;
-    int64_t r = which ? vid - nvec : vid;
-    const int h = (int)(r % H); r /= H;
-    const int s = (int)(r % S);
-    const int b = (int)(r / S);
+    // (token, head) index split in 32-bit arithmetic (the launcher guarantees 2 * nvec < 2^31): a 64-bit divide is ~100 VALU instructions per thread.
+    // Measured (tools/qknorm_bench.py, one session): backward 243 -> 238 us at the cfg2 shape, forward unchanged -- the kernels are bandwidth-bound
+    uint32_t r = (uint32_t)(which ? vid - nvec : vid);
+    const int h = (int)(r % (uint32_t)H); r /= (uint32_t)H;
+    const int s = (int)(r % (uint32_t)S);
+    const int b = (int)(r / (uint32_t)S);
     const QStride sg = which ? sg_k : sg_q, si = which ? si_k : si_q, sd = which ? sd_k : sd_q;
     const bf16_t* gp = (which ? dk_out : dq_out) + b * sg.b + h * sg.h + (int64_t)s * sg.s;
     const bf16_t* ip = (which ? k_in : q_in) + b * si.b + h * si.h + (int64_t)s * si.s;
@@ -169,6 +173,7 @@ int32_t vgpa_qknorm_rope_fwd(const void* q_in, const void* k_in, void* q_out, vo
     if (!qs_ok(qin_strides) || !qs_ok(kin_strides) || !qs_ok(qout_strides) || !qs_ok(kout_strides)) return VGPA_ERR_INVALID;
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S || (rope_mode != 0 && rope_mode != 1)) return VGPA_ERR_INVALID;
     const int64_t threads = 2 * B * S * H * 8;
+    if (2 * B * S * H >= ((int64_t)1 << 31) || threads / 256 >= ((int64_t)1 << 31)) return VGPA_ERR_INVALID;      // the kernels split the vector index in 32 bits
     VGPA_LAUNCH(qknorm_rope_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)q_in,
                        (const bf16_t*)k_in, (bf16_t*)q_out, (bf16_t*)k_out, qmk(qin_strides), qmk(kin_strides), qmk(qout_strides),
                        qmk(kout_strides), wq, bq, wk, bk, rope_cos, rope_sin, (int)text_len, (int)B, (int)H, (int)S, eps, q_out_scale, (int)rope_mode);
@@ -187,6 +192,7 @@ int32_t vgpa_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void*
         return VGPA_ERR_INVALID;
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || text_len < 0 || text_len > S || (rope_mode != 0 && rope_mode != 1)) return VGPA_ERR_INVALID;
     const int64_t threads = 2 * B * S * H * 8;
+    if (2 * B * S * H >= ((int64_t)1 << 31) || threads / 256 >= ((int64_t)1 << 31)) return VGPA_ERR_INVALID;
     VGPA_LAUNCH(qknorm_rope_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dq_out,
                        (const bf16_t*)dk_out, (const bf16_t*)q_in, (const bf16_t*)k_in, (bf16_t*)dq_in, (bf16_t*)dk_in, qmk(dqout_strides),
                        qmk(dkout_strides), qmk(qin_strides), qmk(kin_strides), qmk(dqin_strides), qmk(dkin_strides), wq, wk, rope_cos,
