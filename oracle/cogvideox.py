@@ -261,20 +261,26 @@ class _RoundedSDPA(torch.autograd.Function):
     CHUNK = 4
 
     @staticmethod
-    def forward(ctx, q, k, v, round_o=False):
-        """round_o: the output is rounded to bf16 HERE, so that the backward's delta = rowsum(dO o O) is formed from the STORED bf16 output, as every
+    def forward(ctx, q, k, v, round_o=False, round_pds=True):
+        """round_pds=False: NO rounding at all -- exact softmax(q k^T / sqrt(d)) v in the oracle's precision, head-chunked and recomputed in the
+        backward so that the S x S matrix of a 17 776-token sequence (60 GB in fp32 over 48 heads) never exists (`chunked_attention` of forward();
+        the full-depth parity tests).  Checked against F.scaled_dot_product_attention in tests/test_oracle_kat.py.
+        round_o: the output is rounded to bf16 HERE, so that the backward's delta = rowsum(dO o O) is formed from the STORED bf16 output, as every
         flash-attention backward does (csrc/attention*.hip `attn_delta` / `w1_bwd_prep`, and torch's own bf16 kernels).  That matters: the identity
         rowsum(P o dP) = rowsum(dO o O) behind delta holds for the unrounded O = P V only; with the rounded O each row's dS no longer sums to zero,
         and dQ_i picks up -d(delta_i) * sum_j P_ij K_j -- a COHERENT term, not a random one, which dominates the heavily cancelling q / k gradients of
         the last block (measured: tools/cfg1_round_diag.py, profiles/r04_cfg1_round_diag_*.json)."""
         scale = q.shape[-1] ** -0.5
         o = torch.empty_like(q)
+        rp = (lambda x: x.bfloat16().to(x.dtype)) if round_pds else (lambda x: x)
         for h0 in range(0, q.shape[1], _RoundedSDPA.CHUNK):
             sl = slice(h0, h0 + _RoundedSDPA.CHUNK)
             p = torch.softmax((q[:, sl] @ k[:, sl].transpose(-1, -2)) * scale, dim=-1)
-            o[:, sl] = p.bfloat16().to(p.dtype) @ v[:, sl]
+            o[:, sl] = rp(p) @ v[:, sl]
+            del p
         if round_o:
             o = o.bfloat16().to(o.dtype)
+        ctx.round_pds = round_pds
         ctx.save_for_backward(q, k, v, o)
         return o
 
@@ -283,19 +289,23 @@ class _RoundedSDPA(torch.autograd.Function):
         q, k, v, o = ctx.saved_tensors
         scale = q.shape[-1] ** -0.5
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        rp = (lambda x: x.bfloat16().to(x.dtype)) if ctx.round_pds else (lambda x: x)
         for h0 in range(0, q.shape[1], _RoundedSDPA.CHUNK):
             sl = slice(h0, h0 + _RoundedSDPA.CHUNK)
             p = torch.softmax((q[:, sl] @ k[:, sl].transpose(-1, -2)) * scale, dim=-1)
             delta = (do[:, sl] * o[:, sl]).sum(-1, keepdim=True)
-            ds = (p * (do[:, sl] @ v[:, sl].transpose(-1, -2) - delta)).bfloat16().to(p.dtype)
-            dv[:, sl] = p.bfloat16().to(p.dtype).transpose(-1, -2) @ do[:, sl]
+            dv[:, sl] = rp(p).transpose(-1, -2) @ do[:, sl]
+            ds = (do[:, sl] @ v[:, sl].transpose(-1, -2)).sub_(delta).mul_(p)
+            del p
+            ds = rp(ds)
             dq[:, sl] = (ds @ k[:, sl]) * scale
             dk[:, sl] = (ds.transpose(-1, -2) @ q[:, sl]) * scale
-        return dq, dk, dv, None
+            del ds
+        return dq, dk, dv, None, None
 
 
 def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_rotary_emb=None, capture=None, round_p_ds=False, rnd=False,
-                  exact_delta=False):
+                  exact_delta=False, chunked=False):
     b = f"transformer_blocks.{i}."
     Lt = enc.shape[1]
     H, hd = cfg.num_attention_heads, cfg.attention_head_dim
@@ -329,7 +339,12 @@ def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_r
         # csrc/qknorm.hip folds scale * log2(e) into q before its one rounding; the attention kernels return dq for the UNSCALED q, as bf16
         c = hd ** -0.5 * 1.4426950408889634
         q, k = _rg(_rv(q * c) / c), _r(k)
-    o = _RoundedSDPA.apply(q, k, v, rnd and not exact_delta) if (round_p_ds or rnd) else F.scaled_dot_product_attention(q, k, v)
+    if round_p_ds or rnd:
+        o = _RoundedSDPA.apply(q, k, v, rnd and not exact_delta)
+    elif chunked:
+        o = _RoundedSDPA.apply(q, k, v, False, False)        # exact arithmetic, memory-bounded
+    else:
+        o = F.scaled_dot_product_attention(q, k, v)
     o = _r(o.transpose(1, 2).reshape(B, -1, H * hd), rnd)
     if capture is not None:
         capture.update(q=q, k=k, v=v, attn=o)
@@ -347,8 +362,11 @@ def block_forward(sd, cfg, i, hid, enc, temb, lora=None, lora_scale=2.0, image_r
 
 
 def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, lora_scale=2.0,
-            image_rotary_emb=None, round_p_ds=False, round_activations=False, exact_delta=False):
+            image_rotary_emb=None, round_p_ds=False, round_activations=False, exact_delta=False, checkpoint_blocks=False, chunked_attention=False):
     """hidden_states [B,F,C,H,W], encoder_hidden_states [B,L,4096], timestep [B] -> sample [B,F,C_out,H,W].
+    checkpoint_blocks: each transformer block under torch.utils.checkpoint (non-reentrant), as the reference trains
+    (train/CogVideoX-5B/03_train.py:107-108) -- same values, one block's intermediates alive at a time; chunked_attention: the exact attention without
+    the S x S matrix (see _RoundedSDPA round_pds=False).  Together they let the fp32 oracle run all 42 blocks at S = 17 776 on one 288 GB GPU.
     round_activations: see "activation-rounded mode" above (implies round_p_ds).  exact_delta (with round_activations): the attention backward's
     delta is formed from the UNROUNDED attention output -- the one place where the stored bf16 tensor is not what a precise backward wants."""
     B, Fr, C, H, W = hidden_states.shape
@@ -364,7 +382,14 @@ def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, 
     Lt = encoder_hidden_states.shape[1]
     enc, hid = x[:, :Lt], x[:, Lt:]
     for i in range(cfg.num_layers):
-        hid, enc = block_forward(sd, cfg, i, hid, enc, emb, lora, lora_scale, image_rotary_emb, round_p_ds=round_p_ds, rnd=rnd, exact_delta=exact_delta)
+        def blk(hid, enc, i=i):
+            return block_forward(sd, cfg, i, hid, enc, emb, lora, lora_scale, image_rotary_emb, round_p_ds=round_p_ds, rnd=rnd, exact_delta=exact_delta,
+                                 chunked=chunked_attention)
+        if checkpoint_blocks and torch.is_grad_enabled() and lora is not None:
+            from torch.utils.checkpoint import checkpoint
+            hid, enc = checkpoint(blk, hid, enc, use_reentrant=False)
+        else:
+            hid, enc = blk(hid, enc)
 
     hid = _r(layer_norm(torch.cat([enc, hid], dim=1), sd["norm_final.weight"], sd["norm_final.bias"], cfg.norm_eps), rnd)[:, Lt:]
     m = _r(F.linear(_r(F.silu(emb), rnd), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"]), rnd)
@@ -381,7 +406,7 @@ def forward(sd, cfg, hidden_states, encoder_hidden_states, timestep, lora=None, 
 
 
 def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta=1.0, lora_scale=2.0, round_p_ds=False, round_activations=False,
-                  exact_delta=False, cond=None):
+                  exact_delta=False, cond=None, checkpoint_blocks=False, chunked_attention=False):
     """One preference-pair step as train/CogVideoX-5B/03_train.py:116-157 does it.
 
     x_win/x_lose arrive as the dataset stores them, [B,C,F,H,W] (train/dataset.py:228-229), and are
@@ -395,7 +420,8 @@ def dpo_pair_step(sd, cfg, lora, abar, x_win, x_lose, prompt_emb, t, noise, beta
     xl = x_lose.permute(0, 2, 1, 3, 4)
     xw_n = scheduler.add_noise(abar, xw, noise, t)
     xl_n = scheduler.add_noise(abar, xl, noise, t)
-    kw = dict(round_p_ds=round_p_ds, round_activations=round_activations, exact_delta=exact_delta)
+    kw = dict(round_p_ds=round_p_ds, round_activations=round_activations, exact_delta=exact_delta, checkpoint_blocks=checkpoint_blocks,
+              chunked_attention=chunked_attention)
     if round_activations:       # csrc/noise.hip: x_t and the v-target are bf16 tensors
         xw_n, xl_n = _rv(xw_n), _rv(xl_n)
     if cond is not None:

@@ -268,3 +268,41 @@ def test_wan_oracle_rounded_mode_stays_close_to_plain_and_passes_gradients_to_ev
     oa, _ = run(round_activations=True, exact_delta=True)
     ob, _ = run(round_activations=True, exact_delta=False)
     assert torch.equal(oa, ob)
+
+
+def test_checkpointed_chunked_oracle_equals_the_plain_one():
+    """The memory-bounded form of the oracle the full-depth GPU parity tests run (tests/test_gpu_depth.py: per-block torch.utils.checkpoint as
+    train/CogVideoX-5B/03_train.py:107-108 + the head-chunked exact attention) is the SAME function as the plain one: loss and every adapter
+    gradient agree to fp64 round-off; the chunked attention alone agrees with F.scaled_dot_product_attention forward and backward."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(2, 6, 37, 64, generator=g).double().requires_grad_(True) for _ in range(3))
+    do = torch.randn(2, 6, 37, 64, generator=g).double()
+    ref = F.scaled_dot_product_attention(q, k, v)
+    gr = torch.autograd.grad(ref, (q, k, v), do)
+    got = ocv._RoundedSDPA.apply(q, k, v, False, False)
+    gg = torch.autograd.grad(got, (q, k, v), do)
+    assert float((got - ref).abs().max()) < 1e-13
+    for a, b in zip(gg, gr):
+        assert float((a - b).abs().max()) < 1e-12
+
+    cfg = tiny_cfg(num_layers=3)
+    sd = ocv.init_state_dict(cfg, dtype=torch.float64, mod_std=0.3)
+    abar = osch.alphas_cumprod()
+    xw = torch.randn(1, 16, 3, 8, 8, generator=g).double()
+    xl = torch.randn(1, 16, 3, 8, 8, generator=g).double()
+    txt = torch.randn(1, 6, cfg.text_embed_dim, generator=g).double()
+    t = torch.tensor([123])
+    eps = torch.randn(1, 3, 16, 8, 8, generator=g).double()
+    res = []
+    for kw in ({}, {"checkpoint_blocks": True, "chunked_attention": True}, {"round_activations": True, "exact_delta": True},
+               {"round_activations": True, "exact_delta": True, "checkpoint_blocks": True}):
+        lora = {n: p.clone().requires_grad_(True) for n, p in ocv.init_lora(cfg, r=4, dtype=torch.float64, b_std=0.05).items()}
+        out = ocv.dpo_pair_step(sd, cfg, lora, abar, xw, xl, txt, t, eps, beta=50.0, **kw)
+        out["loss"].backward()
+        res.append((float(out["loss"].detach()), {n: p.grad.clone() for n, p in lora.items()}))
+    for a, b in ((0, 1), (2, 3)):
+        assert abs(res[a][0] - res[b][0]) < 1e-12
+        for n in res[a][1]:
+            assert float((res[a][1][n] - res[b][1][n]).abs().max()) <= 1e-10 * max(1.0, float(res[a][1][n].abs().max())), n
+    assert abs(res[0][0] - math.log(2.0)) > 1e-4       # the comparison is not the trivial B = 0 point
