@@ -85,6 +85,7 @@ def ti2v_timestep_tensor(timestep, z_shape, seq_len, patch_size=(1, 2, 2)):
     z_dim, f, h, w = z_shape
     mask = torch.ones(f, h, w)
     mask[0] = 0.0
+    timestep = float(timestep)                      # a 0-dim tensor on any device
     ts = (mask[:, ::patch_size[1], ::patch_size[2]] * timestep).flatten()
     return torch.cat([ts, ts.new_ones(seq_len - ts.numel()) * timestep]).unsqueeze(0)
 
@@ -96,13 +97,13 @@ def wan_pair_step(model, ref_model, x_win, x_lose, prompt_emb, t, noise, image_l
     B, C, Fr, H, W = x_win.shape
     seq_len = Fr * (H // patch_size[1]) * (W // patch_size[2])
     sigma = flow_sigma(t, num_train_timesteps, shift)
-    sg = sigma.view(B, 1, 1, 1, 1).to(x_win.dtype)
+    sg = sigma.view(B, 1, 1, 1, 1).to(x_win.device, x_win.dtype)
     xw_n = (1.0 - sg) * x_win + sg * noise
     xl_n = (1.0 - sg) * x_lose + sg * noise
     if image_latent is not None:
         xw_n[:, :, 0:1] = image_latent
         xl_n[:, :, 0:1] = image_latent
-    t_batch = torch.cat([ti2v_timestep_tensor(t[b], (C, Fr, H, W), seq_len, patch_size) for b in range(B)], dim=0)
+    t_batch = torch.cat([ti2v_timestep_tensor(t[b], (C, Fr, H, W), seq_len, patch_size) for b in range(B)], dim=0).to(x_win.device)
     ctx = [prompt_emb[b] for b in range(B)]
     with torch.no_grad():                                                            # reference forwards FIRST (:227-229)
         v_wr = torch.stack(ref_model([xw_n[b] for b in range(B)], t=t_batch, context=ctx, seq_len=seq_len))

@@ -212,8 +212,14 @@ class Params:
     the activation-rounded mode of the module docstring (f8_attn: False, True = the device's forward + consistent backward, "r4" = the round-4 device backward,
     "lq" = an experiment: output normalised by the sum of the quantised weights)."""
 
-    def __init__(self, state, lora=None, dtype=torch.float32, fp8_ffn=False, round_activations=False, exact_delta=True, f8_attn=False, f8_min_keys=1024):
-        self.s = {k: v.detach().to(dtype) for k, v in state.items()}
+    def __init__(self, state, lora=None, dtype=torch.float32, fp8_ffn=False, round_activations=False, exact_delta=True, f8_attn=False, f8_min_keys=1024,
+                 checkpoint_blocks=False, chunked_attention=False):
+        """checkpoint_blocks: every block under torch.utils.checkpoint, as the reference trains (train/Wan2.2-TI2V-5B/03_train.py:151-160) -- same values, one
+        block's intermediates alive at a time; chunked_attention: the exact attention head-chunked and recomputed in the backward (oracle/cogvideox.py
+        _RoundedSDPA with round_pds=False) so that the L x L matrix of an 18 480-token sample never exists.  Together: the full 30-block model in fp32 on one GPU
+        (tests/test_gpu_depth_wan.py; pinned to the plain form in tests/test_oracle_kat.py)."""
+        self.checkpoint_blocks, self.chunked_attention = bool(checkpoint_blocks), bool(chunked_attention)
+        self.s = {k: (v if v.dtype == dtype else v.detach().to(dtype)) for k, v in state.items()}
         self.lora = lora or {}
         self.dtype = dtype
         self.fp8_ffn = fp8_ffn
@@ -256,6 +262,8 @@ def _attend(q, k, v, P=None, self_attn=False):
         else:
             o = _RoundedSDPA.apply(q, k, v, not P.exact_delta)
         return _r(o.transpose(1, 2).flatten(2))
+    if P is not None and P.chunked_attention:
+        return _RoundedSDPA.apply(q, k, v, False, False).transpose(1, 2).flatten(2)
     p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(q.shape[-1]), dim=-1)
     return (p @ v).transpose(1, 2).flatten(2)
 
@@ -328,7 +336,13 @@ def forward(P, cfg, x_list, t, context_list, seq_len):
     dev = xb.device
     freqs = torch.cat([rope_params(1024, d - 4 * (d // 6), device=dev), rope_params(1024, 2 * (d // 6), device=dev), rope_params(1024, 2 * (d // 6), device=dev)], dim=1)
     for i in range(cfg["num_layers"]):
-        x = block(P, f"blocks.{i}", x, e0, n, grid, freqs, ctx, eps, cfg.get("cross_attn_norm", True), first=(i == 0))
+        def blk(x, i=i):
+            return block(P, f"blocks.{i}", x, e0, n, grid, freqs, ctx, eps, cfg.get("cross_attn_norm", True), first=(i == 0))
+        if P.checkpoint_blocks and torch.is_grad_enabled() and P.lora:
+            from torch.utils.checkpoint import checkpoint
+            x = checkpoint(blk, x, use_reentrant=False)
+        else:
+            x = blk(x)
     em = (P["head.modulation"].unsqueeze(0) + e.unsqueeze(2)).chunk(2, dim=2)
     x = P.linear("head.head", layer_norm(x, eps) * (1 + em[1].squeeze(2)) + em[0].squeeze(2), f32=True)
     c = cfg["out_dim"]

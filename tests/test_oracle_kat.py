@@ -306,3 +306,38 @@ def test_checkpointed_chunked_oracle_equals_the_plain_one():
         for n in res[a][1]:
             assert float((res[a][1][n] - res[b][1][n]).abs().max()) <= 1e-10 * max(1.0, float(res[a][1][n].abs().max())), n
     assert abs(res[0][0] - math.log(2.0)) > 1e-4       # the comparison is not the trivial B = 0 point
+
+
+def test_wan_checkpointed_chunked_oracle_equals_the_plain_one():
+    """oracle/wan.py Params(checkpoint_blocks=True, chunked_attention=True) -- the form tests/test_gpu_depth_wan.py runs at 30 blocks -- is the same function
+    as the plain oracle (fp64 round-off), in the plain and in the activation-rounded / e4m3-injected modes."""
+    from oracle import wan as ow
+    st, cfg, g = _wan_toy(layers=3)
+    st = {k: v.double() for k, v in st.items()}
+    x = [torch.randn(4, 3, 16, 24, generator=g).bfloat16().double()]
+    L = 3 * 8 * 12
+    t = torch.full((1, L), 500.0)
+    t[:, :96] = 0
+    ctx = [torch.randn(6, 16, generator=g).bfloat16().double()]
+    gout = torch.randn(4, 3, 16, 24, generator=g).double()
+
+    def run(**kw):
+        gl = torch.Generator().manual_seed(3)
+        lora, leaves = {}, {}
+        for b in range(3):
+            for a in ("self_attn", "cross_attn"):
+                for m in "qkvo":
+                    A = (torch.randn(8, 256, generator=gl) * 0.05).double().requires_grad_(True)
+                    Bm = (torch.randn(256, 8, generator=gl) * 0.05).double().requires_grad_(True)
+                    lora[f"blocks.{b}.{a}.{m}"] = (A, Bm, 2.0)
+                    leaves[f"blocks.{b}.{a}.{m}"] = (A, Bm)
+        out = ow.forward(ow.Params(st, lora, dtype=torch.float64, **kw), cfg, x, t, ctx, L)[0]
+        (out * gout).sum().backward()
+        return out.detach(), {k_: (a.grad.clone(), b_.grad.clone()) for k_, (a, b_) in leaves.items()}
+    for base in ({}, dict(round_activations=True, exact_delta=True), dict(round_activations=True, fp8_ffn=True, f8_attn=True, f8_min_keys=64)):
+        o0, g0 = run(**base)
+        o1, g1 = run(checkpoint_blocks=True, chunked_attention=True, **base)
+        assert float((o0 - o1).abs().max()) <= 1e-11 * max(1.0, float(o0.abs().max())), base
+        for n in g0:
+            for i in range(2):
+                assert float((g0[n][i] - g1[n][i]).abs().max()) <= 1e-9 * max(1.0, float(g0[n][i].abs().max())), (base, n, i)

@@ -494,6 +494,7 @@ extern "C" int32_t vgpa_wan_rms_rope_fwd(const void* u, int64_t ld_u, const void
     if (!u || !w || !out || !wan_dims_ok(rows, D) || (rope_cos == nullptr) != (rope_sin == nullptr)) return VGPA_ERR_INVALID;
     if (ld_u < D || ld_u % 8 || ld_out < D || ld_out % 8) return VGPA_ERR_INVALID;
     if (rope_cos && (L <= 0 || head_dim <= 0 || head_dim % 8 || D % head_dim)) return VGPA_ERR_INVALID;
+    if (rope_cos && (((uintptr_t)rope_cos | (uintptr_t)rope_sin) & 15)) return VGPA_ERR_INVALID;      // the forward reads the tables as 16-byte vectors
     VGPA_LAUNCH(wan_rms_rope_fwd_kernel, wan_grid(rows), dim3(64 * WAN_WAVES), 0, stream, (const bf16_t*)u, (const bf16_t*)w, rope_cos, rope_sin, (int)(rope_cos ? L : 1),
                 (int)(rope_cos ? head_dim / 2 : 1), (int)D, rows, eps, ld_u, (bf16_t*)out, ld_out, rstd);
     VGPA_CHECK_LAUNCH();

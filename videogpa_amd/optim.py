@@ -15,6 +15,7 @@ The exchange is selectable (VGPA_DP_COLLECTIVE, or FlatAdamW(collective=...)):
 Every exchange is bracketed by events on the communication stream and its wait by events on the compute stream: comm_report() gives the
 mean collective duration and the time the compute stream really stalled for it -- what bench.py prints at N > 1.
 """
+import collections
 import math
 import os
 
@@ -81,13 +82,17 @@ class FlatParams:
 class FlatAdamW:
     """AdamW + clip-by-global-norm + (optional) data-parallel mean all-reduce over a FlatParams buffer."""
 
+    COMM_EVENT_RING = 256
+
     def __init__(self, flat: FlatParams, lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0,
                  warmup_steps=500, total_steps=10000, process_group=None, collective=None):
         self.flat = flat
         self.collective = (collective or os.environ.get("VGPA_DP_COLLECTIVE", "all_reduce")).lower()
         if self.collective not in ("all_reduce", "rs_ag"):
             raise ValueError(f"collective / VGPA_DP_COLLECTIVE: all_reduce or rs_ag, got {self.collective!r}")
-        self._comm_events = []      # (start, end) on the communication stream, (before, after) the compute stream's wait: one 4-tuple per exchange
+        # (start, end) on the communication stream, (before, after) the compute stream's wait: one 4-tuple per exchange.  A ring of the last
+        # COMM_EVENT_RING exchanges: only comm_report() (bench.py) drains it, a 10 000-step training run never does and must not collect event handles
+        self._comm_events = collections.deque(maxlen=self.COMM_EVENT_RING)
         self._wait_open = None
         self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -160,7 +165,7 @@ class FlatAdamW:
         """{"collective", "bytes", "exchanges", "allreduce_ms", "exposed_wait_ms"}: means over the exchanges since the last call (synchronises).
         allreduce_ms = duration of the collective on the communication stream; exposed_wait_ms = how long the compute stream stood still at the
         optimizer step waiting for it (0 when the collective had finished under the next micro-step's reference pass)."""
-        evs, self._comm_events = self._comm_events, []
+        evs, self._comm_events = list(self._comm_events), collections.deque(maxlen=self.COMM_EVENT_RING)
         if not evs:
             return None
         torch.cuda.synchronize()

@@ -96,7 +96,8 @@ class CogVideoXDPOTrainer(nn.Module):
             else:
                 self.transformer.enable_gradient_checkpointing()
         self.memory_policy_log = None     # what "auto" decided, and from which numbers (set at the first step)
-        if cfg.get("lean_activations") is True:
+        cfg["lean_activations"] = self._lean_setting(cfg.get("lean_activations", "auto"))
+        if cfg["lean_activations"] is True:
             self.transformer.enable_lean_activations(True)       # this package's transformer only (AttributeError on anything else: say so loudly)
         self.ref_transformer = None
         if separate_ref:  # the reference's layout: a second frozen copy (:110-111)
@@ -119,6 +120,25 @@ class CogVideoXDPOTrainer(nn.Module):
         self._rng = None
         self.after_reference = None     # hook between the frozen-reference pass and the policy pass (set by DPOEngine)
 
+    @staticmethod
+    def _lean_setting(v):
+        """config value -> True / False / "auto": bool-likes (1, 0, "true", "False", ...) mean what they say, anything else but "auto" is an error (a truthy
+        non-bool used to run FULL activations silently)"""
+        if isinstance(v, str):
+            low = v.strip().lower()
+            if low == "auto":
+                return "auto"
+            if low in ("true", "1", "yes", "on"):
+                return True
+            if low in ("false", "0", "no", "off"):
+                return False
+            raise ValueError(f'lean_activations: True, False or "auto", got {v!r}')
+        if v is None:
+            return "auto"
+        if isinstance(v, (bool, int)) and v in (0, 1, True, False):
+            return bool(v)
+        raise ValueError(f'lean_activations: True, False or "auto", got {v!r}')
+
     def rng(self, device):
         """Per-rank generator of the (t, eps) stream: seed + rank, so data-parallel ranks draw different noise
         (Lightning seeds every rank's global generator differently through the DistributedSampler/rank offset)."""
@@ -138,27 +158,36 @@ class CogVideoXDPOTrainer(nn.Module):
                 return self.transformer(hs, encoder_hidden_states=prompt, timestep=tt, return_dict=True).sample
 
     # bytes the backward keeps per token and block (bf16 activations of DESIGN section 3: residual stream x2, LN output + LoRA tail, fused q/k/v, normalised
-    # q and k, attention output + its res8 bytes, FF pre-activation, statistics), full set / lean set, at D = 3072; measured 2.9 / 2.2 GB per block and pair at S = 17 776
+    # q and k, attention output + its res8 bytes, FF pre-activation, statistics), full set / lean set, at D = 3072 with the int8 output residual; measured 2.9 /
+    # 2.2 GB per block and pair at S = 17 776.  The bf16 residual form of "Precise delta" keeps 2 bytes per output element instead of 1: + D bytes per token.
     SAVED_BYTES_PER_TOKEN_BLOCK = {False: 79.0e3, True: 62.5e3}
+    WORKSPACE_BYTES = 12e9          # transient buffers of one block's backward + allocator slack that are not in the per-block table
 
     def memory_policy(self, n_seq, tokens, device):
-        """lean_activations = "auto": full activations when the estimate (saved activations + 40 GB of weights, caches, optimizer state and workspaces) stays
-        under 80 % of the device's memory -- the caching allocator needs slack (a 269 GB step fragmented into an out-of-memory error in round 4) -- else lean;
-        if lean does not fit either, say so instead of failing somewhere inside the backward.  Decided once per trainer, logged to stderr."""
+        """lean_activations = "auto": full activations when the estimated saved activations fit into 80 % of what this process can still get on the device --
+        free memory as the driver reports it now (torch.cuda.mem_get_info: other processes, a co-resident scorer / VAE, `separate_ref`'s second copy are all
+        already subtracted there) plus what this process's caching allocator holds but has not handed out -- the caching allocator needs slack (a 269 GB step
+        fragmented into an out-of-memory error in round 4); else lean; if lean does not fit either, say so instead of failing somewhere inside the backward.
+        Decided once per trainer, at the first step (the weights, their caches and the optimizer state are resident by then), logged to stderr."""
         base = self.transformer.get_base_model() if hasattr(self.transformer, "get_base_model") else self.transformer
         if not hasattr(base, "enable_lean_activations") or getattr(base, "gradient_checkpointing", False):
             return None
-        total = torch.cuda.get_device_properties(device).total_memory
+        free, total = torch.cuda.mem_get_info(device)
+        avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         layers, D = len(base.transformer_blocks), base.config.num_attention_heads * base.config.attention_head_dim
-        est = {lean: n_seq * tokens * layers * b * D / 3072 + 40e9 for lean, b in self.SAVED_BYTES_PER_TOKEN_BLOCK.items()}
-        lean = est[False] > 0.80 * total
+        precise = getattr(base.transformer_blocks[0].attn1.core, "precise_delta", "int8") if layers else "int8"
+        extra = {"bf16": 1.0 * D, None: -1.0 * D}.get(precise, 0.0)          # residual bytes per token against the int8 form the table was measured with
+        # caches built lazily by the first forward (fused QKV, K-extended and transposed operands: DESIGN section 3) are not resident yet at the first step
+        lazy = 0.0 if getattr(base.transformer_blocks[0].attn1.core, "_fused", None) is not None else 14e9 * layers / 42 * (D / 3072) ** 2
+        est = {lean: n_seq * tokens * layers * (b * D / 3072 + extra) + self.WORKSPACE_BYTES + lazy for lean, b in self.SAVED_BYTES_PER_TOKEN_BLOCK.items()}
+        lean = est[False] > 0.80 * avail
         base.enable_lean_activations(lean)
-        self.memory_policy_log = {"lean_activations": lean, "sequences": n_seq, "tokens": tokens, "layers": layers, "estimate_full_gb": est[False] / 1e9,
-                                  "estimate_lean_gb": est[True] / 1e9, "device_gb": total / 1e9}
+        self.memory_policy_log = {"lean_activations": lean, "sequences": n_seq, "tokens": tokens, "layers": layers, "precise_delta": precise,
+                                  "estimate_full_gb": est[False] / 1e9, "estimate_lean_gb": est[True] / 1e9, "available_gb": avail / 1e9, "device_gb": total / 1e9}
         import sys
         print(f"videogpa_amd: lean_activations=auto -> {lean} ({n_seq} sequences x {tokens} tokens x {layers} blocks: full {est[False] / 1e9:.0f} GB, "
-              f"lean {est[True] / 1e9:.0f} GB, device {total / 1e9:.0f} GB)" +
-              ("" if est[True] <= 0.92 * total else "; even lean is unlikely to fit: enable_gradient_checkpointing with a stride"), file=sys.stderr, flush=True)
+              f"lean {est[True] / 1e9:.0f} GB, available {avail / 1e9:.0f} of {total / 1e9:.0f} GB)" +
+              ("" if est[True] <= 0.92 * avail else "; even lean is unlikely to fit: enable_gradient_checkpointing with a stride"), file=sys.stderr, flush=True)
         return lean
 
     def shared_step_paired(self, x_pair, prompt_emb, timesteps=None, noise=None, cond_pair=None) -> LossOutput:
@@ -283,8 +312,18 @@ class CogVideoXDPOTrainer(nn.Module):
         return out.loss, logs
 
     def validation_step(self, batch, batch_idx=0):
-        with torch.no_grad():
-            out = self._shared_step(batch)
+        """A validation pass never moves the adapters: the `after_reference` hook (DPOEngine's deferred optimizer step) is held off for its duration.  With
+        a step still pending the policy pass below would otherwise see adapters updated in the MIDDLE of the validation batch; the caller is told instead
+        (DPOEngine.flush() first -- fit.py does)."""
+        hook, self.after_reference = self.after_reference, None
+        try:
+            pending = getattr(getattr(hook, "__self__", None), "_pending", None)
+            if pending is not None:
+                raise RuntimeError("validation_step with an optimizer step still pending in DPOEngine: call engine.flush() before validating")
+            with torch.no_grad():
+                out = self._shared_step(batch)
+        finally:
+            self.after_reference = hook
         return {"val/loss": out.loss, "val/reward_margin": out.reward_margin, "val/reward_accuracy": (out.reward_margin > 0).float().mean()}
 
     def configure_optimizers(self, process_group=None):

@@ -140,8 +140,15 @@ class WanDPOTrainer(nn.Module):
                           "train/reward_accuracy": (out.reward_margin > 0).float().mean()}
 
     def validation_step(self, batch, batch_idx=0):
-        with torch.no_grad():
-            out = self._shared_step(batch)
+        """never moves the adapters: DPOEngine's deferred optimizer step (`after_reference`) is held off, and a step still pending is an error (flush first)"""
+        hook, self.after_reference = self.after_reference, None
+        try:
+            if getattr(getattr(hook, "__self__", None), "_pending", None) is not None:
+                raise RuntimeError("validation_step with an optimizer step still pending in DPOEngine: call engine.flush() before validating")
+            with torch.no_grad():
+                out = self._shared_step(batch)
+        finally:
+            self.after_reference = hook
         return {"val/loss": out.loss, "val/reward_margin": out.reward_margin, "val/reward_accuracy": (out.reward_margin > 0).float().mean()}
 
     def configure_optimizers(self, process_group=None):
