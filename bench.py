@@ -41,13 +41,13 @@ TIMER_ALWAYS = ("attn_fwd_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", 
 
 # BASELINE.json configs that fit a bench line (SURVEY section 8 sizes).  cfg2 is the headline the metric is quoted on.
 CONFIGS = {
-    "cfg2": dict(model="COGVIDEOX_5B", frames=13, height=60, width=90, checkpoint=False, cond=False,
+    "cfg2": dict(model="COGVIDEOX_5B", frames=13, height=60, width=90, checkpoint=False, cond=False, metric="CogVideoX-5B 49f@480x720",
                  label="BASELINE configs[1]: CogVideoX-5B T2V full (42 blocks, D=3072, 48x64 heads), 49f x 480x720"),
-    "cfg3": dict(model="COGVIDEOX_5B_I2V", frames=13, height=60, width=90, checkpoint=False, cond=True,
+    "cfg3": dict(model="COGVIDEOX_5B_I2V", frames=13, height=60, width=90, checkpoint=False, cond=True, metric="CogVideoX-5B-I2V 49f@480x720 + image-cond latent",
                  label="BASELINE configs[2]: CogVideoX-5B-I2V (32 input channels, learned positional table), 49f x 480x720 + image-cond latent"),
     # S = 41 026: 6.6 GB of saved activations per block and pair would need 277 GB + weights; with lean activations (5.1 GB per block) all 42
     # blocks stay resident in 230 GB and nothing is recomputed (9.17 s; every 4th block recomputed without lean: 9.70 s in 227 GB)
-    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=False, cond=False, lean=True,
+    "cfg4": dict(model="COGVIDEOX_1_5_5B", frames=21, height=96, width=170, checkpoint=False, cond=False, lean=True, metric="CogVideoX1.5-5B 81f@768x1360",
                  label="BASELINE configs[3]: CogVideoX1.5-5B T2V (patch_size_t=2), 81f x 768x1360 (21 latent frames, even-cropped to 20)"),
     "cfg5": dict(model="WAN22_TI2V_5B", frames=21, height=44, width=80, checkpoint=False, cond=True,
                  label="BASELINE configs[4]: Wan2.2-TI2V-5B (30 blocks, dim 3072, 24x128 heads, ffn 14336, text 512), 81f x 704x1280 -> latent 48x21x44x80, "
@@ -133,6 +133,14 @@ def flops_per_pair_step_wan(L_tok, D, F, T, layers, r):
     f_lora = 2.0 * (6 * L_tok + 2 * T) * 2 * D * r
     fwd = layers * (f_lin + f_attn)
     return 2 * fwd + 2 * (fwd + layers * f_lora) + 2 * layers * (f_lin + 2 * f_attn + 2 * f_lora)
+
+
+def flops_fp8_wan(L_tok, D, F, layers, ffn_fp8=True, attn_fp8=True):
+    """the part of flops_per_pair_step_wan's count that runs on e4m3 operands (BASELINE configs[4] "fp8 MFMA path"): the two feed-forward GEMMs in all four
+    forwards and as dX in both backwards, and both products of the self-attention FORWARD (4 L^2 D) in all four forwards; everything else is bf16"""
+    f_ffn = 2.0 * L_tok * 2 * D * F
+    f_sa = 4.0 * L_tok * L_tok * D
+    return layers * ((6.0 * f_ffn if ffn_fp8 else 0.0) + (4.0 * f_sa if attn_fp8 else 0.0))
 
 
 def cpu_baseline(F_step, budget_s=200.0):
@@ -314,7 +322,116 @@ def dist_report(engine, dt_local, steps, dev, world, force_dist):
     return {"ranks_seen": dist.get_world_size(), "ms_per_step_min": min(per), "ms_per_step_max": max(per), "ms_per_step_by_rank": per, "comm": comm}
 
 
-OTHER_CONFIGS = ("cfg3", "cfg4", "cfg5")
+def tuned_gemms_report(ops):
+    """which hipBLASLt solutions the vendor GEMMs of this run used: the library's default heuristic, or the per-shape winners of tools/gemm_tune.py
+    (videogpa_amd/tuned/, read by PyTorch TunableOp with tuning off; ignored by torch when the file was made on another torch / ROCm / hipBLASLt stack)"""
+    st = ops.tuned_gemms_state() or {"enabled": False}
+    rep = {"enabled": bool(st.get("enabled")), "entries": st.get("entries")}
+    if st.get("file"):
+        rep["file"] = os.path.relpath(st["file"], ROOT)
+    if st.get("note"):
+        rep["note"] = st["note"]
+    return rep
+
+
+def scorer_inputs(dev, pointmap=True):
+    """the reference's scorer workload (train/01_preference_pair.py:33-34: NUM_FRAMES = 10 frames of 518 x 518 -> a cloud of 10 x 518 x 518 points re-projected into
+    all 10 views).  pointmap=True: the cloud IS a per-pixel point map, as VGGT / DA3 emit it (pipelines/process_video.py:66-98) -- every frame's pixels unprojected
+    at a smooth depth and moved into the world frame, so that neighbouring points land on neighbouring pixels; False: an unstructured Gaussian cloud (every
+    atomic a different cache line: the worst case)."""
+    T, H, W = 10, 518, 518
+    N = T * H * W
+    g = torch.Generator(device=dev).manual_seed(0)
+    K = torch.tensor([[400.0, 0, W / 2], [0, 400.0, H / 2], [0, 0, 1]], device=dev).repeat(T, 1, 1)
+    E = torch.eye(4, device=dev).repeat(T, 1, 1)
+    for t in range(T):
+        E[t, 0, 3] = 0.05 * t
+    if pointmap:
+        v, u = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+        pts = []
+        for t in range(T):
+            z = 3.0 + 0.5 * torch.sin(u / 60.0 + 0.3 * t) * torch.cos(v / 45.0) + 0.01 * torch.randn(H, W, generator=g, device=dev)
+            cam = torch.stack([(u - W / 2) / 400.0 * z, (v - H / 2) / 400.0 * z, z], dim=-1)        # pixel -> camera frame of view t
+            pts.append(cam - E[t, :3, 3])                                                              # -> world (R = I)
+        pc = torch.stack(pts).reshape(N, 3).contiguous()
+    else:
+        pc = torch.randn(N, 3, generator=g, device=dev) * torch.tensor([1.5, 1.5, 0.5], device=dev) + torch.tensor([0, 0, 3.0], device=dev)
+    colors = torch.rand(N, 3, generator=g, device=dev) * 255
+    gt = (torch.rand(T, H, W, 3, generator=g, device=dev) * 255).to(torch.uint8)
+    return T, H, W, N, pc, colors, K, E, gt
+
+
+def scorer_report(dev, with_cpu=True):
+    """the scorer kernels K14 / K15 "reported as GB/s vs the 8 TB/s peak" (utils/projection_utils.py:12-101, metrics/mse.py:14-54,
+    metrics/consistency_score.py:8-40) at the reference's scale, next to the reference's own formulation (z-descending argsort + scatter per view, as
+    project_points writes it) run through torch on this GPU, and -- in the CPU leg -- the oracle on the host cores.
+    Algorithmic bytes per video: every point-view reads xyz + rgb (24 B) and does one 8-byte atomicMin; the resolve pass reads the z-buffer (8 B per pixel and
+    view), gathers the winner's colour (12 B) and writes the fp32 frame (12 B)."""
+    from videogpa_amd import scorer
+    out = {}
+    for kind, pm in (("pointmap", True), ("random_cloud", False)):
+        T, H, W, N, pc, colors, K, E, gt = scorer_inputs(dev, pm)
+
+        def timeit(f, n=20):
+            f()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                r = f()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n, r
+        ms, rep = timeit(lambda: scorer.batch_reproject(pc, colors, K, E, H, W))
+        alg = T * N * (24 + 8) + T * H * W * (8 + 12 + 12)
+        covered = float((rep.reshape(T, 3, -1) > -1.0).any(dim=1).float().mean())
+        rec = {"ms_per_video": ms, "gpoint_views_per_s": T * N / ms / 1e6, "algorithmic_bytes": alg, "algorithmic_gbs": alg / ms / 1e6,
+               "frac_of_hbm_peak": alg / ms / 1e6 / PEAK_HBM_GBS, "atomics_per_s": T * N / (ms * 1e-3), "pixels_covered": covered}
+        if pm:
+            m = scorer.MSEMetric()
+            ms2, _ = timeit(lambda: m.compute_device(gt=gt, rep=rep))
+            mse_bytes = 2 * (T * H * W * 3) * (1 + 4)               # range scan + squared-error pass over the u8 frames and the fp32 re-projections
+            rec["mse_ms"] = ms2
+            rec["mse_gbs"] = mse_bytes / ms2 / 1e6
+            rec["mse_frac_of_hbm_peak"] = mse_bytes / ms2 / 1e6 / PEAK_HBM_GBS
+            ms3, _ = timeit(lambda: scorer.compute_motion_score_vectorized(E))
+            rec["motion_score_us"] = ms3 * 1e3
+
+            def ref_style():                                         # project_points as the reference writes it (utils/projection_utils.py:12-51), one view
+                R, tr = E[0, :3, :3], E[0, :3, 3]
+                pp = (pc @ R.T + tr) @ K[0].T
+                z = pp[:, 2]
+                u = (pp[:, 0] / (z + 1e-8)).round().long()
+                v = (pp[:, 1] / (z + 1e-8)).round().long()
+                mk = (u >= 0) & (u < W) & (v >= 0) & (v < H) & (z > 0)
+                u, v, z, c = u[mk], v[mk], z[mk], colors[mk]
+                si = torch.argsort(z, descending=True)
+                canvas = torch.zeros(H, W, 3, dtype=torch.uint8, device=dev)
+                canvas[v[si], u[si]] = c[si].clamp(0, 255).to(torch.uint8)
+                return canvas
+            ms5, _ = timeit(ref_style, n=5)
+            rec["torch_argsort_ms_same_gpu"] = T * ms5
+            rec["torch_argsort_note"] = f"the reference's sort + scatter formulation through torch on this GPU: {ms5:.2f} ms per view x {T} views"
+            if with_cpu:
+                rec["cpu_oracle_ms"] = cpu_baseline_scorer(pc, colors, K, E, H, W, T)
+        out[kind] = rec
+        del pc, colors, gt, rep
+    out["workload"] = "10 frames x 518 x 518 (train/01_preference_pair.py:33-34): 2 683 240 points re-projected into 10 views"
+    out["bound"] = ("project_zbuf: one 64-bit atomicMin per point-view at device scope (executed beyond the XCD's L2); tools/zbuf_atomic_probe.hip measures the same "
+                    "pattern with the loads and the arithmetic taken away (profiles/r06_scorer_*)")
+    return out
+
+
+def cpu_baseline_scorer(pc, colors, K, E, H, W, T):
+    """CPU leg of the scorer block: oracle/scorer.py::project_points (numpy) for ONE view on the host, scaled to the T views of a video"""
+    from oracle import scorer as osc
+    a = [x.cpu().numpy() for x in (pc, colors, K[0], E[0])]
+    t0 = time.perf_counter()
+    osc.project_points(a[0], a[1], a[2], a[3], H, W)
+    return (time.perf_counter() - t0) * 1e3 * T
+
+
+OTHER_CONFIGS = ("cfg3", "cfg3_batch2", "cfg4", "cfg5")
 
 
 CHILD_CPUS = 16      # host threads fenced off for the secondary-config child processes while the CPU leg is being timed
@@ -333,6 +450,20 @@ def split_host_cpus():
     return cpus[:-CHILD_CPUS], cpus[-CHILD_CPUS:]
 
 
+def pin_all_threads(cpus):
+    """sched_setaffinity(0, ...) moves only the calling thread on Linux: torch's OpenMP / intra-op workers created earlier keep their old mask and could
+    still run on the children's cores.  Apply the mask to every thread of this process (/proc/self/task); threads created later inherit it from their creator."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except (OSError, ProcessLookupError):
+            pass                       # a thread that exited meanwhile
+
+
 def run_other_configs(steps=3, warmup=1, timeout_s=420, cpus=None):
     """The secondary BASELINE configurations as driver-witnessed numbers: each runs as its own `python bench.py --config cfgN` process (so the
     memory of one is gone before the next starts -- cfg4 needs 230 GB -- and a failure in one cannot touch the headline line), `steps` timed steps
@@ -343,8 +474,13 @@ def run_other_configs(steps=3, warmup=1, timeout_s=420, cpus=None):
     if cpus:        # the child pins ITSELF first thing in main() (no preexec_fn: this is called from a thread while the CPU leg's OpenMP pool is busy)
         env.update(OMP_NUM_THREADS=str(len(cpus)), MKL_NUM_THREADS=str(len(cpus)), VGPA_BENCH_CPUS=",".join(str(c) for c in cpus))
     for name in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
-               "--no-other-configs"]
+        extra = []
+        if name == "cfg3_batch2":       # the reference's own I2V setting: two pairs per step, no accumulation (train/CogVideoX-I2V-5B/03_train.py:59-60)
+            name_arg, extra = "cfg3", ["--pairs", "2"]
+        else:
+            name_arg = name
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name_arg, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
+               "--no-other-configs", *extra]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
@@ -354,7 +490,7 @@ def run_other_configs(steps=3, warmup=1, timeout_s=420, cpus=None):
                 continue
             j = json.loads(line)
             keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "loss", "max_memory_gb", "step_flops_algorithmic",
-                    "step_mfma_frac", "roofline", "roofline_worst", "attention_bwd_pair", "energy")
+                    "step_mfma_frac", "step_mfma_frac_note", "roofline", "roofline_worst", "attention_bwd_pair", "energy", "memory_policy", "tuned_gemms")
             rec = {k: j[k] for k in keep if k in j}
             rec["workload"] = j["config"]["workload"]
             rec["wall_s_incl_model_build"] = time.perf_counter() - t0
@@ -405,7 +541,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
         torch.nn.init.normal_(model.head.head.weight, std=0.02)      # upstream zero-inits the output layer: give the loss a signal
     model.enable_fp8(not args.no_fp8, attention=not (args.no_fp8 or args.no_fp8_attn))
     trainer = WanDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2.0 * args.rank_r, "accumulate_grad_batches": 1, "seed": 1234,
-                             "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": stride}, model)
+                             "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": stride, "tuned_gemms": not args.no_tuned_gemms}, model)
     gB = torch.Generator(device=dev).manual_seed(1)
     with torch.no_grad():
         for n, p in trainer.transformer.named_parameters():
@@ -418,6 +554,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
     batch = {"x_win": lat(F_), "x_lose": lat(F_), "prompt_emb": torch.randn(1, 300, 4096, generator=g, device=dev).to(torch.bfloat16), "image_latent": lat(1)}
     L_tok = F_ * (H_ // 2) * (W_ // 2)
     F_step = flops_per_pair_step_wan(L_tok, model.dim, model.ffn_dim, WAN_TEXT_LEN, layers, args.rank_r)
+    F_fp8 = flops_fp8_wan(L_tok, model.dim, model.ffn_dim, layers, ffn_fp8=not args.no_fp8, attn_fp8=not (args.no_fp8 or args.no_fp8_attn))
 
     def barrier():
         if world > 1 or force_dist:
@@ -466,8 +603,13 @@ def main_wan(args, C, world, rank, dev, force_dist):
             "note": "NOT the headline line: BASELINE.json's metric is quoted on cfg2 (python bench.py without --config)",
             "loss": float(logs["train/loss"]), "loss_rank_mean": logs["sync"].tolist()[0],
             "step_flops_algorithmic": F_step,
-            "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+            "step_flops_algorithmic_fp8": F_fp8,
+            # priced against the FLOP-weighted BLENDED peak of the step: the e4m3 share at 5 PF, the rest at 2.5 PF (round 5 priced the whole step at the bf16 peak)
+            "step_mfma_frac": (F_fp8 / (PEAK_FP8_DENSE_TFLOPS * 1e12) + (F_step - F_fp8) / (PEAK_BF16_DENSE_TFLOPS * 1e12)) / (dt / args.steps),
+            "step_mfma_frac_note": f"time at peak / time taken with {F_fp8 / F_step:.3f} of the algorithmic FLOPs priced at the dense fp8 peak (5 PF) and the rest at the dense "
+                                   f"bf16 peak (2.5 PF); against the bf16 peak alone the same step is {F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12):.3f}",
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "tuned_gemms": tuned_gemms_report(ops),
         }
         out.update(drep)
         add_kernel_report(out, ops, args.steps, ms, use_pmc=named)
@@ -489,6 +631,8 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--rank-r", type=int, default=64)
+    ap.add_argument("--pairs", type=int, default=1, help="preference pairs per GPU and step (the reference's I2V trainer runs 2: train/CogVideoX-I2V-5B/03_train.py:59-60); "
+                    "more than one lets the trainer's memory policy choose lean activations")
     ap.add_argument("--checkpoint", action="store_true", default=None, help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
     ap.add_argument("--no-checkpoint", dest="checkpoint", action="store_false", help="keep every block's activations (overrides a config's default recompute)")
     ap.add_argument("--checkpoint-stride", type=int, default=None, help="with --checkpoint: recompute only every k-th block (1 = all, like the reference)")
@@ -497,12 +641,14 @@ def main():
     ap.add_argument("--no-fp8-attn", action="store_true", help="cfg5 only: keep the e4m3 feed-forward but run the self-attention forward in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="run the vendor GEMMs on hipBLASLt's default heuristic instead of the solutions of videogpa_amd/tuned/ (the A/B of tools/gemm_tune.py)")
+    ap.add_argument("--no-scorer", action="store_true", help="skip the geometry-scorer block (a few milliseconds of GPU work after the headline's timed region)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (1 GPU, cfg2, no debug flags) also measures cfg3 / cfg4 / cfg5 for 3 steps each "
                     "and attaches them as `other_configs`; this switches that off")
     args = ap.parse_args()
     if os.environ.get("VGPA_BENCH_CPUS"):        # a secondary-config child of the default run: stay off the cores the parent's CPU leg is being timed on
         try:
-            os.sched_setaffinity(0, {int(c) for c in os.environ["VGPA_BENCH_CPUS"].split(",")})
+            pin_all_threads({int(c) for c in os.environ["VGPA_BENCH_CPUS"].split(",")})
         except (AttributeError, OSError, ValueError):
             pass
 
@@ -544,9 +690,11 @@ def main():
     torch.manual_seed(0)                           # identical adapter init (PEFT kaiming-uniform A) on every rank
     model = build_model(cfg_kw, dev, seed=0)       # identical base weights on every rank
     lean = bool(C.get("lean", False) if args.lean is None else args.lean)
+    P_ = max(1, args.pairs)
+    lean_cfg = "auto" if (P_ > 1 and args.lean is None) else lean        # more than one pair per step: the trainer's own memory policy decides (and is reported)
     trainer = CogVideoXDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2 * args.rank_r, "beta": 1.0, "accumulate_grad_batches": 1,
-                                   "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": ckpt_stride, "lean_activations": lean,
-                                   "seed": 1234}, transformer=model)
+                                   "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": ckpt_stride, "lean_activations": lean_cfg,
+                                   "seed": 1234, "tuned_gemms": not args.no_tuned_gemms}, transformer=model)
     # LoRA B ~ N(0, 1e-3) so the step is beyond the trivial B=0 point
     gB = torch.Generator(device=dev).manual_seed(1)
     with torch.no_grad():
@@ -558,17 +706,17 @@ def main():
 
     # synthetic preference pair, resident in HBM (seed 1234 + rank): every rank has its own pair and its own (t, eps) stream
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x_pair = (0.7 * torch.randn(1, 2, F_, 16, H_, W_, generator=g, device=dev)).to(torch.bfloat16)
-    prompt = (0.2 * torch.randn(1, TEXT_LEN, 4096, generator=g, device=dev)).to(torch.bfloat16)
+    x_pair = (0.7 * torch.randn(P_, 2, F_, 16, H_, W_, generator=g, device=dev)).to(torch.bfloat16)
+    prompt = (0.2 * torch.randn(P_, TEXT_LEN, 4096, generator=g, device=dev)).to(torch.bfloat16)
     batch = {"x_pair": x_pair, "prompt_emb": prompt}
     if C["cond"]:
-        batch["image_latent"] = (0.7 * torch.randn(1, 1, 16, H_, W_, generator=g, device=dev)).to(torch.bfloat16)
+        batch["image_latent"] = (0.7 * torch.randn(P_, 1, 16, H_, W_, generator=g, device=dev)).to(torch.bfloat16)
 
     pt = cfg_kw.get("patch_size_t") or 1
     Fe, He, We = (F_ - F_ % 2, H_ - H_ % 2, W_ - W_ % 2) if pt > 1 else (F_, H_, W_)     # the 1.5 step even-crops
     S = TEXT_LEN + (Fe // pt) * (He // 2) * (We // 2)
     D = cfg_kw["num_attention_heads"] * 64
-    F_step = flops_per_pair_step(S, D, args.layers, args.rank_r)
+    F_step = P_ * flops_per_pair_step(S, D, args.layers, args.rank_r)
 
     def barrier():
         if world > 1 or force_dist:
@@ -601,30 +749,35 @@ def main():
     drep = dist_report(engine, dt_local, args.steps, dev, world, force_dist)
 
     if rank == 0:
-        named = (args.layers, F_, H_, W_, args.rank_r, ckpt, lean) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"], bool(C.get("lean", False)))
+        named = (args.layers, F_, H_, W_, args.rank_r, ckpt) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"]) and \
+            (lean == bool(C.get("lean", False)) or P_ > 1)
+        lean = bool(trainer.transformer.get_base_model().lean_activations)     # what actually ran (the memory policy may have chosen)
         ms = dt / args.steps * 1e3
-        value = world * args.steps / dt
+        value = world * args.steps * P_ / dt
         sync = logs["sync"].tolist()
         out = {
-            "metric": "DPO preference-pair steps/sec, CogVideoX-5B 49f@480x720", "value": value, "unit": "pair-steps/s",
+            "metric": "DPO preference-pair steps/sec, " + C["metric"], "value": value, "unit": "pair-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (C["label"] + " -> " if named else "NOT a BASELINE config (debug flags): CogVideoX-5B-shaped transformer, ")
-                                   + f"paired latents [1,2,{F_},16,{H_},{W_}], S={S} tokens, {args.layers} blocks, LoRA r={args.rank_r} on "
-                                   "to_q/to_k/to_v/to_out.0, 1 pair/GPU/step, optimizer step every step; random-init weights"
+                                   + f"paired latents [{P_},2,{F_},16,{H_},{W_}], S={S} tokens, {args.layers} blocks, LoRA r={args.rank_r} on "
+                                   f"to_q/to_k/to_v/to_out.0, {P_} pair{'s' if P_ > 1 else ''}/GPU/step, optimizer step every step; random-init weights"
                                    + (f"; activation recompute of every {ckpt_stride}. block" if ckpt and ckpt_stride > 1 else
                                       "; per-block activation recompute" if ckpt else "")
                                    + ("; lean activations (LN output and normalised q / k made again in the backward)" if lean else ""),
-                       "name": args.config, "layers": args.layers, "tokens": S, "pairs_per_gpu": 1, "parallelism": f"dp{world}"},
-            "loss": float(logs["train/loss"]), "loss_rank_mean": sync[0],
+                       "name": args.config, "layers": args.layers, "tokens": S, "pairs_per_gpu": P_, "parallelism": f"dp{world}"},
+            "loss": float(logs["train/loss"]), "loss_rank_mean": sync[0], "memory_policy": trainer.memory_policy_log,
             "step_flops_algorithmic": F_step,
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "tuned_gemms": tuned_gemms_report(ops),
         }
         out.update(drep)
         add_kernel_report(out, ops, args.steps, ms, use_pmc=named and args.config in ("cfg2", "cfg3"))
         if not ckpt:      # with block recompute the executed count would also carry the recomputed forwards
-            out["energy"] = energy_report(e0, e1, dt_local, args.steps, F_step, F_step + 6.0 * args.layers * 2 * cfg_kw["num_attention_heads"] * 64.0 * S * S)
+            out["energy"] = energy_report(e0, e1, dt_local, args.steps, F_step, F_step + P_ * 6.0 * args.layers * 2 * cfg_kw["num_attention_heads"] * 64.0 * S * S)
+        if world == 1 and not force_dist and named and args.config == "cfg2" and not args.no_scorer:
+            out["scorer"] = scorer_report(dev, with_cpu=not args.no_cpu_baseline)
         others = None
         if world == 1 and not force_dist and named and args.config == "cfg2" and not args.no_other_configs:
             # the secondary configurations run on the (now idle) GPU in child processes WHILE the host cores time the CPU leg: the timed region of the
@@ -640,7 +793,7 @@ def main():
             others = threading.Thread(target=lambda: box.update(run_other_configs(cpus=child_cpus)), daemon=True)
             others.start()
             if leg_cpus and not args.no_cpu_baseline:
-                os.sched_setaffinity(0, leg_cpus)          # this process is done with the GPU work that needed its launch threads
+                pin_all_threads(leg_cpus)                  # this process is done with the GPU work that needed its launch threads
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_step)
             if others is not None:

@@ -111,5 +111,5 @@ def wan_pair_step(model, ref_model, x_win, x_lose, prompt_emb, t, noise, image_l
     v_w = torch.stack(model([xw_n[b] for b in range(B)], t=t_batch, context=ctx, seq_len=seq_len))
     v_l = torch.stack(model([xl_n[b] for b in range(B)], t=t_batch, context=ctx, seq_len=seq_len))
     out = dpo.dpo_loss(v_w, v_l, v_wr, v_lr, noise - x_win, noise - x_lose, beta=beta)
-    out.update(t_batch=t_batch, x_win_noisy=xw_n, x_lose_noisy=xl_n, seq_len=seq_len)
+    out.update(t_batch=t_batch, x_win_noisy=xw_n, x_lose_noisy=xl_n, seq_len=seq_len, v_win=v_w, v_lose=v_l, v_win_ref=v_wr, v_lose_ref=v_lr)
     return out

@@ -16,7 +16,11 @@ Bounds: stated next to the asserts below; every comparison is made and the repor
 
 A second arm ("rich") repeats the comparison with AdaLN modulation weights of std 0.3 (gates / scales O(0.3), as tests/cfg1_common.py) so that all 42 blocks
 contribute at order one to the residual stream: bench.py's N(0, 0.02) init gives gates of ~0.05 and lets early-block gradients travel mostly through the
-identity path, which is the friendliest case for error growth with depth.
+identity path, which is the friendliest case for error growth with depth.  MEASURED (round 6, profiles/r06_cfg2_depth_parity_rich.json): such a random 42-block
+net amplifies rounding noise by itself -- the activation-rounded ORACLE, fp32 arithmetic that merely rounds the same tensors, is 25-54 % from plain fp32 on the
+gradients, torch bf16 30-380 % -- so absolute bounds against fp32 say nothing about kernels there.  What the arm asserts instead, on EVERY tensor: the HIP path is
+no further from fp32 than 1.35 x the rounded oracle is (measured <= 1.21 x) and than 1.1 x torch bf16 is (measured <= 1.01 x; median 0.37 vs 0.57), and within
+25 % / cosine 0.97 of the rounded oracle (two realisations of the same rounding noise through the same amplifier: measured 3-19 %).
 
 -m gpu only; takes the whole GPU (HIP step 145 GB, then the oracle ~60 GB) and ~10 minutes per arm.
 """
@@ -42,6 +46,7 @@ LOSS_TOL = 1e-3                 # north_star
 PRED_ERR_OVER_RANGE = 0.04      # bf16 activations through 42 blocks (cfg1, 2 blocks: 0.03)
 ROUNDED_REL, ROUNDED_COS = 0.10, 0.995      # against the activation-rounded oracle: the cfg1 bounds, unchanged at 21 x the depth
 FP32_REL_CAP, FLOOR_FACTOR, FP32_REL_FIXED = 0.12, 1.25, 0.08          # against fp32: tests/test_gpu_cfg1.py's rule, unchanged
+RICH_ROUNDED_REL, RICH_ROUNDED_COS, RICH_VS_ROUNDED_ORACLE, RICH_VS_TORCH_BF16, RICH_LOSS_TOL_FP32 = 0.25, 0.97, 1.35, 1.10, 2e-3      # the "rich" arm (see the header)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -178,8 +183,10 @@ def _run(arm):
                         f"lora_B ~ N(0, 1e-3), t = {TIMESTEP}; weights: " + ("bench.py init (N(0, 0.02), biases 0)" if arm == "bench" else
                                                                              "bench.py init with AdaLN modulation linears N(0, 0.3) (gates / scales of order 0.3)"),
               "is_baseline_depth": LAYERS == 42, "arm": arm,
-              "bounds": {"loss": LOSS_TOL, "pred_err_over_range": PRED_ERR_OVER_RANGE, "rounded_rel": ROUNDED_REL, "rounded_cos": ROUNDED_COS,
-                         "fp32_rule": f"min(max({FP32_REL_FIXED}, {FLOOR_FACTOR} x torch-bf16 error), {FP32_REL_CAP})"}}
+              "bounds": ({"loss": LOSS_TOL, "pred_err_over_range": PRED_ERR_OVER_RANGE, "rounded_rel": ROUNDED_REL, "rounded_cos": ROUNDED_COS,
+                          "fp32_rule": f"min(max({FP32_REL_FIXED}, {FLOOR_FACTOR} x torch-bf16 error), {FP32_REL_CAP})"} if arm == "bench" else
+                         {"loss_vs_rounded": LOSS_TOL, "loss_vs_fp32": RICH_LOSS_TOL_FP32, "pred_err_over_range": PRED_ERR_OVER_RANGE, "rounded_rel": RICH_ROUNDED_REL,
+                          "rounded_cos": RICH_ROUNDED_COS, "fp32_rule": f"<= {RICH_VS_ROUNDED_ORACLE} x (rounded oracle vs fp32) + 0.02 and <= {RICH_VS_TORCH_BF16} x (torch bf16 vs fp32) + 0.02"})}
     fails = []
 
     def check(ok, what):
@@ -200,7 +207,7 @@ def _run(arm):
     for name in ("fp32", "rounded"):
         d = abs(hip["loss"] - oracles[name][0]["loss"])
         report[f"loss_abs_err_vs_{name}"] = d
-        check(d < LOSS_TOL, ("loss", name, hip["loss"], oracles[name][0]["loss"]))
+        check(d < (RICH_LOSS_TOL_FP32 if (arm == "rich" and name == "fp32") else LOSS_TOL), ("loss", name, hip["loss"], oracles[name][0]["loss"]))
         for k in ("winner_reward", "loser_reward"):
             ref = oracles[name][0][k]
             check(abs(hip[k] - ref) < 2e-4 + 0.01 * abs(ref), (k, name, hip[k], ref))
@@ -235,8 +242,13 @@ def _run(arm):
             rows[k] = {"rel_vs_fp32": round(e32, 5), "cos_vs_fp32": round(c32, 6), "rel_vs_rounded": round(ero, 5), "cos_vs_rounded": round(cro, 6),
                        "torch_bf16_rel_vs_fp32": round(efl, 5), "rounded_oracle_rel_vs_fp32": round(e_ro32, 5), "bound_vs_fp32": round(bound, 5),
                        "norm_fp32": float(g32[k].double().norm())}
-            check(ero <= ROUNDED_REL and cro >= ROUNDED_COS, (_short(k), "vs activation-rounded oracle", ero, cro))
-            check(e32 <= bound, (_short(k), "vs fp32", e32, bound))
+            if arm == "bench":
+                check(ero <= ROUNDED_REL and cro >= ROUNDED_COS, (_short(k), "vs activation-rounded oracle", ero, cro))
+                check(e32 <= bound, (_short(k), "vs fp32", e32, bound))
+            else:       # the noise-amplifying arm: relative to what fp32 arithmetic with the same roundings, and torch bf16, achieve on the same tensor
+                check(ero <= RICH_ROUNDED_REL and cro >= RICH_ROUNDED_COS, (_short(k), "vs activation-rounded oracle", ero, cro))
+                check(e32 <= RICH_VS_ROUNDED_ORACLE * e_ro32 + 0.02, (_short(k), "vs fp32, against the rounded oracle's own distance", e32, e_ro32))
+                check(e32 <= RICH_VS_TORCH_BF16 * efl + 0.02, (_short(k), "vs fp32, against torch bf16's distance", e32, efl))
         per_tensor.update({_short(k): v for k, v in rows.items()})
         vals = list(rows.values())
         by_block.append({"block": i,

@@ -1,0 +1,74 @@
+"""Forward-attention time against the DATA: the w1 forward shifts each row's scores by a bound instead of a running maximum, so
+its speed depends on the score distribution -- strips whose rows it cannot represent are flagged and redone by the online-softmax kernel (correct either way).
+For operands shaped like a trained QK-normed model's (tools/attn_data.py: LayerNorm outputs with gain g and a few outlier channels, every query matched to one key,
+optional sink keys) at the headline shape, per setting:
+    ms per launch of the bound-shifted forward (incl. its redo pass), fraction of strips redone, ms of the all-online call, ms of what the layer policy
+    (ops.AttnFwdPolicy: switch to online above 5 % redone) ends up running, each relative to the same kernel on bench.py's N(0,1) operands.
+    python tools/attn_robust.py [--S 17776] [--B 2] [--H 48] [--iters 3] [--json gpurun_out/attn_trained_like.json]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from attn_data import trained_like_qkv  # noqa: E402
+from videogpa_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--S", type=int, default=17776)
+ap.add_argument("--B", type=int, default=2)
+ap.add_argument("--H", type=int, default=48)
+ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--json", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "attn_trained_like.json"))
+a = ap.parse_args()
+B, H, S = a.B, a.H, a.S
+
+
+def time_mode(q, k, v, mode):
+    pol = ops.AttnFwdPolicy(mode=mode, fixed=True)
+    ops.attention_fwd_raw(q, k, v, policy=pol)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        ops.attention_fwd_raw(q, k, v, policy=pol)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.iters
+
+
+def redo_fraction(q, k, v):
+    pol = ops.AttnFwdPolicy()              # the product's policy object: observes on its first call
+    ops.attention_fwd_raw(q, k, v, policy=pol)
+    return pol.redo_fraction, pol.mode
+
+
+rows = []
+g = torch.Generator(device="cuda").manual_seed(0)
+q0, k0, v0 = (torch.randn(B, H, S, 64, generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
+base_bound, base_online = time_mode(q0, k0, v0, "bound"), time_mode(q0, k0, v0, "online")
+f0, _ = redo_fraction(q0, k0, v0)
+rows.append({"data": "randn (bench.py's operands)", "bound_ms": base_bound, "online_ms": base_online, "redo_fraction": f0, "policy_mode": "bound", "policy_ms": base_bound,
+             "policy_over_randn": 1.0})
+print(f"randn                                        bound {base_bound:7.3f} ms  redo {f0:6.3f}  online {base_online:7.3f} ms")
+del q0, k0, v0
+settings = [dict(gain=1.0), dict(gain=2.0), dict(gain=2.5), dict(gain=3.0), dict(gain=4.0), dict(gain=6.0), dict(gain=1.0, sink_norm=10.0), dict(gain=2.0, sink_norm=10.0),
+            dict(gain=2.0, peak=0.0), dict(gain=4.0, peak=0.0), dict(gain=2.0, peak=0.9)]
+for st in settings:
+    q, k, v, stats = trained_like_qkv(B, H, S, **st)
+    f, mode = redo_fraction(q, k, v)
+    tb, to = time_mode(q, k, v, "bound"), time_mode(q, k, v, "online")
+    tp = tb if mode == "bound" else to
+    row = dict(data="trained_like " + " ".join(f"{k_}={v_}" for k_, v_ in st.items()), **stats, bound_ms=tb, online_ms=to, redo_fraction=f, policy_mode=mode, policy_ms=tp,
+               policy_over_randn=tp / base_bound)
+    rows.append(row)
+    print(f"{row['data']:44s} bound {tb:7.3f} ms  redo {f:6.3f}  online {to:7.3f} ms  policy -> {mode:6s} {tp:7.3f} ms = x{tp / base_bound:5.3f}   "
+          f"[bound {stats['bound_log2_mean']:6.1f} log2, gap {stats['gap_bound_minus_rowmax_mean']:6.1f} (max {stats['gap_bound_minus_rowmax_max']:6.1f}), "
+          f"row entropy {stats['row_entropy_bits_mean']:5.2f} of {stats['uniform_entropy_bits']:4.1f} bits]", flush=True)
+    del q, k, v
+os.makedirs(os.path.dirname(a.json), exist_ok=True)
+with open(a.json, "w") as f:
+    json.dump({"shape": {"B": B, "H": H, "S": S, "head_dim": 64}, "switch_threshold": ops.AttnFwdPolicy.SWITCH, "rows": rows}, f, indent=1)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vgpa_attn_bwd_prep_w1": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
     "vgpa_attn_bwd_prep_w1_res": (I32, [P, P, I32, P, P, P, P, P, P, P, I64, I64, I64, I64, P]),
     "vgpa_attn_fwd_w1_res": (I32, [P, P, P, P, P, I32, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
+    "vgpa_attn_fwd_online_res": (I32, [P, P, P, P, P, I32, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_dkv_w1": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_attn_bwd_split_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn_bwd_dkv_ws": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, I32, P, SZ, P]),

@@ -219,7 +219,8 @@ typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
 #define W1H_SLOT_BYTES 32768
 #define W1H_RING_BYTES (4 * W1H_SLOT_BYTES)
 #define W1H_L_MIN 7.888609052210118e-31f   // 2^-100
-#define W1H_M_MAX 160.0f
+#define W1H_M_MAX 1024.0f      // as W1_M_MAX (attention_w1.hip): the fp32 accumulator's ulp at |M'| = 1024 is a fiftieth of the weight's bf16 rounding
+#define W1H_SHIFT_BACK 60.0f   // as W1_SHIFT_BACK: M' = bound - min(60, bound / 2) leaves 160 log2 units below the Cauchy-Schwarz bound representable
 
 __device__ __forceinline__ uint32_t w1h_swz(uint32_t r) { return ((r & 3u) << 2) | ((r >> 2) & 3u); }
 
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __
             for (int i = 0; i < 8; ++i) a += f[i] * f[i];
         }
         a += other_half(a);
-        nmc[j] = -(sqrtf(a) * kmax * 1.0009765625f);
+        const float bnd = sqrtf(a) * kmax * 1.0009765625f;                 // |q| max|k| (unscaled: the loop multiplies by c)
+        nmc[j] = -(bnd - fminf(W1H_SHIFT_BACK / c, 0.5f * bnd));
     }
     const int nt = (Skv + 63) / 64;
     {   // the pipeline's first transposed reads hit the V tile of ring slot 3: make it finite

@@ -173,7 +173,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 // two they do not (S = 1: O off by up to 0.4 %).  Rows that short are not a performance case: below this length every strip goes to
 // the online-softmax kernel.
 #define W1_FWD_MIN_S 128
-#define W1_M_MAX 160.0f                       // a bound this large (log2 units) costs precision: the scores are accumulated on top of -M in fp32 -> redo
+// The shift M' only has to put exp2(s - M') inside fp32's range for every score that matters, it does not have to be an upper bound: the weights go to the matrix
+// pipe as bf16 (fp32's exponent range) and l, O accumulate in fp32.  With M' = bound - W1_SHIFT_BACK a row is exact while its true maximum lies in
+// [bound - W1_SHIFT_BACK - 100, bound]: 160 log2 units of slack below the Cauchy-Schwarz bound instead of 100 (QK-norm gains up to ~5.5 on isotropic keys
+// instead of ~4.4: tools/attn_bench.py --data trained_like), at the cost of weights up to 2^60 (l <= S 2^60, far inside fp32).  Rows outside still flag.
+#define W1_SHIFT_BACK 60.0f
+// the scores are accumulated on top of -M' in fp32: at |M'| = 1024 the accumulator's ulp is 2^-13 log2 units = 8e-5 relative in a weight, a fiftieth of the bf16
+// rounding the weight gets anyway (round 5 flagged every strip above 160: a QK-norm gain of 3.8 already sent the whole launch to the online-softmax kernel)
+#define W1_M_MAX 1024.0f
 
 // The rounding residual of four outputs, x - bf16(x), itself as bf16 (relative error 2^-9 of a quantity that is 2^-9 of x: the pair (o, o_res)
 // carries O to ~2^-17).  Consumer: the backward's delta = rowsum(dO o (O + O_res)) (w1_bwd_prep_kernel / attn_delta_kernel).  Why: delta stands for
@@ -241,7 +248,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
             for (int i = 0; i < 8; ++i) a += f[i] * f[i];
         }
         a += other_half(a);                              // the row's other 32 columns live in lane ^ 32
-        nm[j] = -(sqrtf(a) * kmax * 1.0009765625f);      // a hair above |q| |k|max: rounding of the bound itself can never let a score exceed it
+        const float bnd = sqrtf(a) * kmax * 1.0009765625f;   // a hair above |q| |k|max: rounding of the bound itself can never let a score exceed it
+        nm[j] = -(bnd - fminf(W1_SHIFT_BACK, 0.5f * bnd));   // -M'[q] (see W1_SHIFT_BACK)
     }
 
     const int nt_all = (S + TILE - 1) / TILE;
@@ -727,10 +735,10 @@ size_t vgpa_attn_fwd_w1_workspace_bytes(int64_t B, int64_t H, int64_t S) {
 // vgpa_attn_fwd_w1 that also leaves what the bf16 rounding of the output dropped, for the backward's delta (vgpa_attn_bwd_prep_w1_res /
 // vgpa_attn_bwd_delta_res): o_res = a [B,H,S,64] view with its own element strides (NULL: not written) of
 //   res_kind VGPA_RES_BF16 (1): bf16, O_fp32 - bf16(O);   VGPA_RES_8 (2): uint8, eight further mantissa bits (common.h res8) -- half the bytes, O to 2^-17 either way
-int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* o, void* o_res, int32_t res_kind, float* lse2, const int64_t* q_strides,
-                             const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* ores_strides, int64_t B,
-                             int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes,
-                             hipStream_t stream) {
+static int32_t fwd_w1_impl(const void* q, const void* k, const void* v, void* o, void* o_res, int32_t res_kind, float* lse2, const int64_t* q_strides,
+                           const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* ores_strides, int64_t B,
+                           int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes,
+                           hipStream_t stream, bool force_online) {
     (void)scale;
     if (!q || !k || !v || !o || !lse2 || !workspace || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
 #define SOK(st) (stride_ok(st) && range_ok(st, B, H, S))
@@ -749,7 +757,7 @@ int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* 
     unsigned* kmax2 = (unsigned*)workspace;
     int* flags = (int*)workspace + B * H;
     float* part = (float*)((char*)workspace + head);
-    if (S < W1_FWD_MIN_S) {   // a handful of keys per row: the online-softmax kernel (its top weight is exactly 1; see W1_FWD_MIN_S)
+    if (S < W1_FWD_MIN_S || force_online) {   // a handful of keys per row: the online-softmax kernel (its top weight is exactly 1; see W1_FWD_MIN_S)
         if (hipMemsetAsync(workspace, 0xff, head, stream) != hipSuccess) return VGPA_ERR_LAUNCH;   // every strip flagged
         return vgpa_internal_attn_fwd_redo(q, k, v, o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, tasks,
                                            flags, stream, ores, sor, rk);
@@ -782,6 +790,23 @@ int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* 
     }
     return vgpa_internal_attn_fwd_redo(q, k, v, o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt, tasks, flags, stream,
                                        ores, sor, rk);
+}
+int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* o, void* o_res, int32_t res_kind, float* lse2, const int64_t* q_strides,
+                             const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* ores_strides, int64_t B,
+                             int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes,
+                             hipStream_t stream) {
+    return fwd_w1_impl(q, k, v, o, o_res, res_kind, lse2, q_strides, k_strides, v_strides, o_strides, ores_strides, B, H, S, head_dim, scale, split_mode, workspace,
+                       ws_bytes, stream, false);
+}
+// Same arguments, same results, same workspace: EVERY strip on the online-softmax (running-maximum) kernel.  For inputs whose row maxima lie further below
+// |q| max|k| than the bound-shifted kernel represents (most strips of vgpa_attn_fwd_w1_res flagged: its redo count is the first int32 block of the workspace
+// behind the B*H kmax words) this is the faster call: one sweep instead of two (videogpa_amd.transformer.AttentionCore switches on the measured count).
+int32_t vgpa_attn_fwd_online_res(const void* q, const void* k, const void* v, void* o, void* o_res, int32_t res_kind, float* lse2, const int64_t* q_strides,
+                                 const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* ores_strides, int64_t B,
+                                 int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace, size_t ws_bytes,
+                                 hipStream_t stream) {
+    return fwd_w1_impl(q, k, v, o, o_res, res_kind, lse2, q_strides, k_strides, v_strides, o_strides, ores_strides, B, H, S, head_dim, scale, split_mode, workspace,
+                       ws_bytes, stream, true);
 }
 int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                          const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale,

@@ -437,6 +437,49 @@ def lora_grad(u, v, s=1.0):
     return g
 
 
+# ---------------------------------------------------------------------------------------------------------------- vendor-GEMM solution selection
+# The dense projections are hipBLASLt's (north_star: MFMA by hand for attention and LoRA only): 31 % of the cfg2 step.  torch asks hipBLASLt's heuristic for ONE
+# solution per shape; the library holds hundreds that are valid for it.  tools/gemm_tune.py times every one of them at the shapes of the step (PyTorch TunableOp:
+# the same hipblasLtMatmul call, algo chosen by index) and writes the winners to videogpa_amd/tuned/tunableop_gfx950.csv; use_tuned_gemms() makes torch pick them.
+# The file is keyed by (torch, ROCm, hipBLASLt versions, gfx arch): on any other stack torch ignores it and the default heuristic runs -- never a wrong kernel.
+TUNED_GEMM_FILE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
+_TUNED_GEMMS = None          # None: undecided; else {"enabled": bool, "file": path | None, "entries": int}
+
+
+def use_tuned_gemms(enabled=True, path=None):
+    """Select the vendor-GEMM solutions found by tools/gemm_tune.py (PyTorch TunableOp reading a results file, tuning itself OFF: an unknown shape runs the default
+    heuristic's kernel).  Called once by the trainers (config key "tuned_gemms", default True); process-wide because torch's GEMM dispatch is.  -> the decision, logged
+    by the caller.  A process that already runs TunableOp its own way (PYTORCH_TUNABLEOP_ENABLED set) is left alone."""
+    global _TUNED_GEMMS
+    import torch.cuda.tunable as tn
+    if _os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is not None:
+        _TUNED_GEMMS = {"enabled": tn.is_enabled(), "file": tn.get_filename(), "entries": None, "note": "PYTORCH_TUNABLEOP_* set by the caller: left as is"}
+        return _TUNED_GEMMS
+    path = path or TUNED_GEMM_FILE
+    if not torch.cuda.is_available():
+        _TUNED_GEMMS = {"enabled": False, "file": None, "entries": 0}
+        return _TUNED_GEMMS
+    if not enabled or not _os.path.isfile(path):
+        if _TUNED_GEMMS is not None and _TUNED_GEMMS.get("enabled"):
+            tn.enable(False)
+        _TUNED_GEMMS = {"enabled": False, "file": None, "entries": 0}
+        return _TUNED_GEMMS
+    if _TUNED_GEMMS is not None and _TUNED_GEMMS.get("enabled") and _TUNED_GEMMS.get("file") == path:
+        return _TUNED_GEMMS
+    with open(path) as f:
+        entries = sum(1 for ln in f if ln.startswith(("Gemm", "ScaledGemm")))
+    tn.enable(True)
+    tn.tuning_enable(False)
+    tn.record_untuned_enable(False)
+    tn.set_filename(path, False)
+    _TUNED_GEMMS = {"enabled": True, "file": path, "entries": entries}
+    return _TUNED_GEMMS
+
+
+def tuned_gemms_state():
+    return _TUNED_GEMMS
+
+
 # dX = dY W of a frozen projection: torch.autograd issues it as an "NN" GEMM, which hipBLASLt runs 4-25 % slower at these
 # shapes than the "TN" form x W^T (tools/gemm_bench.py: fused q,k,v 1.91 -> 1.44 ms, FF 2.24 -> 2.07 / 2.08 -> 1.89 ms).  The
 # base weights never change during LoRA training, so a transposed copy is kept next to each weight (11 GB for CogVideoX-5B,
@@ -924,7 +967,37 @@ def prescale_q(q, scale=None):
     return (q.float() * (scale * LOG2E)).to(q.dtype)
 
 
-def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o_pad=0, o_res=None):
+class AttnFwdPolicy:
+    """Which forward one attention layer runs, decided from what the kernel itself reports.  "bound": the w1 kernel (softmax shifted by a row bound instead of a
+    running maximum; strips whose rows it cannot represent are flagged and redone inside the same call by the online-softmax kernel -- results never depend on
+    it, time does: + 1.05 launches' worth per flagged strip).  "online": every strip on the online-softmax kernel (vgpa_attn_fwd_online_res), the faster call once
+    more than SWITCH of the strips would be redone.  The flags of a layer's first CHECKS calls (and of every RECHECK-th call after) are read back -- one host
+    sync each -- and the layer switches for good when the flagged fraction exceeds SWITCH.  `fixed` pins the mode (tools, tests)."""
+    SWITCH, CHECKS, RECHECK = 0.05, 2, 1024
+
+    def __init__(self, mode="bound", fixed=False):
+        self.mode, self.fixed = mode, fixed
+        self.calls = 0
+        self.redo_fraction = None          # of the most recent observed call
+        self.switched_at = None
+
+    def wants_flags(self):
+        return self.mode == "bound" and not self.fixed and (self.calls < self.CHECKS or self.calls % self.RECHECK == 0)
+
+    def observe(self, fraction):
+        self.redo_fraction = fraction
+        if not self.fixed and fraction > self.SWITCH:
+            self.mode, self.switched_at = "online", self.calls
+
+
+def attention_redo_fraction(ws, B, H, S):
+    """fraction of the (batch, head, 256-row strip) tasks the last vgpa_attn_fwd_w1* call on workspace `ws` flagged and redid (synchronises)"""
+    tasks = B * H * ((S + 255) // 256)
+    flags = ws[:4 * (B * H + tasks)].view(torch.int32)[B * H:]
+    return float((flags != 0).float().mean())
+
+
+def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o_pad=0, o_res=None, policy=None):
     """q,k,v: bf16 [B,H,S,64] views (any batch/head/token strides).  -> o [B,S,H*64] bf16, lse2 [B,H,S] fp32.
     o_res: optional [B,S,H*64] buffer, bf16 or uint8, that receives what the output's bf16 rounding dropped (w1 forward only; see "Precise delta").
     split_mode: -1 lets the launcher cut the tasks of a mostly empty last scheduling round into key-range chunks,
@@ -941,15 +1014,15 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
     if "fwd" in ATTN_W1:
         ws_bytes = _lib.query("vgpa_attn_fwd_w1_workspace_bytes", B, H, S)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-        if o_res is not None:
-            rv = o_res.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
-            _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
-                "vgpa_attn_fwd_w1_res", q, k, v, o, o_res, _res_kind(o_res), lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), _bhs_strides(rv),
-                B, H, S, Dh, float(scale), int(split_mode), ws, ws_bytes, _stream()))
-            return o, lse
+        rv = None if o_res is None else o_res.unflatten(-1, (H, Dh)).permute(0, 2, 1, 3)
+        entry = "vgpa_attn_fwd_online_res" if (policy is not None and policy.mode == "online") else "vgpa_attn_fwd_w1_res"
         _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
-            "vgpa_attn_fwd_w1", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), B, H, S, Dh,
-            float(scale), int(split_mode), ws, ws_bytes, _stream()))
+            entry, q, k, v, o, o_res, _res_kind(o_res), lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(ov), None if rv is None else _bhs_strides(rv),
+            B, H, S, Dh, float(scale), int(split_mode), ws, ws_bytes, _stream()))
+        if policy is not None:
+            if policy.wants_flags() and not torch.cuda.is_current_stream_capturing():
+                policy.observe(attention_redo_fraction(ws, B, H, S))
+            policy.calls += 1
         return o, lse
     if o_res is not None:
         raise RuntimeError("attention_fwd_raw: o_res needs the w1 forward (VGPA_ATTN_W1 includes fwd)")
@@ -1115,7 +1188,7 @@ class _QKNormAttentionFn(torch.autograd.Function):
     QK-norm (+ optional 3D RoPE on tokens >= text_len) -> flash attention; backward returns dqkv in the same layout."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad, rope_mode=0, recompute_qk=False, precise_delta=None):
+    def forward(ctx, qkv, wq, bq, wk, bk, rope_cos, rope_sin, text_len, H, eps, o_pad, grad_pad, rope_mode=0, recompute_qk=False, precise_delta=None, fwd_policy=None):
         """o_pad / grad_pad: the attention output / the gradient of qkv are returned as heads of buffers that much wider (the
         LoRA tails of the projections on either side, see LoraExt).  recompute_qk: the normalised q / k are not kept for the backward
         but made again from qkv (one more pass of the QK-norm kernel, bit-identical) -- a third of this node's saved bytes."""
@@ -1134,7 +1207,7 @@ class _QKNormAttentionFn(torch.autograd.Function):
         o_res = None
         if precise_delta and "fwd" in ATTN_W1 and ctx.needs_input_grad[0]:
             o_res = torch.empty(B, S, H * Dh, dtype=torch.uint8 if precise_delta == "int8" else torch.bfloat16, device=qkv.device)
-        o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad, o_res=o_res)
+        o, lse = attention_fwd_raw(qn, kn, v, q_prescaled=True, o_pad=o_pad, o_res=o_res, policy=fwd_policy)
         if recompute_qk:
             ctx.save_for_backward(qkv, o, lse, wq, wk, rope_cos, rope_sin, bq, bk, o_res)
         else:
@@ -1173,16 +1246,16 @@ class _QKNormAttentionFn(torch.autograd.Function):
             "vgpa_qknorm_rope_bwd", dqn, dkn, q_in, k_in, dq_in, dk_in, _bhs_strides(dqn), _bhs_strides(dkn), _bhs_strides(q_in),
             _bhs_strides(k_in), _bhs_strides(dq_in), _bhs_strides(dk_in), wq, wk, rope_cos, rope_sin, text_len, B, H, S, Dh,
             float(eps), rope_mode, _stream()), "byte")
-        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0, rope_mode=0, recompute_qk=False, precise_delta="int8"):
+def qknorm_attention(qkv, wq, bq, wk, bk, H, text_len=0, rope=None, eps=1e-6, o_pad=0, grad_pad=0, rope_mode=0, recompute_qk=False, precise_delta="int8", fwd_policy=None):
     """rope = (cos, sin) fp32 [S - text_len, 64]; rope_mode 0: interleaved pairs (diffusers' CogVideoX), 1: half-split pairs inside each
     32-feature half (VGGT's RotaryPositionEmbedding2D, tables from `rope2d_tables`).  precise_delta: "int8" | "bf16" | None, see "Precise delta"."""
     cos, sin = (None, None) if rope is None else rope
     if precise_delta not in (None, "int8", "bf16"):
         raise ValueError(f'precise_delta: "int8", "bf16" or None, got {precise_delta!r}')
-    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad, rope_mode, bool(recompute_qk), precise_delta)
+    return _QKNormAttentionFn.apply(qkv, wq, bq, wk, bk, cos, sin, text_len, H, eps, o_pad, grad_pad, rope_mode, bool(recompute_qk), precise_delta, fwd_policy)
 
 
 def rope2d_tables(pos, head_dim=64, frequency=100.0):

@@ -40,6 +40,7 @@ DEFAULT_CONFIG: Dict[str, Any] = {
     "lean_activations": "auto",
     "metric_name": "consistency_score", "min_gap": 0.05, "motion_threshold": 1e-3,
     "log_every_n_steps": 10,
+    "tuned_gemms": True,                      # pick the hipBLASLt solutions of videogpa_amd/tuned/ (ops.use_tuned_gemms); False = the library's default heuristic
     "seed": 0,                                # (t, eps) stream = seed + rank: every rank draws its own
 }
 
@@ -119,6 +120,7 @@ class CogVideoXDPOTrainer(nn.Module):
         self.global_step = 0
         self._rng = None
         self.after_reference = None     # hook between the frozen-reference pass and the policy pass (set by DPOEngine)
+        self.tuned_gemms = ops.use_tuned_gemms(bool(cfg.get("tuned_gemms", True)))      # vendor-GEMM solutions of tools/gemm_tune.py, when the file matches this stack
 
     @staticmethod
     def _lean_setting(v):

@@ -182,6 +182,7 @@ class AttentionCore:
         self._fused = None
         self._qkv_ext = self._out_ext = None
         self.precise_delta = ops.precise_delta_default()     # "int8" | "bf16" | None: what the forward keeps of its output for the backward's delta (ops "Precise delta")
+        self.fwd_policy = ops.AttnFwdPolicy()                # bound-shifted or online-softmax forward, from the kernel's own redo count (ops.AttnFwdPolicy)
 
     def fused_qkv(self):
         """[3D, D] weight / [3D] bias, cached while the three base weights are unchanged (frozen base)."""
@@ -231,7 +232,7 @@ class AttentionCore:
             qkv = ops.frozen_linear(n, W, b)
         a = ops.qknorm_attention(qkv, _f32(m.norm_q.weight), _f32(m.norm_q.bias), _f32(m.norm_k.weight), _f32(m.norm_k.bias),
                                  m.heads, text_len, rope, self.qk_eps, o_pad=out_pad, grad_pad=in_pad, recompute_qk=lean_src is not None,
-                                 precise_delta=self.precise_delta)
+                                 precise_delta=self.precise_delta, fwd_policy=self.fwd_policy)
         wo, bo, _ = _parts(m.to_out[0])
         if out_pad:
             if self._out_ext is None:
@@ -352,6 +353,11 @@ class CogVideoXTransformer3DModel(nn.Module):
             raise ValueError(f'precise_delta: "int8", "bf16" or None, got {mode!r}')
         for blk in self.transformer_blocks:
             blk.attn1.core.precise_delta = mode
+
+    def attention_forward_report(self):
+        """per block: which forward its attention runs and the fraction of strips the bound-shifted kernel last had to redo (ops.AttnFwdPolicy)"""
+        return [{"block": i, "mode": b.attn1.core.fwd_policy.mode, "redo_fraction": b.attn1.core.fwd_policy.redo_fraction,
+                 "switched_at_call": b.attn1.core.fwd_policy.switched_at} for i, b in enumerate(self.transformer_blocks)]
 
     # ------------------------------------------------------------------ diffusers-style protocol
     @property

@@ -24,7 +24,7 @@ DEFAULT_CONFIG: Dict[str, Any] = {           # train/Wan2.2-TI2V-5B/03_train.py:
     "learning_rate": 5e-6, "beta": 1.0, "max_steps": 10000, "warmup_steps": 500, "batch_size": 1, "accumulate_grad_batches": 2,
     "gradient_clip_val": 1.0, "weight_decay": 0.01, "num_train_timesteps": 1000, "shift": 5.0,
     "lora_rank": 64, "lora_alpha": 128.0, "lora_dropout": 0.0, "lora_target_modules": ["q", "k", "v", "o"],
-    "patch_size": (1, 2, 2), "seed": 0,
+    "patch_size": (1, 2, 2), "seed": 0, "tuned_gemms": True,
     "pair_batch": True,      # MI355X-first: win and lose as one batch through the denoiser (False = two calls, like the reference)
     # the reference recomputes every block in the backward (03_train.py:150-159, sized for 80 GB parts); 288 GB hold the activations of
     # the full-size pair step (measured 206 GB), which saves one forward in five: None leaves the model as the caller configured it,
@@ -64,6 +64,7 @@ class WanDPOTrainer(nn.Module):
         self.global_step = 0
         self._rng = None
         self.after_reference = None      # DPOEngine's hook: a deferred optimizer step lands between the reference and the policy pass
+        self.tuned_gemms = ops.use_tuned_gemms(bool(cfg.get("tuned_gemms", True)))
         if cfg["enable_gradient_checkpointing"] is not None:
             base = self.transformer.get_base_model()
             if not hasattr(base, "enable_gradient_checkpointing"):
