@@ -1,5 +1,6 @@
 """Cross-attention shape of the Wan2.2 step (Sq = 18480 video tokens, Skv = 512 text tokens, B*H = 48) through ops.attention128, forward + backward,
-timed per entry; run once per VGPA_ATTN128_MIN_SWEEP setting:   PYTHONPATH=. VGPA_ATTN128_MIN_SWEEP=512 python tools/attn128_cross_time.py"""
+timed per entry; run once per sweep-length setting, which is a compile-time constant of a variant build since round 6 (the library reads no environment):
+    tools/build_variant.sh sweep512 -DATTN128_W1_MIN_KEYS=512 && VGPA_LIB=$PWD/var/lib_sweep512.so PYTHONPATH=. python tools/attn128_cross_time.py"""
 import os
 
 import torch
@@ -22,5 +23,5 @@ for _ in range(5):
     o.backward(do)
 torch.cuda.synchronize()
 for name, s in ops.TIMER.summary().items():
-    print(f"min_sweep={os.environ.get('VGPA_ATTN128_MIN_SWEEP', 'default'):8s} {name:28s} {s['avg_ms']:7.3f} ms")
+    print(f"lib={os.path.basename(os.environ.get('VGPA_LIB', 'product')):16s} {name:28s} {s['avg_ms']:7.3f} ms")
 print("checksums", float(o.float().abs().sum()), float(q.grad.float().abs().sum()), float(k.grad.float().abs().sum()), float(v.grad.float().abs().sum()))

@@ -7,7 +7,7 @@ knob=$1
 rm -rf /tmp/tree_knob && mkdir -p /tmp/tree_knob && cp -r $R/videogpa_amd $R/tools $R/include $R/profiles /tmp/tree_knob/
 cd /tmp/tree_knob
 W1_KNOBS=$knob python tools/gen_w1_asm.py > /dev/null
-for f in w1_dq_loop w1_dkv_loop w1_fwd128_loop w1_fwd128f8_loop w1_dkv128_loop w1_dq128_loop w1_dq128x2_loop w1_gemm_loop; do cp $R/videogpa_amd/csrc/$f.inc videogpa_amd/csrc/$f.inc; done
+for f in w1_dq_loop w1_dkv_loop w1_fwd128_loop w1_fwd128f8_loop w1_dkv128_loop w1_dq128_loop w1_dq128x2_loop; do cp $R/videogpa_amd/csrc/$f.inc videogpa_amd/csrc/$f.inc; done
 python -m videogpa_amd.build --force > /dev/null 2>&1
 for rep in 1 2; do
   echo "== product loop (run $rep)"; cd $R && python tools/attn_bench.py --iters 3 --which fwd --energy 1.5 2>&1 | grep -E "^attn_fwd "

@@ -1492,7 +1492,8 @@ def main():
     a = ap.parse_args()
     bad = 0
     for name, gen in TARGETS.items():
-        path = os.path.join(ROOT, "videogpa_amd", "csrc", name)
+        # the GEMM probe's loop belongs to a variant build only (tools/variants/gemm_w1.hip); everything else is product source
+        path = os.path.join(ROOT, "tools", "variants", name) if name.startswith("w1_gemm_") else os.path.join(ROOT, "videogpa_amd", "csrc", name)
         text = f"// GENERATED by tools/gen_w1_asm.py -- do not edit; regenerate with `python tools/gen_w1_asm.py`\n" + gen()
         if a.check:
             if not os.path.exists(path) or open(path).read() != text:

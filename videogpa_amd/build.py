@@ -34,7 +34,7 @@ def _compile(src, force):
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
     if force or _stale(obj, [src] + headers):
         # the MFMA kernels keep fp32 adds / multiplies unpacked: v_pk_*_f32 does not co-issue with the matrix pipe (attention.hip)
-        extra = ["-fno-slp-vectorize"] if os.path.basename(src) in ("attention.hip", "attention_w1.hip", "attention_hd128.hip", "gemm_w1.hip", "lora.hip") else []
+        extra = ["-fno-slp-vectorize"] if os.path.basename(src) in ("attention.hip", "attention_w1.hip", "attention_hd128.hip", "lora.hip") else []
         r = subprocess.run([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

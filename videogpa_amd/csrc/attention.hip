@@ -51,225 +51,8 @@
 #endif
 #define PSUM_TRIGGER 1024.0f   // a half-lane tile sum above this (or inf/NaN) means some score outgrew the running max by > ~2^5
 
-#ifdef VGPA_VARIANTS   // the first-generation three-block forward (phase-stamp diagnostics): variant builds only
-// QB = 32-row query blocks per wave.
-// Softmax bookkeeping is kept off the VALU (the kernel is VALU-issue bound at head_dim 64):
-//  * Q arrives pre-scaled by scale*log2(e) (vgpa_qknorm_rope_fwd's q_out_scale; one rounding), and -m (running max)
-//    is folded into the QK^T MFMA chain by one extra k-step, so P = exp2(accumulator) with no per-score FMA;
-//  * the per-tile row max is NOT computed on the fast path: P is formed optimistically against the current m and the
-//    tile's partial sum is checked; only when a wave sees a sum above PSUM_TRIGGER (always on the first tile) does it
-//    take the slow path: recompute S, take the true max, raise m, rescale O and l (wave-uniform, so both half-lanes
-//    of a row always share one m).  P stays <= ~2^10, harmless in bf16 / fp32.
-template <int QB, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 8 && QB == 1) ? 4 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                         const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                         float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
-                                                         int S, int H, int n_qt) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // K[2], V[2]
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = vid / n_qt, qt = vid % n_qt;
-    const int b = bh / H, h = bh % H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int q0 = (qt * NW + wave) * (32 * QB);
-
-    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
-    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
-    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
-
-    bf16x8_t qf[QB][4], qx[QB];
-    f32x16_t o[QB][2];
-    float m[QB], l[QB];
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        load_row_frags(Qb, sq.s, q0 + 32 * j, S, lane, qf[j]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
-        m[j] = -INFINITY;
-        l[j] = 0.f;
-        qx[j] = shift_frag(0.f, hi);
-    }
-    bf16x8_t kx;   // K-side of the shift k-step: ones in k-slots 0..2 of the lower half-lanes
-    {
-        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
-        kx = f32_to_frag(o8);
-    }
-
-    const int nt = (S + TILE - 1) / TILE;
-    u32x4_t kr[8 / NW], vr[8 / NW];
-    tile_load(Kb, sk.s, 0, S, kr);
-    tile_load(Vb, sv.s, 0, S, vr);
-    tile_store(lds, kr);
-    tile_store(lds + 2 * TILE_ELEMS, vr);
-#pragma unroll
-    for (int j = 0; j < QB; ++j) frags_arrived(qf[j]);
-    const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
-    const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
-#ifdef FWD_DIAG
-    unsigned diag_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long diag_start = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const bf16_t* kl = lds + (t & 1) * TILE_ELEMS;
-        const bf16_t* vl = lds + (2 + (t & 1)) * TILE_ELEMS;
-        if (t + 1 < nt) {
-            tile_load_buf(krs, sk.s, (t + 1) * TILE, koff, kr);
-            tile_load_buf(vrs, sv.s, (t + 1) * TILE, voff, vr);
-        }
-        const bool tail = (t == nt - 1) && (S & (TILE - 1));
-        DIAG_STAMP(0);
-        f32x16_t s[QB][2];
-        float psum[QB];
-        bool slow = (t == 0) || tail;   // the ragged last tile is masked on the slow path only: the fast path stays branch-free
-        if (!slow) {
-            // fast path: accumulators = c*q.k - m  ->  P = exp2(.)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int j = 0; j < QB; ++j) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
-                    s[j][kb] = mfma32(kx, qx[j], s[j][kb]);
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < QB; ++j) {
-                f32x2_t ps2 = {0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const f32x2_t p = {__builtin_amdgcn_exp2f(s[j][kb][r]), __builtin_amdgcn_exp2f(s[j][kb][r + 1])};
-                        s[j][kb][r] = p[0];
-                        s[j][kb][r + 1] = p[1];
-                        ps2 += p;
-                    }
-                psum[j] = ps2[0] + ps2[1];
-                slow = slow || !(psum[j] <= PSUM_TRIGGER);
-            }
-            slow = __any(slow);
-        }
-        if (slow) {
-            // slow path (first tile, or a row outgrew its running max): exact max, raise m, rescale
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int j = 0; j < QB; ++j)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < QB; ++j) {
-                if (tail) {
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (t * TILE + kb * 32 + acc_row(r, hi) >= S) s[j][kb][r] = -INFINITY;
-                }
-                float mx = s[j][0][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[j][0][r]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][1][r]);
-                mx = fmaxf(mx, other_half(mx));
-                const float m_new = fmaxf(m[j], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
-                m[j] = m_new;
-                qx[j] = shift_frag(m_new, hi);
-                l[j] *= alpha;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { o[j][0][i] *= alpha; o[j][1][i] *= alpha; }
-                float ps = 0.f;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(s[j][kb][r] - m_new);
-                        s[j][kb][r] = p;
-                        ps += p;
-                    }
-                psum[j] = ps;
-            }
-        }
-        DIAG_STAMP(1);
-#pragma unroll
-        for (int j = 0; j < QB; ++j) l[j] += psum[j];
-        if (t + 1 < nt) {   // the other buffer is free since the last barrier: store before the PV product so the LDS write latency hides under it
-            tile_store(lds + ((t + 1) & 1) * TILE_ELEMS, kr);
-            tile_store(lds + (2 + ((t + 1) & 1)) * TILE_ELEMS, vr);
-        }
-        // O^T[d, q] += V^T[d, key] P^T[key, q]; each V fragment feeds all QB query blocks
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                bf16x8_t pf[QB];
-#pragma unroll
-                for (int j = 0; j < QB; ++j) pf[j] = pack_frag(s[j][kb], 8 * cc);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const bf16x8_t vf = frag_tr(vl, kb * 32 + 16 * cc, db * 32, lane);
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) o[j][db] = mfma32(vf, pf[j], o[j][db]);
-                }
-            }
-        DIAG_STAMP(2);
-        __syncthreads();
-        DIAG_STAMP(3);
-    }
-
-#ifdef FWD_DIAG
-    {
-        const unsigned long long diag_end = __builtin_amdgcn_s_memtime();
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if (lane == 0) {
-            unsigned* d = reinterpret_cast<unsigned*>(LSE2) + ((size_t)blockIdx.x * NW + wave) * 32;
-            d[0] = hwid; d[1] = xcc; d[2] = (unsigned)diag_start; d[3] = (unsigned)(diag_start >> 32);
-            d[4] = (unsigned)diag_end; d[5] = (unsigned)(diag_end >> 32); d[6] = vid; d[7] = 0;
-            for (int i = 0; i < 16; ++i) d[16 + i] = diag_t[i];
-        }
-    }
-#endif
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        const float lt = l[j] + other_half(l[j]);
-        const float inv = 1.f / lt;
-        const int q = q0 + 32 * j + (lane & 31);
-        if (q < S) {
-            bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2_t w;
-                    w[0] = pack_bf16x2(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv);
-                    w[1] = pack_bf16x2(o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
-                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
-                }
-#ifndef FWD_DIAG
-            if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
-#endif
-        }
-    }
-}
-
+#ifdef VGPA_VARIANTS   // measured-slower experiments / diagnostics live in tools/variants/ (variant builds only)
+#include "attn_fwd_v1_kernel.inc"
 #endif  // VGPA_VARIANTS
 
 // =====================================================================================================
@@ -618,341 +401,8 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
     if (lane == 0) LSE2[(int64_t)bh * S + q] = M + __builtin_amdgcn_logf(L);
 }
 
-#ifdef VGPA_VARIANTS   // measured-slower experiment: variant builds only
-// =====================================================================================================
-// Forward, PING-PONG (selected by VGPA_ATTN_FWD=pp).  The forward is VALU-issue bound at head_dim 64: per 64 x 64 score tile a
-// wave has ~1150 matrix-pipe cycles (36 MFMAs) and ~1300-1450 VALU cycles (64 exp, 64 adds, 32 packs per lane), and inside ONE wave
-// they overlap badly (the dependent chain MFMA -> exp -> pack -> MFMA); two free-running waves on a SIMD do not phase-lock either
-// (2120 SIMD-cycles per wave-tile against ~1250 for a perfectly overlapped pair).  Here the overlap is made explicit
-// ACROSS the two waves of a SIMD: a 512-thread workgroup = 8 waves, waves 0-3 (group 0) and 4-7 (group 1) run the same sequence
-//       M(t): S_t = K_t Q^T (with -m folded in)  and  O += V_{t-1}^T P_{t-1}^T         36 MFMAs + LDS fragment reads, no VALU
-//       V(t): P_t = exp2(S_t), row sums, the max check, pack to bf16                      VALU only
-// one phase apart, with a workgroup barrier after every phase -- so on every SIMD one wave is always in an M phase while its partner
-// is in a V phase, and a pure-MFMA wave next to a pure-VALU wave co-issue almost perfectly (tools/ubench_mix).  The K / V tiles are
-// staged once per workgroup for 512 query rows (half the LDS fill traffic per row of the 4-wave kernels): 3-slot rings, the global
-// loads of tile t+2 (K) / t+1 (V) are issued by all threads in even phases and stored in odd phases, which no reader of the slot can
-// overlap (see the slot arithmetic at stage_store).  Softmax bookkeeping is the checked form of attn_fwd_kernel (V1): P is formed
-// against the running max folded into the MFMA chain; a tile sum above PSUM_TRIGGER (and the first / ragged tile) takes the slow
-// path -- recompute S, exact max, rescale -- inside the V phase (rare).
-//
-// MEASURED (MI355X, headline shape, profiles/r02g_pingpong_forward.txt) -- a NEGATIVE result, kept selectable and parity-tested like
-// the fused backward: 8.0-8.4 ms against 7.0 ms for attn_fwd_pipe_kernel.  Ablations of this kernel: V phases only (no MFMA issued)
-// 4.65 ms, M phases only (no exp / sums / packs) 6.77 ms, both 8.2 ms.  The M phase alone needs ~1800 cycles for its 1152 cycles of
-// MFMAs: the wave has the matrix pipe to itself, so every LDS fragment round trip (24 reads per tile, issued just in time because the
-// allocator is at 256 VGPRs with spills) is exposed -- in the free-running kernels the SIMD partner fills exactly those bubbles.
-// Requesting all fragments of a phase up front needs ~64 more registers than a QB = 2 wave has (tried: 49 spills); QB = 1 has the
-// registers but reads one LDS fragment per MFMA (LDS ~80 % busy).  s_setprio(3) around the M phase made it slower (8.8 ms).  The
-// wave -> SIMD map needed for the pairing is (w, w + 4) on this part (tools/hwid_probe: 1024 of 1024 workgroups), read from HW_ID.
-// =====================================================================================================
-#define PP_NW 8
-__device__ __forceinline__ void pp_barrier() {
-    // LDS traffic of this phase must be complete; the global loads in flight (next tiles) deliberately cross the barrier
-#ifdef PP_NO_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
-
-#ifdef PP_NO_MFMA   // timing experiment only: the M phase keeps its LDS reads but issues no MFMA
-__device__ __forceinline__ f32x16_t pp_fake_mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
-    asm volatile("" ::"v"(a), "v"(b));
-    return c;
-}
-#define PP_MFMA pp_fake_mfma
-#else
-#define PP_MFMA mfma32
-#endif
-template <int QB, bool DO_S, bool DO_PV>
-__device__ __forceinline__ void pp_phase_m(const bf16_t* kl, const bf16_t* vl, int lane, const bf16x8_t& kx, const bf16x8_t (&qx)[QB],
-                                           const bf16x8_t (&qf)[QB][4], const bf16x8_t (&pf)[QB][2][2], f32x16_t (&s)[QB][2],
-                                           f32x16_t (&o)[QB][2]) {
-    // All PV products first (they consume the packed P_{t-1}; 4 independent accumulators o[j][db]), then the new scores with the
-    // two key halves interleaved (4 independent accumulators s[j][kb]): consecutive MFMAs never depend on each other, and the packed
-    // P is dead before any score register is written again (the allocator can give both the same registers).
-    if (DO_PV) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const bf16x8_t vf = frag_tr(vl, kb * 32 + 16 * cc, db * 32, lane);
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) o[j][db] = PP_MFMA(vf, pf[j][kb][cc], o[j][db]);
-                }
-    }
-    if (DO_S) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int j = 0; j < QB; ++j) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
-                s[j][kb] = PP_MFMA(kx, qx[j], s[j][kb]);                     // - m
-            }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
-#pragma unroll
-                for (int j = 0; j < QB; ++j) s[j][kb] = PP_MFMA(kf, qf[j][ks], s[j][kb]);
-            }
-    }
-}
-
-template <int QB>
-__device__ __forceinline__ void pp_phase_v(const bf16_t* kl, int t, int S, bool force_slow, bool tail, int lane, int hi, const bf16x8_t (&qf)[QB][4],
-                                           bf16x8_t (&qx)[QB], float (&m)[QB], float (&l)[QB], f32x16_t (&o)[QB][2], f32x16_t (&s)[QB][2],
-                                           bf16x8_t (&pf)[QB][2][2]) {
-    float psum[QB];
-    bool slow = force_slow;
-#ifdef PP_NO_V   // timing experiment only
-    if (!slow) {
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            psum[j] = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) asm volatile("" : "=v"(pf[j][kb][cc]) : "v"(s[j][kb]));
-            l[j] += 1.f;
-        }
-        return;
-    }
-#endif
-    if (!slow) {
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-#ifdef PP_NO_EXP
-                    const float a = s[j][kb][r] * 1e-9f, b = s[j][kb][r + 1] * 1e-9f;
-#else
-                    const float a = __builtin_amdgcn_exp2f(s[j][kb][r]), b = __builtin_amdgcn_exp2f(s[j][kb][r + 1]);
-#endif
-                    s[j][kb][r] = a;
-                    s[j][kb][r + 1] = b;
-                    p0 = nopack_add(p0, a);
-                    p1 = nopack_add(p1, b);
-                }
-            psum[j] = p0 + p1;
-            slow = slow || !(psum[j] <= PSUM_TRIGGER);
-        }
-        slow = __any(slow);
-    }
-    if (slow) {   // first tile, ragged tile, or a row outgrew its running max: exact max, raise m, rescale (MFMAs in a V phase: rare)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int j = 0; j < QB; ++j)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = frag_row(kl, kb * 32, ks, lane);
-#pragma unroll
-                for (int j = 0; j < QB; ++j) s[j][kb] = mfma32(kf, qf[j][ks], s[j][kb]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            if (tail) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (t * TILE + kb * 32 + acc_row(r, hi) >= S) s[j][kb][r] = -INFINITY;
-            }
-            float mx = s[j][0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[j][0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][1][r]);
-            mx = fmaxf(mx, other_half(mx));
-            const float m_new = fmaxf(m[j], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
-            m[j] = m_new;
-            qx[j] = shift_frag(m_new, hi);
-            l[j] *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o[j][0][i] *= alpha; o[j][1][i] *= alpha; }
-            float ps = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[j][kb][r] - m_new);
-                    s[j][kb][r] = pv;
-                    ps += pv;
-                }
-            psum[j] = ps;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        l[j] += psum[j];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) pf[j][kb][cc] = pack_frag(s[j][kb], 8 * cc);
-    }
-}
-
-template <int QB>
-__global__ __launch_bounds__(64 * PP_NW, 2) void attn_fwd_pp_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                     const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                                     float* __restrict__ LSE2, TStride sq, TStride sk, TStride sv, TStride so,
-                                                                     int S, int H, int n_qt) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[6 * TILE_ELEMS];   // K ring [3], V ring [3]
-    __shared__ int simd_of[PP_NW];
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = vid / n_qt, qt = vid % n_qt;
-    const int b = bh / H, h = bh % H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int q0 = (qt * PP_NW + wave) * (32 * QB);
-    {   // which SIMD did the hardware put this wave on?  (HW_ID bits [5:4]; the wave -> SIMD map is not architected)
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (lane == 0) simd_of[wave] = (int)((hwid >> 4) & 3u);
-    }
-
-    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
-    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
-    const bf16_t* Vb = V + ((size_t)b * sv.b + (size_t)h * sv.h);
-    bf16_t* const kring = lds;
-    bf16_t* const vring = lds + 3 * TILE_ELEMS;
-
-    bf16x8_t qf[QB][4], qx[QB], pf[QB][2][2];
-    f32x16_t o[QB][2], s[QB][2];
-    float m[QB], l[QB];
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        load_row_frags(Qb, sq.s, q0 + 32 * j, S, lane, qf[j]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
-        m[j] = -INFINITY;
-        l[j] = 0.f;
-        qx[j] = shift_frag(0.f, hi);
-    }
-    bf16x8_t kx;
-    {
-        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
-        kx = f32_to_frag(o8);
-    }
-    const int nt = (S + TILE - 1) / TILE;
-    const bool ragged = (S & (TILE - 1)) != 0;
-    const rsrc_t krs = tile_rsrc(Kb, sk.s, S), vrs = tile_rsrc(Vb, sv.s, S);
-    const uint32_t koff = tile_lane_byte_offset(sk.s), voff = tile_lane_byte_offset(sv.s);
-    u32x4_t kr[1], vr[1];
-    // prologue: K_0, K_1, V_0 (rows past S read as zeros)
-    tile_load_buf(krs, sk.s, 0, koff, kr);
-    tile_store(kring, kr);
-    tile_load_buf(krs, sk.s, TILE, koff, kr);
-    tile_store(kring + TILE_ELEMS, kr);
-    tile_load_buf(vrs, sv.s, 0, voff, vr);
-    tile_store(vring, vr);
-#pragma unroll
-    for (int j = 0; j < QB; ++j) frags_arrived(qf[j]);
-    __syncthreads();
-    // group = rank of this wave among the waves that share its SIMD (2 waves per SIMD at 256 VGPRs): the two partners of a SIMD are
-    // always in opposite phases.  Any placement is correct; only the MFMA / VALU overlap depends on it.
-    int grp_v = 0;
-#pragma unroll
-    for (int w = 0; w < PP_NW; ++w) grp_v += (w < wave && simd_of[w] == simd_of[wave]) ? 1 : 0;
-    const int grp = __builtin_amdgcn_readfirstlane(grp_v) & 1;
-
-    // Global phase 2t: all threads issue the loads of K_{t+2}, V_{t+1};  phase 2t+1: all threads store them to slots (t+2)%3, (t+1)%3.
-    // Readers: group 0 runs M(t) [reads K slot t%3, V slot (t-1)%3] in phase 2t, group 1 in phase 2t+1; the slow path of V(t) re-reads
-    // K slot t%3 in phases 2t+1 / 2t+2.  A store in phase 2t+1 hits K slot (t+2)%3 = (t-1)%3 (last read in phase 2t-1 / 2t) and V slot
-    // (t+1)%3 = (t-2)%3 (last read by M(t-1) in phase 2t-1): never a slot somebody can still read, and barrier-separated from the
-    // next reader (phase 2t+4 / 2t+2).
-#define PP_STAGE_ISSUE(t)                                         \
-    do {                                                          \
-        tile_load_buf(krs, sk.s, ((t) + 2) * TILE, koff, kr);     \
-        tile_load_buf(vrs, sv.s, ((t) + 1) * TILE, voff, vr);     \
-    } while (0)
-#define PP_STAGE_STORE(t)                                              \
-    do {                                                               \
-        tile_store(kring + (((t) + 2) % 3) * TILE_ELEMS, kr);          \
-        tile_store(vring + (((t) + 1) % 3) * TILE_ELEMS, vr);          \
-    } while (0)
-#define PP_KL(t) (kring + ((t) % 3) * TILE_ELEMS)
-#define PP_VL(t) (vring + (((t) + 2) % 3) * TILE_ELEMS)     /* V_{t-1} */
-#define PP_V(t) pp_phase_v<QB>(PP_KL(t), (t), S, (t) == 0 || (ragged && (t) == nt - 1), ragged && (t) == nt - 1, lane, hi, qf, qx, m, l, o, s, pf)
-
-    if (grp == 0) {
-        // phases 0, 1: M(0) (scores only), V(0)
-        PP_STAGE_ISSUE(0);
-        pp_phase_m<QB, true, false>(PP_KL(0), PP_VL(0), lane, kx, qx, qf, pf, s, o);
-        pp_barrier();
-        PP_V(0);
-        PP_STAGE_STORE(0);
-        pp_barrier();
-        for (int t = 1; t < nt; ++t) {
-            PP_STAGE_ISSUE(t);
-            pp_phase_m<QB, true, true>(PP_KL(t), PP_VL(t), lane, kx, qx, qf, pf, s, o);
-            pp_barrier();
-            PP_V(t);
-            PP_STAGE_STORE(t);
-            pp_barrier();
-        }
-        // phases 2nt, 2nt+1: M(nt) = the last PV; then idle
-        pp_phase_m<QB, false, true>(PP_KL(nt), PP_VL(nt), lane, kx, qx, qf, pf, s, o);
-        pp_barrier();
-        pp_barrier();
-    } else {
-        // phase 0 idle (loads only), phase 1: M(0)
-        PP_STAGE_ISSUE(0);
-        pp_barrier();
-        pp_phase_m<QB, true, false>(PP_KL(0), PP_VL(0), lane, kx, qx, qf, pf, s, o);
-        PP_STAGE_STORE(0);
-        pp_barrier();
-        for (int t = 1; t < nt; ++t) {
-            PP_STAGE_ISSUE(t);
-            PP_V(t - 1);
-            pp_barrier();
-            pp_phase_m<QB, true, true>(PP_KL(t), PP_VL(t), lane, kx, qx, qf, pf, s, o);
-            PP_STAGE_STORE(t);
-            pp_barrier();
-        }
-        PP_V(nt - 1);
-        pp_barrier();
-        pp_phase_m<QB, false, true>(PP_KL(nt), PP_VL(nt), lane, kx, qx, qf, pf, s, o);
-        pp_barrier();
-    }
-#undef PP_STAGE_ISSUE
-#undef PP_STAGE_STORE
-#undef PP_KL
-#undef PP_VL
-#undef PP_V
-
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        const float lt = l[j] + other_half(l[j]);
-        const float inv = 1.f / lt;
-        const int q = q0 + 32 * j + (lane & 31);
-        if (q < S) {
-            bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2_t w;
-                    w[0] = pack_bf16x2(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv);
-                    w[1] = pack_bf16x2(o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
-                    *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * g + 4 * hi) = w;
-                }
-            if (hi == 0) LSE2[(int64_t)bh * S + q] = m[j] + __builtin_amdgcn_logf(lt);  // v_log_f32 is log2
-        }
-    }
-}
-
+#ifdef VGPA_VARIANTS   // measured-slower experiments / diagnostics live in tools/variants/ (variant builds only)
+#include "attn_fwd_pp_kernel.inc"
 #endif  // VGPA_VARIANTS
 
 // =====================================================================================================
@@ -1371,220 +821,8 @@ __global__ __launch_bounds__(256) void attn_dkv_merge_kernel(const float* __rest
     dV[(size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)key * sdv.s + lane] = f32_to_bf16(av);
 }
 
-#ifdef VGPA_VARIANTS   // measured-slower experiment: variant builds only
-// =====================================================================================================
-// Backward, fused:  dK, dV AND dQ in one sweep (5 matrix products per score block instead of the 7 of the split
-// dK/dV + dQ pair).  Workgroup = 8 waves = 256 keys; wave w keeps dK^T, dV^T of its 32 keys in registers exactly as
-// attn_bwd_dkv_kernel does.  For dQ the per-tile dS (bf16, [256 keys][64 q]) is handed through LDS: after one
-// barrier, wave w owns the (q-block, d-block) = (w&1, (w>>1)&1) 32x32 piece of dQ for key half w>>2, contracts its
-// 128 keys against K^T fragments it holds in registers for the whole kernel (hardware transpose reads of the dS
-// tile), and adds the result to a caller-zeroed fp32 dQ[B,H,S,64] with row-contiguous fp32 atomics (128 B per
-// half-wave).  Workgroups of one head start their q sweep at different tiles so they do not hit the same dQ rows at
-// the same time.  fp32 atomics make dQ run-to-run reproducible only to rounding (like every atomic-based attention
-// backward); dK/dV stay deterministic.
-// =====================================================================================================
-#define FUSED_KEYS 256
-__device__ __forceinline__ void tile_load1(const bf16_t* base, uint32_t row_stride, int row0, int S, u32x4_t& r) {
-    const int c = threadIdx.x;   // 512 threads: one 16-byte chunk each
-    int row = row0 + (c >> 3);
-    row = row < S ? row : S - 1;
-    r = *reinterpret_cast<const u32x4_t*>(base + ((uint32_t)row * row_stride + (uint32_t)((c & 7) * 8)));
-}
-__device__ __forceinline__ void tile_store1(bf16_t* lds, const u32x4_t& r) {
-    const int c = threadIdx.x;
-    *reinterpret_cast<u32x4_t*>(lds + (c >> 3) * PITCH + (c & 7) * 8) = r;
-}
-
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                               const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
-                                                               const float* __restrict__ LSE2, const float* __restrict__ DELTA,
-                                                               float* __restrict__ dQ32, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
-                                                               TStride sq, TStride sk, TStride sv, TStride sdo, TStride sdk, TStride sdv,
-                                                               int S, int H, int n_kt, float scale, float kscale) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS + 16];        // Q[2], dO[2] (+ stats in the padding columns)
-    __shared__ __attribute__((aligned(16))) bf16_t dsl[FUSED_KEYS * PITCH];         // K staging at start, then dS[key][q] per tile
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = vid / n_kt, kt = vid % n_kt;
-    const int b = bh / H, h = bh % H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int k0 = kt * FUSED_KEYS + wave * 32;
-    const int qblk = wave & 1, dblk = (wave >> 1) & 1, half = wave >> 2;
-
-    const bf16_t* Qb = Q + ((size_t)b * sq.b + (size_t)h * sq.h);
-    const bf16_t* Kb = K + ((size_t)b * sk.b + (size_t)h * sk.h);
-    const bf16_t* dOb = dO + ((size_t)b * sdo.b + (size_t)h * sdo.h);
-    const float* Lb = LSE2 + (int64_t)bh * S;
-    const float* Db = DELTA + (int64_t)bh * S;
-    float* dQb = dQ32 + (int64_t)bh * S * HD;
-    bf16x8_t kf[4], vf[4];
-    load_row_frags(Kb, sk.s, k0, S, lane, kf);
-    load_row_frags(V + ((size_t)b * sv.b + (size_t)h * sv.h), sv.s, k0, S, lane, vf);
-    bf16x8_t ones;
-    {
-        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hi == 0) { o8[0] = 1.f; o8[1] = 1.f; o8[2] = 1.f; }
-        ones = f32_to_frag(o8);
-    }
-    for (int i = threadIdx.x; i < (4 * TILE_ELEMS + 16) / 8; i += 512) {
-        u32x4_t z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4_t*>(lds + i * 8) = z;
-    }
-    // stage this workgroup's 256 K rows once, take the K^T fragments this wave needs for dQ, then reuse the buffer for dS
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = threadIdx.x + 512 * j;
-        int row = kt * FUSED_KEYS + (c >> 3);
-        row = row < S ? row : S - 1;
-        *reinterpret_cast<u32x4_t*>(dsl + (c >> 3) * PITCH + (c & 7) * 8) =
-            *reinterpret_cast<const u32x4_t*>(Kb + ((uint32_t)row * sk.s + (uint32_t)((c & 7) * 8)));
-    }
-    __syncthreads();
-    bf16x8_t ktf[8];   // B operand of dQ[q,d] += dS[q,key] K[key,d]: n = d, k-slots = the 128 keys of this wave's half
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) ktf[ks] = frag_tr(dsl, 128 * half + 16 * ks, dblk * 32, lane);
-    __syncthreads();
-
-    f32x16_t dk[2], dv[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
-
-    const int nt = (S + TILE - 1) / TILE;
-    const int start = (int)(((int64_t)kt * 37) % nt);     // stagger the q sweep across the workgroups of a head
-    auto tile_of = [&](int i) { int x = i + start; return x >= nt ? x - nt : x; };
-    const bool key_tail = (kt * FUSED_KEYS + FUSED_KEYS > S);
-    const bool key_ok = (k0 + (lane & 31)) < S;
-    u32x4_t qr, dor;
-    float st = 0.f;
-    auto stat_load = [&](int tq) {
-        if (threadIdx.x < 2 * TILE) {
-            int q = tq * TILE + (threadIdx.x & (TILE - 1));
-            q = q < S ? q : S - 1;
-            st = (threadIdx.x < TILE) ? Lb[q] : Db[q];
-        }
-    };
-    auto stat_store = [&](int buf) {
-        if (threadIdx.x < 2 * TILE) {
-            const float t0 = -st;
-            const float a1 = round_bf16(t0), a2 = round_bf16(t0 - a1), a3 = round_bf16((t0 - a1) - a2);
-            u32x4_t w = {pack_bf16x2(a1, a2), pack_bf16x2(a3, 0.f), 0u, 0u};
-            bf16_t* tile = lds + ((threadIdx.x < TILE ? 0 : 2) + buf) * TILE_ELEMS;
-            *reinterpret_cast<u32x4_t*>(tile + (threadIdx.x & (TILE - 1)) * PITCH + 64) = w;
-        }
-    };
-    tile_load1(Qb, sq.s, tile_of(0) * TILE, S, qr);
-    tile_load1(dOb, sdo.s, tile_of(0) * TILE, S, dor);
-    stat_load(tile_of(0));
-    tile_store1(lds, qr);
-    tile_store1(lds + 2 * TILE_ELEMS, dor);
-    stat_store(0);
-    __syncthreads();
-
-    for (int i = 0; i < nt; ++i) {
-        const int tq = tile_of(i);
-        const bf16_t* ql = lds + (i & 1) * TILE_ELEMS;
-        const bf16_t* dol = lds + (2 + (i & 1)) * TILE_ELEMS;
-        if (i + 1 < nt) {
-            const int tn = tile_of(i + 1);
-            tile_load1(Qb, sq.s, tn * TILE, S, qr);
-            tile_load1(dOb, sdo.s, tn * TILE, S, dor);
-            stat_load(tn);
-        }
-        const bool tail = (tq == nt - 1) && (S & (TILE - 1));
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16_t s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            s = mfma32(frag_row(ql, qb * 32, 4, lane), ones, s);                                         // - lse2[q]
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(frag_row(ql, qb * 32, ks, lane), kf[ks], s);      // S[q,key] - lse2
-            dp = mfma32(frag_row(dol, qb * 32, 4, lane), ones, dp);                                      // - delta[q]
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_row(dol, qb * 32, ks, lane), vf[ks], dp);   // dP[q,key] - delta
-            f32x16_t ds;
-            if (tail) {   // query rows past the end: exp2(-inf) = 0 (masking kept out of the exp loop)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (tq * TILE + qb * 32 + acc_row(r, hi) >= S) s[r] = -INFINITY;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2_t p = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-                f32x2_t d = {dp[r], dp[r + 1]};
-                d = d * p;
-                s[r] = p[0];
-                s[r + 1] = p[1];
-                ds[r] = d[0];
-                ds[r + 1] = d[1];
-            }
-            if (key_tail && !key_ok) {   // keys past the end must not reach dQ (their dK/dV columns are never stored)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ds[r] = 0.f;
-            }
-            // dS[key = this lane][q = qb*32 + rows] -> LDS, 4 consecutive q (8 bytes) per store
-            bf16_t* dsp = dsl + (wave * 32 + (lane & 31)) * PITCH + qb * 32 + 4 * hi;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2_t w;
-                w[0] = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
-                w[1] = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
-                *reinterpret_cast<u32x2_t*>(dsp + 8 * g) = w;
-            }
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const bf16x8_t pf = pack_frag(s, 8 * cc);
-                const bf16x8_t dsf = pack_frag(ds, 8 * cc);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = mfma32(frag_tr(dol, qb * 32 + 16 * cc, db * 32, lane), pf, dv[db]);   // dV^T[d,key] += dO^T P
-                    dk[db] = mfma32(frag_tr(ql, qb * 32 + 16 * cc, db * 32, lane), dsf, dk[db]);   // dK^T[d,key] += Q^T dS
-                }
-            }
-        }
-        __syncthreads();   // dS tile complete
-        {
-            f32x16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = mfma32(frag_tr(dsl, 128 * half + 16 * ks, qblk * 32, lane), ktf[ks], acc);   // dQ[q,d]
-            float* dqp = dQb + (int64_t)(tq * TILE + qblk * 32) * HD + dblk * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qrow = acc_row(r, hi);
-#ifdef FUSED_NO_ATOMIC
-                asm volatile("" ::"v"(acc[r]));
-#else
-                if (tq * TILE + qblk * 32 + qrow < S) atomicAdd(dqp + qrow * HD, acc[r] * scale);
-#endif
-            }
-        }
-        if (i + 1 < nt) {
-            tile_store1(lds + ((i + 1) & 1) * TILE_ELEMS, qr);
-            tile_store1(lds + (2 + ((i + 1) & 1)) * TILE_ELEMS, dor);
-            stat_store((i + 1) & 1);
-        }
-        __syncthreads();   // next tiles staged; dS tile free again
-    }
-    const int k = k0 + (lane & 31);
-    if (k < S) {
-        bf16_t* kp = dK + ((size_t)b * sdk.b + (size_t)h * sdk.h + (size_t)k * sdk.s);
-        bf16_t* vp = dV + ((size_t)b * sdv.b + (size_t)h * sdv.h + (size_t)k * sdv.s);
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2_t w;
-                w[0] = pack_bf16x2(dk[db][4 * g] * kscale, dk[db][4 * g + 1] * kscale);
-                w[1] = pack_bf16x2(dk[db][4 * g + 2] * kscale, dk[db][4 * g + 3] * kscale);
-                *reinterpret_cast<u32x2_t*>(kp + db * 32 + 8 * g + 4 * hi) = w;
-                w[0] = pack_bf16x2(dv[db][4 * g], dv[db][4 * g + 1]);
-                w[1] = pack_bf16x2(dv[db][4 * g + 2], dv[db][4 * g + 3]);
-                *reinterpret_cast<u32x2_t*>(vp + db * 32 + 8 * g + 4 * hi) = w;
-            }
-    }
-}
-
+#ifdef VGPA_VARIANTS   // measured-slower experiments / diagnostics live in tools/variants/ (variant builds only)
+#include "attn_bwd_fused_kernel.inc"
 #endif  // VGPA_VARIANTS
 
 #ifndef DQ_QB
@@ -1630,18 +868,9 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
     if (!q || !k || !v || !o || !lse2 || head_dim != HD || B <= 0 || H <= 0 || S <= 0 || S > (1 << 24)) return VGPA_ERR_INVALID;
     if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(o_strides)) return VGPA_ERR_INVALID;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o)) return VGPA_ERR_INVALID;
-#ifdef VGPA_VARIANTS
-    static const int use_pp = [] { const char* e = getenv("VGPA_ATTN_FWD"); return (e && e[0] == 'p' && e[1] == 'p') ? 1 : 0; }();
-    if (use_pp) {   // ping-pong kernel: 512 query rows per workgroup, no tail split
-        const int n_qt_pp = (int)((S + 64 * PP_NW - 1) / (64 * PP_NW));
-        const int64_t nb = (int64_t)n_qt_pp * B * H;
-        if (nb > 0x7fffffff) return VGPA_ERR_INVALID;
-        VGPA_LAUNCH((attn_fwd_pp_kernel<2>), dim3((unsigned)nb), dim3(64 * PP_NW), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                    (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt_pp);
-        VGPA_CHECK_LAUNCH();
-        return VGPA_OK;
-    }
-#endif
+#ifdef VGPA_VARIANTS   // measured-slower experiments / diagnostics live in tools/variants/ (variant builds only)
+#include "attn_fwd_pp_dispatch.inc"
+#endif  // VGPA_VARIANTS
     const int n_qt = (int)((S + FWD_QB * FWD_NW * 32 - 1) / (FWD_QB * FWD_NW * 32));
     const int64_t nblk = (int64_t)n_qt * B * H;
     if (nblk > 0x7fffffff) return VGPA_ERR_INVALID;
@@ -1673,11 +902,8 @@ static int32_t attn_fwd_impl(const void* q, const void* k, const void* v, void* 
         return VGPA_OK;
     }
 #endif
-#ifdef VGPA_VARIANTS
-    VGPA_LAUNCH((attn_fwd_kernel<FWD_QB, FWD_NW>), dim3((unsigned)nblk), dim3(64 * FWD_NW), FWD_DYN_LDS, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                (bf16_t*)o, lse2, mk(q_strides), mk(k_strides), mk(v_strides), mk(o_strides), (int)S, (int)H, n_qt);
-    VGPA_CHECK_LAUNCH();
-    return VGPA_OK;
+#ifdef VGPA_VARIANTS   // measured-slower experiments / diagnostics live in tools/variants/ (variant builds only)
+#include "attn_fwd_v1_dispatch.inc"
 #else
     return VGPA_ERR_INVALID;   // other blockings exist in variant builds only
 #endif
@@ -1846,24 +1072,8 @@ int32_t vgpa_attn_bwd_dq_ws(const void* q, const void* k, const void* v, const v
                             split_mode, workspace, ws_bytes, stream);
 }
 
-#ifdef VGPA_VARIANTS
-// fused backward: dK, dV (bf16 views) and dQ accumulated into dq_f32 -- fp32 [B,H,S,64] contiguous, ZEROED BY THE CALLER.
-int32_t vgpa_attn_bwd_fused(const void* q, const void* k, const void* v, const void* d_o, const float* lse2, const float* delta,
-                            float* dq_f32, void* dk, void* dv, const int64_t* q_strides, const int64_t* k_strides,
-                            const int64_t* v_strides, const int64_t* do_strides, const int64_t* dk_strides, const int64_t* dv_strides,
-                            int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, hipStream_t stream) {
-    if (!q || !k || !v || !d_o || !lse2 || !delta || !dq_f32 || !dk || !dv || !bwd_common_ok(B, H, S, head_dim)) return VGPA_ERR_INVALID;
-    if (!SOK(q_strides) || !SOK(k_strides) || !SOK(v_strides) || !SOK(do_strides) || !SOK(dk_strides) || !SOK(dv_strides) || !al16(q) ||
-        !al16(k) || !al16(v) || !al16(d_o) || !al16(dk) || !al16(dv))
-        return VGPA_ERR_INVALID;
-    const int n_t = (int)((S + FUSED_KEYS - 1) / FUSED_KEYS);
-    VGPA_LAUNCH(attn_bwd_fused_kernel, dim3((unsigned)((int64_t)n_t * B * H)), dim3(512), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, dq_f32, (bf16_t*)dk, (bf16_t*)dv, mk(q_strides), mk(k_strides),
-                mk(v_strides), mk(do_strides), mk(dk_strides), mk(dv_strides), (int)S, (int)H, n_t, scale, 0.6931471805599453f);
-    VGPA_CHECK_LAUNCH();
-    return VGPA_OK;
-}
-
+#ifdef VGPA_VARIANTS   // measured-slower experiments / diagnostics live in tools/variants/ (variant builds only)
+#include "attn_bwd_fused_entry.inc"
 #endif  // VGPA_VARIANTS
 
 // the whole backward (delta -> dK/dV -> dQ) with a caller-provided workspace for delta

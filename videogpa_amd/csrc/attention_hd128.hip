@@ -890,16 +890,11 @@ extern "C" size_t vgpa_attn128_fwd_workspace_bytes(int64_t B, int64_t H, int64_t
 }
 
 // workspace NULL (or too few keys for the pipeline to pay): the compiler-scheduled kernel
+#ifndef ATTN128_W1_MIN_KEYS
 #define ATTN128_W1_MIN_KEYS 1024
-// the sweep length from which the one-wave-per-SIMD kernels are used; VGPA_ATTN128_MIN_SWEEP overrides it (measurements, tests)
-static int64_t attn128_min_sweep() {
-    static const int64_t v = [] {
-        const char* e = getenv("VGPA_ATTN128_MIN_SWEEP");
-        const long n = e ? atol(e) : 0;
-        return (int64_t)(n >= 256 ? n : ATTN128_W1_MIN_KEYS);
-    }();
-    return v;
-}
+#endif
+// the sweep length from which the one-wave-per-SIMD kernels are used (-DATTN128_W1_MIN_KEYS=... in a variant build for measurements; no environment is read)
+static constexpr int64_t attn128_min_sweep() { return ATTN128_W1_MIN_KEYS; }
 // o_res8 (optional: uint8 [B, H, Sq, 128] view with its own element strides; NULL = not written): eight further mantissa bits of every output value
 // (common.h res8) for the backward's delta -- "precise delta", see vgpa_attn_fwd_w1_res
 static inline bool res8_ok(const void* o_res8, const int64_t* st, int64_t B, int64_t H, int64_t S) {
@@ -1289,11 +1284,11 @@ extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void*
     return VGPA_OK;
 }
 
-// VGPA_ATTN128_DQ_X2=0 selects the one-q-block-per-wave dQ kernel (A/B measurements)
-static bool attn128_dq_x2() {
-    static const bool v = [] { const char* e = getenv("VGPA_ATTN128_DQ_X2"); return !(e && e[0] == '0'); }();
-    return v;
-}
+// -DATTN128_DQ_X2=0 (variant build) selects the one-q-block-per-wave dQ kernel (A/B measurements)
+#ifndef ATTN128_DQ_X2
+#define ATTN128_DQ_X2 1
+#endif
+static constexpr bool attn128_dq_x2() { return ATTN128_DQ_X2 != 0; }
 
 // workspace: delta [B*H*Sq] + the statistics planes [B, H, 2, Sq] (fp32)
 extern "C" size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Sq) {

@@ -13,6 +13,20 @@
 // output dimension, so results leave as 8-byte row-contiguous pieces.
 #include "attn_w1.h"
 
+// measurement knobs of variant builds (tools/build_variant.sh ... -DLORA_DOWN_NS=3); the product library is built with the defaults and reads no environment
+#ifndef LORA_DOWN_DMA
+#define LORA_DOWN_DMA 1
+#endif
+#ifndef LORA_DOWN_DMA_NCB
+#define LORA_DOWN_DMA_NCB 2
+#endif
+#ifndef LORA_DOWN_NS
+#define LORA_DOWN_NS 4
+#endif
+#ifndef LORA_GRAD_WGS
+#define LORA_GRAD_WGS 768
+#endif
+
 #include <cstdlib>
 
 // ---- staging helpers with bounds (zero fill) -------------------------------------------------------------------
@@ -378,18 +392,19 @@ int32_t vgpa_lora_down(const void* X, int64_t ldx, const void* A, void* T, int64
     const int ncb = (int)((R + 31) / 32);
     const dim3 grid((unsigned)((M + 63) / 64));
     // LDS-DMA form (descriptor offsets are 32 bit: one workgroup's 64 rows of X and the whole of A must be addressable, incl. the
-    // chunks requested past K); VGPA_LORA_DOWN_DMA=0 selects the register-staged kernel
-    static const bool dma_off = getenv("VGPA_LORA_DOWN_DMA") && getenv("VGPA_LORA_DOWN_DMA")[0] == '0';
+    // chunks requested past K); -DLORA_DOWN_DMA=0 (a variant build: tools/build_variant.sh) selects the register-staged kernel.  The library reads no
+    // environment: every measurement knob below is a compile-time constant of a variant build.
+    constexpr bool dma_off = LORA_DOWN_DMA == 0;
     // measured (tools/lora_bench.py, round 5: stand-alone, every call on the next of six operands so that the 256 MB infinity cache cannot serve the
     // 218 MB read -- a loop over ONE operand reports 5.0-5.4 TB/s, the step sees what follows): R = 64 with the 4-stage ring 59.7 / 57.6 us at M = 35 552 /
     // 36 960 = 3.66 / 3.95 TB/s, with 3 stages (three workgroups per CU resident) 60.6 / 58.3 us; two 64-row blocks per A chunk (half the L2 -> LDS stream
     // of A) 68.7 us -- fewer, larger workgroups lose more than the halved A traffic gains.  R = 192 (the shared q/k/v down-projection, ONE launch per layer
-    // and policy pass) is 116-128 us on either kernel, with 2-4 stages and with one or two row blocks alike (VGPA_LORA_DOWN_DMA_NCB / VGPA_LORA_DOWN_NS
-    // override for measurements): the ring stays with the narrow adapters
-    static const int dma_max_ncb = getenv("VGPA_LORA_DOWN_DMA_NCB") ? atoi(getenv("VGPA_LORA_DOWN_DMA_NCB")) : 2;
+    // and policy pass) is 116-128 us on either kernel, with 2-4 stages and with one or two row blocks alike (-DLORA_DOWN_DMA_NCB / -DLORA_DOWN_NS
+    // variant builds): the ring stays with the narrow adapters
+    constexpr int dma_max_ncb = LORA_DOWN_DMA_NCB;
     if (!dma_off && ncb <= dma_max_ncb && (uint64_t)64 * (uint64_t)ldx * 2 + (uint64_t)K * 2 + 1024 < (1ull << 32) && ((uint64_t)R + 8) * (uint64_t)K * 2 + 1024 < (1ull << 32)) {
 #define LDD(N, S) VGPA_LAUNCH((lora_down_dma_kernel<N, S>), grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)A, (bf16_t*)T, ldt, M, (int)K, (int)R)
-        static const int ns = getenv("VGPA_LORA_DOWN_NS") ? atoi(getenv("VGPA_LORA_DOWN_NS")) : 4;
+        constexpr int ns = LORA_DOWN_NS;
         switch (ncb * 10 + ns) {
             case 14: LDD(1, 4); break; case 24: LDD(2, 4); break;
             case 13: LDD(1, 3); break; case 23: LDD(2, 3); break;
@@ -437,7 +452,7 @@ static void lora_grad_plan(int64_t M, int64_t P, int64_t Q, int* n_pt, int* n_qt
     *n_qt = (int)((Q + 63) / 64);
     // workgroups aimed at: 768 = three per CU (37 KiB of LDS each).  Measured at M = 35 552 on cache-cold operands (tools/lora_bench.py): 512 -> 62.4 us,
     // 768 -> 57.0, 1024 -> 62.0 (3.84 TB/s at 768)
-    static const int64_t target = getenv("VGPA_LORA_GRAD_WGS") ? atoll(getenv("VGPA_LORA_GRAD_WGS")) : 768;
+    constexpr int64_t target = LORA_GRAD_WGS;
     int64_t sp = target / ((int64_t)*n_pt * *n_qt);
     if (sp < 1) sp = 1;
     const int64_t max_splits = (M + 255) / 256;

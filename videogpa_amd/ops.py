@@ -483,8 +483,12 @@ def tuned_gemms_state():
 # dX = dY W of a frozen projection: torch.autograd issues it as an "NN" GEMM, which hipBLASLt runs 4-25 % slower at these
 # shapes than the "TN" form x W^T (tools/gemm_bench.py: fused q,k,v 1.91 -> 1.44 ms, FF 2.24 -> 2.07 / 2.08 -> 1.89 ms).  The
 # base weights never change during LoRA training, so a transposed copy is kept next to each weight (11 GB for CogVideoX-5B,
-# made at the first backward) and dX is computed as dY (W^T)^T.  VGPA_WT_CACHE=0 turns it off.
-_WT_CACHE = _os.environ.get("VGPA_WT_CACHE", "1") == "1"
+# made at the first backward) and dX is computed as dY (W^T)^T.
+# Dispatch constants below (this one, GEMM_SPLIT_*, GEMM_ROW_SLACK, ATTN_*) are MODULE constants: a measurement tool flips them from Python before its first call
+# (tools/*.py); nothing here reads the environment.  The environment carries only the three model-level settings -- VGPA_PRECISE_DELTA (default of the per-model
+# precise_delta), VGPA_DP_COLLECTIVE (optim.FlatAdamW), lean activations are a trainer config key -- plus VGPA_LIB (which build of the library to load) and
+# VGPA_FORCE_DIST (run the N > 1 code path on one GPU: tests).
+_WT_CACHE = True
 
 
 def _transposed(W):
@@ -501,9 +505,9 @@ def _transposed(W):
 # M = 18 480, also inside the power-limited step: cfg5 bf16 GEMMs 300 -> 272 ms per step, measured A/B in one session (profiles/r04_gemm_split_ab.txt);
 # at the CogVideoX shapes (M = 35 552) the same split changes nothing or costs (feed-forward shapes: +20 ms), and the fp8 GEMMs do not care.  So the
 # split is set by the model that knows its rows per sample (WanModel.forward) and applies only to row counts that are a multiple of it.
-# VGPA_GEMM_SPLIT_M in the environment overrides the models' choice (0 = never split); VGPA_GEMM_SPLIT_EXT_ONLY=1 restricts it to the LoRA-extended GEMMs.
-_GEMM_SPLIT_ENV = _os.environ.get("VGPA_GEMM_SPLIT_M")
-GEMM_SPLIT_EXT_ONLY = _os.environ.get("VGPA_GEMM_SPLIT_EXT_ONLY", "0") == "1"
+# GEMM_SPLIT_OVERRIDE (tools: an int overrides the models' choice, 0 = never split); GEMM_SPLIT_EXT_ONLY restricts the split to the LoRA-extended GEMMs.
+GEMM_SPLIT_OVERRIDE = None
+GEMM_SPLIT_EXT_ONLY = False
 # The setting is SCOPED, not process state: a model wraps its forward in `with gemm_rows_per_call(L):` (a contextvar: other models / threads of the process
 # see 0), every autograd node below records the value it ran its forward GEMM with (ctx.rows_per_call) and runs its backward GEMMs with the same one -- the
 # autograd engine's threads never consult the context.  A checkpointed block re-enters the context in its recomputation (WanModel.forward).
@@ -521,7 +525,7 @@ def gemm_rows_per_call(rows):
 
 
 def current_gemm_rows():
-    return int(_GEMM_SPLIT_ENV) if _GEMM_SPLIT_ENV is not None else _GEMM_ROWS.get()
+    return int(GEMM_SPLIT_OVERRIDE) if GEMM_SPLIT_OVERRIDE is not None else _GEMM_ROWS.get()
 
 
 def _slack_rows(x2):
@@ -616,7 +620,7 @@ def bump_adapter_epoch():
 # fused q/k/v projection -6.7 %, attention-out projection -17 %, FF1 -2 %, for 0.8 % more rows; tools/gemm_m_probe.py, profiles/r04_gemm_m_probe.txt).  GEMM rows are
 # independent, so the activation buffers that feed GEMMs are allocated with that many rows of STORAGE (logical shape unchanged, contents of the slack never read
 # by anything but the GEMM, whose extra output rows nobody reads) and _linear_rows runs over the padded count.  Only when the padding is <= 1.25 % of the rows.
-GEMM_ROW_SLACK = _os.environ.get("VGPA_GEMM_ROW_SLACK", "1") == "1"
+GEMM_ROW_SLACK = True
 
 
 def gemm_rows(M, N=None, K=None, wide=False):
@@ -914,14 +918,14 @@ LOG2E = 1.4426950408889634
 # backward attention: "split" (default) = deterministic dK/dV kernel + dQ kernel (7 matrix products per score block);
 # "fused" = one kernel with dQ by fp32 atomics (5 products).  Measured on MI355X at the headline shape the fused form
 # is SLOWER (46.6 ms vs 26.5 ms per layer): its 60 GB of dQ atomics per launch run at ~2.6 TB/s (23.9 ms without them).
-# It stays selectable (VGPA_ATTN_BWD=fused) and parity-tested.
-ATTN_BWD_FUSED = _os.environ.get("VGPA_ATTN_BWD", "split") == "fused"
+# It lives in tools/variants/ (variant builds export vgpa_attn_bwd_fused; ops.ATTN_BWD_FUSED = True selects it there).
+ATTN_BWD_FUSED = False        # True needs a variant build (tools/build_variant.sh: vgpa_attn_bwd_fused lives in tools/variants/)
 # tail-round treatment of the attention launches (vgpa_attn_*_ws split_mode): -1 automatic (default), 0 off
-ATTN_SPLIT_MODE = int(_os.environ.get("VGPA_ATTN_SPLIT", "-1"))
+ATTN_SPLIT_MODE = -1
 # Attention kernels come from the "w1" family (csrc/attention_w1.hip: one wave per SIMD, LDS-DMA rings, generated hand-scheduled
-# main loops).  VGPA_ATTN_W1 = comma list out of {fwd, dq, dkv} selects which (default all three; "none" = the 2-waves-per-SIMD
-# kernels of attention.hip, which stay in the library as the redo path of the forward and for A/B runs).
-ATTN_W1 = set(x for x in _os.environ.get("VGPA_ATTN_W1", "fwd,dq,dkv").split(",") if x and x != "none")
+# main loops).  ATTN_W1 = subset of {fwd, dq, dkv} selects which (default all three; empty = the 2-waves-per-SIMD kernels of attention.hip,
+# which stay in the library as the online-softmax / redo path of the forward and for A/B runs: tools set ops.ATTN_W1).
+ATTN_W1 = {"fwd", "dq", "dkv"}
 # "Precise delta": the attention forward also stores what the bf16 rounding of its output dropped, and the backward forms delta = rowsum(dO o O) from the
 # completed output.  delta stands for rowsum(P o dP); formed from the bf16 O alone (what every flash-attention backward, torch's included, does) each row's dS
 # stops summing to zero and dQ picks up a coherent error -d(delta_i) sum_j P_ij K_j that swamps q / k gradients which are small by cancellation (37-87 % of
@@ -1025,7 +1029,7 @@ def attention_fwd_raw(q, k, v, scale=None, q_prescaled=False, split_mode=None, o
             policy.calls += 1
         return o, lse
     if o_res is not None:
-        raise RuntimeError("attention_fwd_raw: o_res needs the w1 forward (VGPA_ATTN_W1 includes fwd)")
+        raise RuntimeError("attention_fwd_raw: o_res needs the w1 forward (ops.ATTN_W1 includes \"fwd\")")
     ws_bytes = _lib.query("vgpa_attn_fwd_workspace_bytes", B, H, S) if split_mode != 0 else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
     _timed("attn_fwd_kernel", 4.0 * S * S * Dh * B * H, lambda: _lib.call(
@@ -1079,7 +1083,7 @@ def attention_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale=None, q_prescaled=F
         _bhs_strides(dq), B, H, S, Dh, float(scale), int(split_mode), wsp, ws_bytes, st))
 
 
-ATTN128_W1 = _os.environ.get("VGPA_ATTN128_W1", "1") == "1"    # 0: the compiler-scheduled hd128 forward everywhere
+ATTN128_W1 = True    # False: the compiler-scheduled hd128 forward everywhere (tools)
 
 
 ATTN128_F8_MIN_KEYS = 1024      # below this the e4m3 forward's prep passes and pipeline fill do not pay (cross-attention over 512 text tokens stays bf16)
