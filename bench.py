@@ -322,6 +322,59 @@ def dist_report(engine, dt_local, steps, dev, world, force_dist):
     return {"ranks_seen": dist.get_world_size(), "ms_per_step_min": min(per), "ms_per_step_max": max(per), "ms_per_step_by_rank": per, "comm": comm}
 
 
+def preflight(world, rank, local_rank, dev):
+    """N > 1 runs must be attributable from their own output: every rank reports its device, free memory and the collective library it loaded; rank 0 prints the
+    table to stderr before the first step and attaches it to the JSON line.  (NCCL_DEBUG=VERSION, set before the process group comes up, makes RCCL print its own
+    version line to stderr as well.)"""
+    free, total = torch.cuda.mem_get_info(dev)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:      # noqa: BLE001
+        ver = f"unavailable ({e!r})"
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": local_rank, "device": props.name, "gcn_arch": getattr(props, "gcnArchName", None), "free_gb": free / 2 ** 30, "total_gb": total / 2 ** 30,
+            "rccl_version": ver, "torch": torch.__version__, "hip": torch.version.hip, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "VGPA_DP_COLLECTIVE": os.environ.get("VGPA_DP_COLLECTIVE", "all_reduce"), "pid": os.getpid(), "host": os.uname().nodename}
+    rows = [None] * dist.get_world_size()
+    dist.all_gather_object(rows, mine)
+    if rank == 0:
+        for r in rows:
+            print(f"bench.py preflight: rank {r['rank']} -> GPU {r['local_rank']} {r['device']} ({r['gcn_arch']}), {r['free_gb']:.0f} of {r['total_gb']:.0f} GiB free, RCCL {r['rccl_version']}, "
+                  f"torch {r['torch']} / HIP {r['hip']}, HSA_ENABLE_IPC_MODE_LEGACY={r['HSA_ENABLE_IPC_MODE_LEGACY']}", file=sys.stderr, flush=True)
+    return rows
+
+
+def collective_ab(engine, batch, steps, world, force_dist, dev, barrier):
+    """the OTHER gradient-exchange form over a second short timed region (same model, same batch), so that ONE `bench.py --gpus N` invocation yields the
+    all_reduce / rs_ag A/B (a ring all-reduce is bound by one xGMI link, reduce-scatter + all-gather use all seven).  Runs after the headline's region
+    and never touches its numbers.  -> {collective: {"ms_per_step", "comm"}} for the second form (every rank must call this)."""
+    opt = engine.opt
+    first = opt.collective
+    other = "rs_ag" if first == "all_reduce" else "all_reduce"
+    opt.collective = other
+    try:
+        engine.micro_step(batch)               # one untimed step on the new form (buffers, communicator channels)
+        engine.flush()
+        opt.comm_report()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            engine.micro_step(batch)
+        engine.flush()
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        comm = opt.comm_report()
+        if comm is not None:
+            w = torch.tensor([comm["exposed_wait_ms"], comm["allreduce_ms"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            comm["exposed_wait_ms_max_over_ranks"], comm["allreduce_ms_max_over_ranks"] = float(w[0].item()), float(w[1].item())
+        return {other: {"steps": steps, "ms_per_step": float(tt.item()) / steps * 1e3, "comm": comm}}
+    finally:
+        opt.collective = first
+
+
 def tuned_gemms_report(ops):
     """which hipBLASLt solutions the vendor GEMMs of this run used: the library's default heuristic, or the per-shape winners of tools/gemm_tune.py
     (videogpa_amd/tuned/, read by PyTorch TunableOp with tuning off; ignored by torch when the file was made on another torch / ROCm / hipBLASLt stack)"""
@@ -585,6 +638,8 @@ def main_wan(args, C, world, rank, dev, force_dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     drep = dist_report(engine, dt_local, args.steps, dev, world, force_dist)
+    if getattr(args, "preflight", None):
+        drep["preflight"] = args.preflight
     if rank == 0:
         named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8, args.no_fp8_attn) == (30, C["frames"], C["height"], C["width"], 64, False, False, False)
         ms = dt / args.steps * 1e3
@@ -642,6 +697,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="run the vendor GEMMs on hipBLASLt's default heuristic instead of the solutions of videogpa_amd/tuned/ (the A/B of tools/gemm_tune.py)")
+    ap.add_argument("--no-collective-ab", action="store_true", help="N > 1: skip the second short timed region that runs the other gradient-exchange form (all_reduce <-> rs_ag)")
     ap.add_argument("--no-scorer", action="store_true", help="skip the geometry-scorer block (a few milliseconds of GPU work after the headline's timed region)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (1 GPU, cfg2, no debug flags) also measures cfg3 / cfg4 / cfg5 for 3 steps each "
                     "and attaches them as `other_configs`; this switches that off")
@@ -666,12 +722,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")      # RCCL prints its version line to stderr when the communicator comes up
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pre = None
     if world > 1 or force_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
         if rank == 0:
             print(f"bench.py: RCCL process group up, {dist.get_world_size()} ranks", file=sys.stderr, flush=True)
+        pre = preflight(world, rank, local_rank, dev)
+    args.preflight = pre
 
     from videogpa_amd import ops, transformer as vtr
     from videogpa_amd.trainer import CogVideoXDPOTrainer, DPOEngine
@@ -747,6 +807,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     drep = dist_report(engine, dt_local, args.steps, dev, world, force_dist)
+    if (world > 1 or force_dist) and not args.no_collective_ab:
+        ab = collective_ab(engine, batch, min(args.steps, 3), world, force_dist, dev, barrier)
+        if drep.get("comm"):
+            drep["collective_ab"] = dict({drep["comm"]["collective"]: {"steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "comm": drep["comm"]}}, **ab)
+    if args.preflight:
+        drep["preflight"] = args.preflight
 
     if rank == 0:
         named = (args.layers, F_, H_, W_, args.rank_r, ckpt) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"]) and \

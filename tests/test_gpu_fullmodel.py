@@ -204,13 +204,18 @@ def test_engine_micro_steps_through_a_real_rccl_communicator(monkeypatch):
 def test_bench_line_under_a_forced_process_group_carries_the_comm_attribution():
     """`bench.py` with VGPA_FORCE_DIST=1 (the N > 1 code path on the one GPU of this box: RCCL group of one rank, side-stream exchange, deferred optimizer
     step) on a 2-block debug shape: the JSON line carries what a scaling loss would be attributed from -- ranks_seen, per-rank ms_per_step (min / max) and
-    comm = {collective, bytes, exchanges, allreduce_ms, exposed_wait_ms (+ max over ranks)} -- for both collectives."""
+    comm = {collective, bytes, exchanges, allreduce_ms, exposed_wait_ms (+ max over ranks)} -- for both collectives; since round 6 ONE invocation
+    carries both forms (`collective_ab`: a second short timed region on the other exchange) and the per-rank `preflight` table (device, free memory, RCCL version)."""
     import json
+    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for coll in ("all_reduce", "rs_ag"):
-        env = dict(os.environ, VGPA_FORCE_DIST="1", VGPA_DP_COLLECTIVE=coll, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        with socket.socket() as sk:          # a free port per run (a fixed one collides under parallel test runs: ADVICE r5)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, VGPA_FORCE_DIST="1", VGPA_DP_COLLECTIVE=coll, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--layers", "2", "--frames", "3", "--height", "16", "--width", "16", "--steps", "3",
                             "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -220,7 +225,12 @@ def test_bench_line_under_a_forced_process_group_carries_the_comm_attribution():
         c = j["comm"]
         assert c["collective"] == coll and c["exchanges"] == 3 and c["bytes"] > 4 * 2 * 4 * 64 * 3072 and c["allreduce_ms"] > 0
         assert 0 <= c["exposed_wait_ms"] <= c["exposed_wait_ms_max_over_ranks"] + 1e-9
-        print({coll: c})
+        ab = j["collective_ab"]
+        assert set(ab) == {"all_reduce", "rs_ag"} and all(v["ms_per_step"] > 0 and v["comm"]["collective"] == k and v["comm"]["exchanges"] == 3 for k, v in ab.items())
+        pre = j["preflight"]
+        assert len(pre) == 1 and pre[0]["rank"] == 0 and pre[0]["free_gb"] > 1 and pre[0]["rccl_version"][0].isdigit()
+        assert "preflight: rank 0" in r.stderr
+        print({coll: c, "ab": {k: v["ms_per_step"] for k, v in ab.items()}})
 
 
 @pytest.mark.parametrize("recompute,mem_gb", [(True, 80), (False, 230)])

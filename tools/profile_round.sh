@@ -8,10 +8,22 @@
 tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline \
-    > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_$tag.log
+# the HEADLINE process only (--no-other-configs --no-scorer: round 5 profiled the default command, whose cfg3 child wrote the first csv `find | head -1` picked up)
+PSTEPS=2; PWARM=1
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag --output-format csv -- python $R/bench.py --steps $PSTEPS --warmup $PWARM --no-cpu-baseline \
+    --no-other-configs --no-scorer > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_$tag.log
+nf=$(find $R/gpurun_out/prof_$tag -name "*kernel_stats.csv" | wc -l)
+[ "$nf" -ne 1 ] && echo "profile_round.sh: expected ONE kernel_stats.csv (one traced process), found $nf" | tee -a $R/gpurun_out/prof_$tag.log
 f=$(find $R/gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $R/gpurun_out/${tag}_bench_kernel_stats.csv && python $R/profiles/summarize.py $f 40 > $R/gpurun_out/${tag}_bench_kernel_stats_summary.txt
+# the trace must be the headline's: 84 forward launches (42 blocks x reference + policy pass) per step x (steps + warm-up)
+python - "$f" $((84 * (PSTEPS + PWARM))) <<'PYEOF' | tee -a $R/gpurun_out/prof_$tag.log
+import csv, sys
+want = int(sys.argv[2])
+n = sum(int(r["Calls"]) for r in csv.DictReader(open(sys.argv[1])) if r["Name"].startswith("void attn_fwd_w1_kernel<false>") or r["Name"].startswith("attn_fwd_w1_kernel<false>"))
+print(f"profile_round.sh: attn_fwd_w1_kernel<false> launches in the trace: {n} (expected {want})" + ("" if n == want else "  <-- NOT the headline process's trace"))
+sys.exit(0 if n == want else 3)
+PYEOF
 find $R/gpurun_out/prof_$tag -name "*kernel_trace.csv" -delete    # large; the stats are what is kept
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch --output-format csv -- python $R/tools/attn_bench.py --iters 2 > $R/gpurun_out/pmc_${tag}_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write --output-format csv -- python $R/tools/attn_bench.py --iters 2 > $R/gpurun_out/pmc_${tag}_write.log 2>&1
@@ -44,4 +56,11 @@ find $R/gpurun_out/prof_${tag}_a128 -name "*kernel_trace.csv" -delete
 rocm-smi --showpower --showclocks --showmaxpower --json > $R/gpurun_out/${tag}_rocm_smi_idle.json 2>&1
 timeout 300 python $R/tools/power_trace.py --out $R/gpurun_out/power_${tag}.json -- python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-kernel-timer \
     > $R/gpurun_out/power_${tag}_bench.json 2> $R/gpurun_out/power_${tag}.log
+# the geometry scorer at the reference's scale (10 x 518^2): kernel stats + FETCH / WRITE traffic of project_zbuf / project_resolve / conf_threshold / mvcs / mse
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_scorer --output-format csv -- python $R/tools/scorer_bench.py > $R/gpurun_out/prof_${tag}_scorer.log 2>&1
+fs=$(find $R/gpurun_out/prof_${tag}_scorer -name "*kernel_stats.csv" | head -1)
+[ -n "$fs" ] && cp $fs $R/gpurun_out/${tag}_scorer_kernel_stats.csv && python $R/profiles/summarize.py $fs 20 > $R/gpurun_out/${tag}_scorer_kernel_stats_summary.txt
+find $R/gpurun_out/prof_${tag}_scorer -name "*kernel_trace.csv" -delete
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch_scorer --output-format csv -- python $R/tools/scorer_bench.py --quick > $R/gpurun_out/pmc_${tag}_fetch_scorer.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write_scorer --output-format csv -- python $R/tools/scorer_bench.py --quick > $R/gpurun_out/pmc_${tag}_write_scorer.log 2>&1
 python $R/tools/pmc_traffic.py $R/gpurun_out $tag
