@@ -3,8 +3,9 @@ train/CogVideoX-5B/03_train.py:61,265) = 40 preference-pair micro-steps at the g
 latents (S = 13 538), LoRA r = 64 / alpha 128 on to_q / to_k / to_v / to_out.0, beta = 1 (:56) -- on the HIP engine (CogVideoXDPOTrainer._shared_step, FlatAdamW:
 fused clip + AdamW, cosine warm-up) against the SAME loop run by the oracle in fp32 on the same GPU (oracle/cogvideox.py::dpo_pair_step with the adapters'
 bf16 copies inside the forward as PEFT's autocast makes them, torch.optim.AdamW + clip_grad_norm_ + the cosine-warm-up multiplier), identical pairs, timesteps and
-noise.  Four fixed pairs are cycled (10 passes over them), with a learning rate (1.5e-4, 30 x the reference's 5e-6) at which the loss on those pairs falls by more than
-1e-2 within the 20 steps: a curve that really moves.  (At 1e-3 the same loop is unstable in fp32 already -- the loss on one pair jumps from 0.26 to 1.18 between two
+noise.  Four fixed pairs are cycled (10 passes over them), with a learning rate (6e-5, 12 x the reference's 5e-6) at which the loss on those pairs falls by more than
+1e-2 within the 20 steps: a curve that really moves.  (The error grows with the distance the loss has moved: at 1.5e-4 one pair's loss falls from 0.693 to 0.449 and the device is 1.6e-3 off there, 0.9e-3 or less everywhere else
+(profiles/r06_loss_curve_width_lr1.5e-4.json); at 1e-3 the same loop is unstable in fp32 already -- the loss on one pair jumps from 0.26 to 1.18 between two
 passes -- and two runs of ANY arithmetic type separate: measured in round 6, profiles/r06_loss_curve_width_lr1e-3.json.)  The toy-sized test this supersedes as evidence (tests/test_gpu_model.py::test_loss_curve_matches_oracle_training_loop: 54 tokens, 2 heads) stays as a fast check.
 
 Three device modes (model-level settings, ops.py "Precise delta" / transformer.enable_lean_activations):
@@ -32,7 +33,7 @@ from oracle import scheduler as osch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 OPT_STEPS, ACCUM, N_PAIRS = 20, 2, 4
-CONF = {"beta": 1.0, "learning_rate": 1.5e-4, "weight_decay": 0.01, "warmup_steps": 2, "max_steps": OPT_STEPS, "accumulate_grad_batches": ACCUM, "gradient_clip_val": 1.0}
+CONF = {"beta": 1.0, "learning_rate": 6e-5, "weight_decay": 0.01, "warmup_steps": 2, "max_steps": OPT_STEPS, "accumulate_grad_batches": ACCUM, "gradient_clip_val": 1.0}
 TIMESTEPS = (417, 83, 901, 640)
 LOSS_TOL, MOVE_MIN, DRIFT_MAX = 1e-3, 1e-2, 0.35
 MODES = {"int8": ("int8", False), "int8_lean": ("int8", True), "plain": (None, False)}

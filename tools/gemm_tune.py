@@ -7,6 +7,8 @@ solution per shape.  This tool has PyTorch TunableOp time EVERY hipBLASLt soluti
   python tools/gemm_tune.py table [--file ...] [--json gpurun_out/gemm_tune_table.json]
         for every tuned entry with >= 1e11 FLOP: rebuilds the operands from the entry's key (m, n, k, lda, ldb, ldc), then times the library default and the tuned solution
         back to back in this process -- ms AND joules per launch (rsmi energy counter, tools/energy.py) -- and prints the table.
+  python tools/gemm_tune.py prune [--table gpurun_out/gemm_tune_table.json] [--min-gain 1.005]
+        keeps only the entries whose tuned solution the table confirms (faster AND not more joules): what ships in videogpa_amd/tuned/.
 The step-level A/B (what counts) is `python bench.py --no-tuned-gemms` against `python bench.py` in one session: kernels["hipblaslt_gemm (vendor)"] and energy.
 """
 import argparse
@@ -141,6 +143,28 @@ def table(args):
             json.dump({"file": os.path.relpath(args.file, ROOT), "validators": header, "rows": out_rows}, f, indent=1)
 
 
+def prune(args):
+    """keep only the entries the steady-state table (ms AND joules per launch at the part's power cap, default and tuned interleaved) confirms: TunableOp times every
+    candidate in a short burst at a clock the step never sees (its FF2 time: 1.51 ms; the same solution back to back: 2.0 ms), so some of its winners LOSE under
+    the cap.  Entries without a table row (small GEMMs) go back to the library's heuristic too."""
+    header, rows = _read(args.file)
+    tab = json.load(open(args.table))["rows"]
+    keep = {}
+    for r in tab:
+        key = f"tn_{r['N']}_{r['M']}_{r['K']}_ld_{r['lda_W']}_{r['ld_x']}_{r['N']}"
+        gain_t, gain_j = r["default_ms"] / r["tuned_ms"], r["default_J"] / r["tuned_J"]
+        ok = r["solution"] != "Default" and gain_t >= args.min_gain and gain_j >= 1.0
+        print(f"{r['op']:36s} {key:44s} {r['solution']:26s} time x{gain_t:5.3f} joules x{gain_j:5.3f} -> {'KEEP' if ok else 'default heuristic'}")
+        if ok:
+            keep[(r["op"], key)] = rows[(r["op"], key)]
+    with open(args.out, "w") as f:
+        for ln in header:
+            f.write(ln + "\n")
+        for (op, key), (sol, ms) in sorted(keep.items()):
+            f.write(f"{op},{key},{sol},{ms}\n")
+    print(f"wrote {args.out}: {len(keep)} of {len(rows)} entries kept")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -155,5 +179,10 @@ if __name__ == "__main__":
     b.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "gemm_tune_table.json"))
     b.add_argument("--min-flop", type=float, default=1e11)
     b.add_argument("--seconds", type=float, default=1.0)
+    c = sub.add_parser("prune")
+    c.add_argument("--file", default=DEFAULT_FILE)
+    c.add_argument("--table", default=os.path.join(ROOT, "gpurun_out", "gemm_tune_table.json"))
+    c.add_argument("--out", default=DEFAULT_FILE)
+    c.add_argument("--min-gain", type=float, default=1.005)
     args = ap.parse_args()
-    {"tune": tune, "table": table}[args.cmd](args)
+    {"tune": tune, "table": table, "prune": prune}[args.cmd](args)

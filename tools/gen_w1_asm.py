@@ -541,6 +541,16 @@ class FwdLoop:
                 cc, db = c >> 1, c & 1
                 d = ar(32 * j + 16 * db, 16)
                 out.append((f"{MFMA} {d}, {ar(self.frag_reg(c), 4)}, {vr(self.PK(pc, j, cc), 4)}, {d}", c))
+                if KNOB.get("mfsum") and db == 1 and j == 1:
+                    # W1_KNOBS=mfsum=1: l[q] += sum_k P[k][q] as a 16x16x32 product of a SPARSE selector against the same packed P registers the PV product
+                    # reads.  Read as the B operand of v_mfma_f32_16x16x32_bf16, lane L of the 32x32x16 B fragment (column q = L % 32, keys 8 (L / 32) ..+7 of the
+                    # 16-key chunk) is column n' = L % 16, k'-block L / 16: blocks 0, 2 hold q = n' (keys 0-7, 8-15), blocks 1, 3 hold q = n' + 16.  With
+                    # A'[0][k'] = 1 on blocks 0, 2 and A'[1][k'] = 1 on blocks 1, 3 (a[128:131]: 1.0 pairs in lanes 0, 32 and 17, 49, zero elsewhere)
+                    # D'[0][n'] = rowsum(q = n'), D'[1][n'] = rowsum(q = n' + 16): lanes 0-15 of the first two of the four accumulator registers.  64 matrix-pipe
+                    # cycles per half-step (4 passes each) against the 32 v_add_f32 they replace; 2 of A's 16 rows are non-zero, so the multiplier array barely toggles.
+                    for jj in range(2):
+                        dl = vr(128 + 4 * jj, 4)
+                        out.append((f"v_mfma_f32_16x16x32_bf16 {dl}, {ar(128, 4)}, {vr(self.PK(pc, jj, cc), 4)}, {dl}", None))
             else:
                 ks = (i - 8) >> 1
                 d = vr(self.S(pa, j), 16)
@@ -557,6 +567,8 @@ class FwdLoop:
             s0 = self.S(pb, j) + 2 * p
             w = self.PK(pb, j, p >> 2) + (p & 3)
             l0, l1 = 128 + 4 * j + ((2 * p) & 3), 128 + 4 * j + ((2 * p + 1) & 3)
+            if KNOB.get("mfsum"):      # row sums on the matrix pipe (see mfmas): no adds at all
+                return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"], [None, None], f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
             if KNOB.get("pksum"):      # the two row-sum adds as ONE packed add (same fp32 additions in the same order: bit-identical results)
                 return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
                         [f"v_pk_add_f32 {vr(l0, 2)}, {vr(l0, 2)}, {vr(s0, 2)}", None],
@@ -584,10 +596,14 @@ class FwdLoop:
         em.raw(f"{label}:")
 
     def half_step(self, em, slotA, kbA, slotC, kbC, pa, nxt, fill_first=()):
-        need = {f: 2 * f for f in range(8)}
+        ms = self.mfmas(pa, pa)
+        need = {}
+        for idx, (_, f) in enumerate(ms):           # first MFMA that reads each fragment (f: 2 f without the mfsum products)
+            if f is not None and f not in need:
+                need[f] = idx
         post = [lambda f=f: self.issue_frag(em, f, 0, 0, nxt[0], nxt[1], tag=("n", f)) for f in range(4)]
         em.retag({("n", f): f for f in range(4)})
-        schedule(em, self.mfmas(pa, pa), lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
+        schedule(em, ms, lambda f: self.issue_frag(em, f, slotA, kbA, slotC, kbC), need, self.valu_ops(pa ^ 1), self.LEAD,
                  pre_issued=(0, 1, 2, 3), post_issue=post, fill_first=fill_first)
 
     def generate(self):
@@ -595,6 +611,9 @@ class FwdLoop:
         SAVE_M0, CNT, KREM, TMP = "%0", "%1", "%2", "%3"
         RK, RV, KSTEP, VSTEP, WBASE, NITER, KREM0 = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]", "%[krem]"
         em.raw(f"s_mov_b32 {SAVE_M0}, m0")
+        if KNOB.get("mfsum"):
+            for i in range(4):                                     # the selector operand A' (v158: 0x3f803f80 in lanes 0, 17, 32, 49, else 0)
+                em.raw(f"v_accvgpr_write_b32 a{128 + i}, v158")
         em.raw(f"s_mov_b32 {CNT}, {NITER}")
         em.raw(f"s_mov_b32 {KREM}, {KREM0}")
         for i in range(64):
@@ -1483,7 +1502,9 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_gemm_loop.inc": lambda: GemmLoop().generate(),
            "w1_gemm_clobbers.inc": lambda: clobbers([], [(128, 175)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),
-           "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 127)])}
+           "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 127)] + ([(128, 131)] if KNOB.get("mfsum") else [])),
+           # what the C++ around the forward loop must know about the knobs the loop was generated with (attention_w1.hip: selector operand, epilogue)
+           "w1_fwd_knobs.inc": lambda: f"#define W1_FWD_MFSUM {1 if KNOB.get('mfsum') else 0}\n"}
 
 
 def main():

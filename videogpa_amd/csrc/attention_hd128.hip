@@ -220,7 +220,8 @@ typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
 #define W1H_RING_BYTES (4 * W1H_SLOT_BYTES)
 #define W1H_L_MIN 7.888609052210118e-31f   // 2^-100
 #define W1H_M_MAX 1024.0f      // as W1_M_MAX (attention_w1.hip): the fp32 accumulator's ulp at |M'| = 1024 is a fiftieth of the weight's bf16 rounding
-#define W1H_SHIFT_BACK 60.0f   // as W1_SHIFT_BACK: M' = bound - min(60, bound / 2) leaves 160 log2 units below the Cauchy-Schwarz bound representable
+#define W1H_SAMPLE_KEYS 64     // as W1_SAMPLE_KEYS / W1_SAMPLE_UP (attention_w1.hip): the shift follows a sampled lower bound of the row maximum
+#define W1H_SAMPLE_UP 64.0f
 
 __device__ __forceinline__ uint32_t w1h_swz(uint32_t r) { return ((r & 3u) << 2) | ((r >> 2) & 3u); }
 
@@ -282,8 +283,34 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __
             for (int i = 0; i < 8; ++i) a += f[i] * f[i];
         }
         a += other_half(a);
-        const float bnd = sqrtf(a) * kmax * 1.0009765625f;                 // |q| max|k| (unscaled: the loop multiplies by c)
-        nmc[j] = -(bnd - fminf(W1H_SHIFT_BACK / c, 0.5f * bnd));
+        nmc[j] = sqrtf(a) * kmax * 1.0009765625f;                          // b[q] = |q| max|k| (unscaled: the loop multiplies by c)
+    }
+    if (Skv >= 2 * W1H_SAMPLE_KEYS) {   // M'[q] = min(b, m_s + 64 log2 units), m_s = the row's maximum over 64 keys spread over the sweep (attention_w1.hip W1_SAMPLE_UP)
+        const bf16_t* Ks = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+        const uint32_t step = (uint32_t)Skv / W1H_SAMPLE_KEYS;
+        float ms[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int kb = 0; kb < W1H_SAMPLE_KEYS / 32; ++kb) {
+            bf16x8_t kf[8];
+            load_row_frags128(Ks, sk.s * step, 32 * kb, W1H_SAMPLE_KEYS, lane, kf);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(kf[ks]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = mfma32(kf[ks], qf[j][ks], acc);
+                float m = acc[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = fmaxf(m, acc[i]);
+                ms[j] = fmaxf(ms[j], fmaxf(m, other_half(m)));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) nmc[j] = -fminf(nmc[j], ms[j] + W1H_SAMPLE_UP / c);      // unscaled units: the loop multiplies by c
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) nmc[j] = -nmc[j];
     }
     const int nt = (Skv + 63) / 64;
     {   // the pipeline's first transposed reads hit the V tile of ring slot 3: make it finite

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 // (flags[task] = 1) and redone by the online-softmax kernel of attention.hip
 // (vgpa_internal_attn_fwd_redo), so the result never depends on the bound being tight.
 // =====================================================================================================
+#include "w1_fwd_knobs.inc"                   // W1_FWD_MFSUM: what the generated loop expects around it (tools/gen_w1_asm.py W1_KNOBS; 0 in the product)
 #define W1_FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64] (un-normalised), M[256], l[256] -- layout of attention.hip's split forward
 #define W1_L_MIN 7.8886e-31f                  // 2^-100: below this the row's sum is too close to underflow -> redo
 // With the shift at the row BOUND the largest weight of a row is exp2(s_max - M), not 1, so it carries a bf16 rounding error in the
@@ -174,10 +175,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 // the online-softmax kernel.
 #define W1_FWD_MIN_S 128
 // The shift M' only has to put exp2(s - M') inside fp32's range for every score that matters, it does not have to be an upper bound: the weights go to the matrix
-// pipe as bf16 (fp32's exponent range) and l, O accumulate in fp32.  With M' = bound - W1_SHIFT_BACK a row is exact while its true maximum lies in
-// [bound - W1_SHIFT_BACK - 100, bound]: 160 log2 units of slack below the Cauchy-Schwarz bound instead of 100 (QK-norm gains up to ~5.5 on isotropic keys
-// instead of ~4.4: tools/attn_bench.py --data trained_like), at the cost of weights up to 2^60 (l <= S 2^60, far inside fp32).  Rows outside still flag.
-#define W1_SHIFT_BACK 60.0f
+// pipe as bf16 (fp32's exponent range) and l, O accumulate in fp32.  M'[q] = min(b[q], m_s[q] + W1_SAMPLE_UP) with b = |q| max|k| (Cauchy-Schwarz, >= every score) and
+// m_s = the row's maximum over W1_SAMPLE_KEYS keys spread evenly over the sequence (16 MFMAs per wave in the prologue: 0.2 % of the sweep), a LOWER bound of the true
+// maximum m*.  Then  M' - m* <= M' - m_s <= 64  always (nothing that matters underflows: terms below 2^-62 of the row's largest are dropped), and  m* - M' <= 112
+// (no overflow: l <= S 2^112 < 2^127) whenever b - m_s <= 176 or, beyond that, whenever the true maximum is not more than 176 log2 units above the sampled one.  A row
+// outside (an extreme outlier key the sample missed) makes l = inf: the strip is flagged and redone by the online-softmax kernel, as before.
+// Round 5 shifted by b itself (p <= 1) and flagged every strip whose maximum lay > 100 below b or whose b exceeded 160: a QK-norm gain of 2.5 with a few outlier
+// channels (row entropy < 1 bit) sent the whole launch to the redo kernel, 2.5-3 x the time (tools/attn_robust.py, profiles/r06*_attn_trained_like.*).
+#define W1_SAMPLE_KEYS 64
+#define W1_SAMPLE_UP 64.0f
 // the scores are accumulated on top of -M' in fp32: at |M'| = 1024 the accumulator's ulp is 2^-13 log2 units = 8e-5 relative in a weight, a fiftieth of the bf16
 // rounding the weight gets anyway (round 5 flagged every strip above 160: a QK-norm gain of 3.8 already sent the whole launch to the online-softmax kernel)
 #define W1_M_MAX 1024.0f
@@ -248,8 +254,32 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
             for (int i = 0; i < 8; ++i) a += f[i] * f[i];
         }
         a += other_half(a);                              // the row's other 32 columns live in lane ^ 32
-        const float bnd = sqrtf(a) * kmax * 1.0009765625f;   // a hair above |q| |k|max: rounding of the bound itself can never let a score exceed it
-        nm[j] = -(bnd - fminf(W1_SHIFT_BACK, 0.5f * bnd));   // -M'[q] (see W1_SHIFT_BACK)
+        nm[j] = sqrtf(a) * kmax * 1.0009765625f;         // b[q], a hair above |q| |k|max: rounding of the bound itself can never let a score exceed it
+    }
+    {   // m_s[q]: the row's maximum over W1_SAMPLE_KEYS keys spread evenly over the sequence -- a LOWER bound of the true maximum (see W1_SAMPLE_UP)
+        const bf16_t* Ks = K + ((size_t)b * sk.b + (size_t)h * sk.h);
+        const uint32_t step = (uint32_t)S / W1_SAMPLE_KEYS;          // S >= W1_FWD_MIN_S = 128 here: step >= 2, the last sampled row is 63 step < S
+        float ms[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) ms[j] = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < W1_SAMPLE_KEYS / 32; ++kb) {
+            bf16x8_t kf[4];
+            load_row_frags(Ks, sk.s * step, 32 * kb, W1_SAMPLE_KEYS, lane, kf);
+            frags_arrived(kf);
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = mfma32(kf[ks], qf[j][ks], acc);      // S^T[key][q]: this lane holds 16 keys of column q = lane & 31
+                float m = acc[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = fmaxf(m, acc[i]);
+                ms[j] = fmaxf(ms[j], fmaxf(m, other_half(m)));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QB; ++j) nm[j] = -fminf(nm[j], ms[j] + W1_SAMPLE_UP);        // -M'[q]
     }
 
     const int nt_all = (S + TILE - 1) / TILE;
@@ -290,8 +320,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
     const int kend = nt * TILE < S ? nt * TILE : S;
     const uint32_t krem = (uint32_t)(kend - tb * TILE);                   // valid keys from tile tb on (of this chunk)
     const uint32_t hi4 = 4u * (uint32_t)hi;
+#if W1_FWD_MFSUM   // row sums on the matrix pipe: the selector operand of the 16x16x32 products (1.0 pairs in lanes 0, 32 -> row 0 and 17, 49 -> row 1)
+    const uint32_t sel = (lane == 0 || lane == 32 || lane == 17 || lane == 49) ? 0x3f803f80u : 0u;
+#define W1_FWD_SEL_IN , "{v158}"(sel)
+#else
+#define W1_FWD_SEL_IN
+#endif
     f32x16_t o[QB][2];
-    u32x8_t lv;   // l[j][0..3]: four partial row sums per q-block
+    u32x8_t lv;   // l[j][0..3]: four partial row sums per q-block (W1_FWD_MFSUM: the 16x16 accumulator of the selector product)
     uint32_t t0, t1, t2, t3;
     uint64_t c0, c1;   // s_memtime at the loop's start and end (read by tools/w1_clock.py through -DW1_CLOCKS builds)
     asm volatile(
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
         : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), [c0] "=&s"(c0), [c1] "=&s"(c1), "={a[0:15]}"(o[0][0]), "={a[16:31]}"(o[0][1]), "={a[32:47]}"(o[1][0]), "={a[48:63]}"(o[1][1]),
           "={v[128:135]}"(lv), "+{v[152:155]}"(voff)
         : [rk] "s"(krs.w), [rv] "s"(vrs.w), [kstep] "s"(kstep), [vstep] "s"(vstep), [wbase] "s"(wbase), [niter] "s"(niter), [krem] "s"(krem),
-          "{a[64:79]}"(qf0), "{a[80:95]}"(qf1), "{v136}"(nm[0]), "{v137}"(nm[1]), "{v[144:151]}"(la8), "{v156}"(hi4)
+          "{a[64:79]}"(qf0), "{a[80:95]}"(qf1), "{v136}"(nm[0]), "{v137}"(nm[1]), "{v[144:151]}"(la8), "{v156}"(hi4) W1_FWD_SEL_IN
         : "memory", "scc", "vcc",
 #include "w1_fwd_clobbers.inc"
     );
@@ -309,8 +345,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
     float l[QB];
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
+#if W1_FWD_MFSUM   // D'[0][n'] = rowsum(q = n'), D'[1][n'] = rowsum(q = n' + 16): lanes 0-15 of the accumulator's first two registers
+        const float s0 = __shfl(__uint_as_float(lv[4 * j]), lane & 15, 64), s1 = __shfl(__uint_as_float(lv[4 * j + 1]), lane & 15, 64);
+        l[j] = (lane & 16) ? s1 : s0;
+#else
         const float a = (__uint_as_float(lv[4 * j]) + __uint_as_float(lv[4 * j + 1])) + (__uint_as_float(lv[4 * j + 2]) + __uint_as_float(lv[4 * j + 3]));
         l[j] = a + other_half(a);   // the other 16 key rows of every 32-key block live in lane ^ 32
+#endif
     }
     if (SPLIT) {   // partial result of this key range: un-normalised O (scaled by 2^-M), M, l
         float* pb = part + ((size_t)(vid - task0) * nsplit + chunk) * W1_FWD_PART_FLOATS;
