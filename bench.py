@@ -375,6 +375,16 @@ def collective_ab(engine, batch, steps, world, force_dist, dev, barrier):
         opt.collective = first
 
 
+def attention_forward_summary(base, args):
+    """which forward each attention layer ended up on (ops.AttnFwdPolicy: the bound-shifted w1 kernel, or the online-softmax entry once more than 5 % of a layer's
+    strips had to be redone) and the largest redone fraction the kernels reported -- so that a run on a trained checkpoint shows whether its time is the fast path's"""
+    rep = base.attention_forward_report()
+    fr = [r["redo_fraction"] for r in rep if r["redo_fraction"] is not None]
+    return {"weights": args.weights + (f" (QK-norm gain {args.qk_gain})" if args.weights == "trained_like" else ""), "layers": len(rep),
+            "layers_on_online_softmax": sum(r["mode"] == "online" for r in rep), "max_redo_fraction": max(fr) if fr else None,
+            "mean_redo_fraction": sum(fr) / len(fr) if fr else None}
+
+
 def tuned_gemms_report(ops):
     """which hipBLASLt solutions the vendor GEMMs of this run used: the library's default heuristic, or the per-shape winners of tools/gemm_tune.py
     (videogpa_amd/tuned/, read by PyTorch TunableOp with tuning off; ignored by torch when the file was made on another torch / ROCm / hipBLASLt stack)"""
@@ -686,6 +696,9 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--rank-r", type=int, default=64)
+    ap.add_argument("--weights", choices=["bench", "trained_like"], default="bench", help="trained_like: QK-norm gains of --qk-gain with a few 3 x outlier channels and biases (low-entropy "
+                    "attention rows: what the bound-shifted forward has to cope with on a trained checkpoint) instead of the gains of 1 a random init gives; NOT a BASELINE config")
+    ap.add_argument("--qk-gain", type=float, default=2.5)
     ap.add_argument("--pairs", type=int, default=1, help="preference pairs per GPU and step (the reference's I2V trainer runs 2: train/CogVideoX-I2V-5B/03_train.py:59-60); "
                     "more than one lets the trainer's memory policy choose lean activations")
     ap.add_argument("--checkpoint", action="store_true", default=None, help="per-block activation recompute (needed beyond ~22k tokens per sequence)")
@@ -749,6 +762,15 @@ def main():
     cfg_kw = dict(getattr(vtr, C["model"]), num_layers=args.layers)
     torch.manual_seed(0)                           # identical adapter init (PEFT kaiming-uniform A) on every rank
     model = build_model(cfg_kw, dev, seed=0)       # identical base weights on every rank
+    if args.weights == "trained_like":
+        gq = torch.Generator(device=dev).manual_seed(7)
+        with torch.no_grad():
+            for blk in model.transformer_blocks:
+                for nrm in (blk.attn1.norm_q, blk.attn1.norm_k):
+                    w = args.qk_gain * (1 + 0.2 * torch.randn(64, generator=gq, device=dev))
+                    w[:3] *= 3.0
+                    nrm.weight.copy_(w.to(nrm.weight.dtype))
+                    nrm.bias.copy_((0.1 * args.qk_gain * torch.randn(64, generator=gq, device=dev)).to(nrm.bias.dtype))
     lean = bool(C.get("lean", False) if args.lean is None else args.lean)
     P_ = max(1, args.pairs)
     lean_cfg = "auto" if (P_ > 1 and args.lean is None) else lean        # more than one pair per step: the trainer's own memory policy decides (and is reported)
@@ -816,7 +838,7 @@ def main():
 
     if rank == 0:
         named = (args.layers, F_, H_, W_, args.rank_r, ckpt) == (42, C["frames"], C["height"], C["width"], 64, C["checkpoint"]) and \
-            (lean == bool(C.get("lean", False)) or P_ > 1)
+            (lean == bool(C.get("lean", False)) or P_ > 1) and args.weights == "bench"
         lean = bool(trainer.transformer.get_base_model().lean_activations)     # what actually ran (the memory policy may have chosen)
         ms = dt / args.steps * 1e3
         value = world * args.steps * P_ / dt
@@ -833,6 +855,7 @@ def main():
                                    + ("; lean activations (LN output and normalised q / k made again in the backward)" if lean else ""),
                        "name": args.config, "layers": args.layers, "tokens": S, "pairs_per_gpu": P_, "parallelism": f"dp{world}"},
             "loss": float(logs["train/loss"]), "loss_rank_mean": sync[0], "memory_policy": trainer.memory_policy_log,
+            "attention_forward": attention_forward_summary(trainer.transformer.get_base_model(), args),
             "step_flops_algorithmic": F_step,
             "step_mfma_frac": F_step / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,

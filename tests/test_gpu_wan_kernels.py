@@ -263,6 +263,34 @@ def test_attention128_many_queries_over_short_key_sweeps_vs_fp64(B, H, Sq, Skv):
     _close(vg.grad, rv, "dv", tol=0.03)
 
 
+def test_attention128_e4m3_flagged_strips_are_redone_on_the_dequantised_operands():
+    """a strip the e4m3 kernel flags (here: one head whose keys carry a 40 x outlier, so that most rows lie > 100 log2 units below |q8| max|k8| and their
+    sums underflow) is recomputed by the bf16 running-max kernel; with deq buffers supplied that pass runs on the dequantised operands, so the recomputed softmax
+    rows of (q_deq, k_deq) against lse2 sum to one on the flagged rows like on all others, and the output there is the softmax of (q_deq, k_deq, v_deq)."""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(92)
+    B, H, S = 1, 2, 1280
+    tm = lambda t: t.bfloat16().permute(0, 2, 1, 3)
+    q = tm(torch.randn(B, S, H, 128, device="cuda", generator=g))
+    kk = torch.randn(B, S, H, 128, device="cuda", generator=g)
+    kk[:, 700, 1] *= 40.0                                    # head 1: one huge key
+    k = tm(kk)
+    v = tm(torch.randn(B, S, H, 128, device="cuda", generator=g))
+    scale = 128 ** -0.5
+    deq = tuple(torch.full((B, S, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=True, deq=deq)
+    qd, kd, vd = (t.unflatten(-1, (H, 128)).permute(0, 2, 1, 3).double() for t in deq)
+    LOG2E = 1.4426950408889634
+    s2 = (qd @ kd.transpose(-1, -2)) * (scale * LOG2E)
+    rows = torch.exp2(s2 - lse.double()[..., None]).sum(-1)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    assert (rows[:, 1] - 1).abs().max().item() <= 8e-3, (rows[:, 1] - 1).abs().max().item()        # the head with the outlier: redone rows included
+    assert (rows[:, 0] - 1).abs().max().item() <= 8e-3
+    ref = torch.softmax(s2 / LOG2E, dim=-1) @ vd
+    got = o.view(B, S, H, 128).permute(0, 2, 1, 3).double()
+    assert ((got - ref).abs() <= 0.03 + 0.03 * ref.abs()).all(), (got - ref).abs().max().item()
+
+
 def test_attention128_e4m3_outlier_rows_and_short_sweeps():
     """a 40x query row (bound above 160 -> strip flagged, redone in bf16), a 40x key row (every bound loose), and a 512-key sweep (below
     ATTN128_F8_MIN_KEYS: the bf16 kernels serve it -- the Wan2.2 cross-attention over the text tokens)"""

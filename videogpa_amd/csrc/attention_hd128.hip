@@ -1264,7 +1264,8 @@ extern "C" size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int6
            f8_align((size_t)(B * H * Skv) * 128) + f8_align((size_t)(B * H * 128 * Lp));
 }
 // softmax(scale q k^T) v with e4m3 matrix operands (forward only: same arguments and results as vgpa_attn128_fwd; the workspace holds the quantised
-// copies and is scratch).  Strips the kernel flags (row sum near underflow, bound too large) are redone by the bf16 running-max kernel.
+// copies and is scratch).  Strips the kernel flags (row sum near underflow, bound too large) are redone by the bf16 running-max kernel -- from the dequantised
+// operands when those are asked for (so that every row's output is the softmax of what the backward gets), from q, k, v otherwise.
 // q_deq / k_deq / v_deq (optional, all or none): bf16 copies of the operands the products really ran on -- hand THEM to vgpa_attn128_bwd in place of q, k, v
 // and its recomputed P = exp2(c q k^T - lse2) is this forward's p / l (rows sum to one), dP is formed from the v the forward used and delta = rowsum(dO o O)
 // matches both: the backward is then the straight-through gradient of THIS forward instead of the gradient of a neighbouring bf16 one.
@@ -1305,8 +1306,12 @@ extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void*
                 (bf16_t*)q_deq, (bf16_t*)k_deq, (bf16_t*)v_deq, sqd, skd, svd);
     VGPA_LAUNCH(attn128_fwd_f8_kernel, dim3((unsigned)tasks256), dim3(256), 0, stream, (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)v8t, (const float*)qn2,
                 (const unsigned*)kmax2, (const unsigned*)stats, (bf16_t*)o, lse2, flags, mk128(o_strides), (int)Sq, (int)Skv, (int)Lp, (int)H, (int)n_q256, c, ores, sor);
-    VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2,
-                mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags, ores, sor);
+    // redo pass over the flagged strips (bf16 running-max kernel).  With dequantised operands supplied it runs on THEM: the rows it rewrites (o, lse2, res8) are then
+    // the softmax of exactly the q / k / v the backward will be handed, as everywhere else (round 5 redid from the original bf16 operands, which left those rows'
+    // recomputed P = exp2(c q_deq k_deq - lse2) summing to 1 +- several %: ADVICE r5)
+    VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)(deq ? q_deq : q), (const bf16_t*)(deq ? k_deq : k),
+                (const bf16_t*)(deq ? v_deq : v), (bf16_t*)o, lse2, deq ? sqd : mk128(q_strides), deq ? skd : mk128(k_strides), deq ? svd : mk128(v_strides),
+                mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags, ores, sor);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
