@@ -254,3 +254,82 @@ def test_bench_fences_the_cpu_leg_and_the_secondary_config_children_onto_disjoin
     assert sorted(child) == list(range(124, 140)) and set(leg) == {3, 5, 7, 9} | set(range(100, 124))
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(2 * bench.CHILD_CPUS)), raising=False)
     assert bench.split_host_cpus() == (None, None)
+
+
+def _tiny_trainer(**cfg):
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, num_layers=1, time_embed_dim=32, text_embed_dim=48, use_rotary_positional_embeddings=True).to(torch.bfloat16)
+    return CogVideoXDPOTrainer(dict({"lora_rank": 4, "lora_alpha": 8}, **cfg), transformer=m)
+
+
+def test_lean_activations_setting_is_normalised_and_anything_else_is_an_error():
+    """a truthy non-bool (1, "true") used to run FULL activations silently because of an `is True` check."""
+    import pytest
+    from videogpa_amd.trainer import CogVideoXDPOTrainer
+    f = CogVideoXDPOTrainer._lean_setting
+    assert [f(v) for v in (True, 1, "true", "True", "1", "on")] == [True] * 6
+    assert [f(v) for v in (False, 0, "false", "0", "off")] == [False] * 5
+    assert f("auto") == "auto" and f(None) == "auto" and f(" AUTO ") == "auto"
+    for bad in ("lean", 2, 0.5, [True]):
+        with pytest.raises(ValueError):
+            f(bad)
+    tr = _tiny_trainer(lean_activations=1)
+    assert tr.config["lean_activations"] is True and tr.transformer.get_base_model().lean_activations
+    assert _tiny_trainer(lean_activations="false").config["lean_activations"] is False
+
+
+def test_validation_step_refuses_to_run_over_a_pending_optimizer_step_and_holds_the_hook_off():
+    """DPOEngine defers the optimizer step into the NEXT micro-step's `after_reference` hook; a validation pass must neither trigger it (the
+    policy pass would see adapters updated in the middle of the batch) nor run while one is pending."""
+    import pytest
+
+    class Eng:
+        _pending = object()
+        fired = 0
+
+        def _from_hook(self):
+            self.fired += 1
+    eng = Eng()
+    tr = _tiny_trainer()
+    tr.after_reference = eng._from_hook
+    with pytest.raises(RuntimeError, match="flush"):
+        tr.validation_step({"x_pair": torch.zeros(1, 2, 1, 16, 4, 4, dtype=torch.bfloat16), "prompt_emb": torch.zeros(1, 2, 48, dtype=torch.bfloat16)})
+    assert eng.fired == 0 and tr.after_reference == eng._from_hook          # restored
+    eng._pending = None
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X only"):          # gets as far as the model (no GPU here), with the hook held off
+        tr.validation_step({"x_pair": torch.zeros(1, 2, 1, 16, 4, 4, dtype=torch.bfloat16), "prompt_emb": torch.zeros(1, 2, 48, dtype=torch.bfloat16)})
+    assert eng.fired == 0 and tr.after_reference == eng._from_hook
+
+
+def test_attention_forward_policy_switches_on_the_kernels_own_redo_count():
+    from videogpa_amd import ops
+    p = ops.AttnFwdPolicy()
+    assert p.mode == "bound" and p.wants_flags()
+    p.observe(0.0); p.calls += 1
+    assert p.mode == "bound" and p.wants_flags()
+    p.observe(0.04); p.calls += 1
+    assert p.mode == "bound" and not p.wants_flags()             # two checks done, next re-check at call RECHECK
+    p.calls = ops.AttnFwdPolicy.RECHECK
+    assert p.wants_flags()
+    p.observe(0.5)
+    assert p.mode == "online" and p.switched_at == ops.AttnFwdPolicy.RECHECK and not p.wants_flags()
+    q = ops.AttnFwdPolicy(mode="bound", fixed=True)
+    q.observe(1.0)
+    assert q.mode == "bound" and not q.wants_flags()
+
+
+def test_tuned_gemm_file_is_wired_but_off_without_a_gpu(monkeypatch):
+    """ops.use_tuned_gemms: the shipped TunableOp results file names only hipBLASLt solutions of shapes the step issues; without a GPU nothing is switched on, and a
+    caller that runs TunableOp its own way is left alone."""
+    from videogpa_amd import ops
+    assert os.path.isfile(ops.TUNED_GEMM_FILE)
+    rows = [ln.strip().split(",") for ln in open(ops.TUNED_GEMM_FILE) if ln.strip()]
+    assert {r[1] for r in rows if r[0] == "Validator"} >= {"PT_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME"}
+    entries = [r for r in rows if r[0] != "Validator"]
+    assert entries and all(r[0].startswith(("GemmTunableOp_BFloat16", "GemmAndBiasTunableOp_BFloat16", "ScaledGemmTunableOp")) and r[2].startswith("Gemm_Hipblaslt_") for r in entries)
+    if not torch.cuda.is_available():
+        st = ops.use_tuned_gemms(True)
+        assert st["enabled"] is False
+    monkeypatch.setenv("PYTORCH_TUNABLEOP_ENABLED", "0")
+    st = ops.use_tuned_gemms(True)
+    assert "left as is" in st.get("note", "")

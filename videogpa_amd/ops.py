@@ -453,7 +453,9 @@ def use_tuned_gemms(enabled=True, path=None):
     global _TUNED_GEMMS
     import torch.cuda.tunable as tn
     if _os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is not None:
-        _TUNED_GEMMS = {"enabled": tn.is_enabled(), "file": tn.get_filename(), "entries": None, "note": "PYTORCH_TUNABLEOP_* set by the caller: left as is"}
+        gpu = torch.cuda.is_available()
+        _TUNED_GEMMS = {"enabled": tn.is_enabled() if gpu else False, "file": tn.get_filename() if gpu else None, "entries": None,
+                        "note": "PYTORCH_TUNABLEOP_* set by the caller: left as is"}
         return _TUNED_GEMMS
     path = path or TUNED_GEMM_FILE
     if not torch.cuda.is_available():
