@@ -275,5 +275,7 @@ def test_cfg2_full_depth_pair_step_matches_the_fp32_oracle_block_by_block():
     _run("bench")
 
 
+@pytest.mark.skipif(os.environ.get("VGPA_DEPTH_RICH", "0") != "1", reason="opt-in (VGPA_DEPTH_RICH=1): 2.2 more minutes of a whole GPU; measured in round 6, "
+                    "profiles/r06_cfg2_depth_parity_rich.json")
 def test_cfg2_full_depth_with_order_one_gates_matches_the_fp32_oracle_block_by_block():
     _run("rich")
