@@ -145,8 +145,10 @@ int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const v
                             const int64_t* do_strides, const int64_t* dq_strides, int64_t B, int64_t H, int64_t S, int64_t head_dim,
                             float scale, int32_t split_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 /* Forward on the "w1" structure (attention_w1.hip); arguments and results as vgpa_attn_fwd_ws, the workspace
- * (>= vgpa_attn_fwd_w1_workspace_bytes) is required.  Scores are shifted by M' = b - min(60, b / 2), b = the row bound |q| max|k|, instead of a running
- * maximum; 256-row strips whose sum comes too close to underflow (or overflows) are redone by the online-softmax kernel in the same call. */
+ * (>= vgpa_attn_fwd_w1_workspace_bytes) is required.  Scores are shifted per row by M' = min(b, m_s + 64), b = the bound |q| max|k|, m_s = the row's maximum
+ * over 64 keys spread evenly over the sequence, instead of a running maximum; 256-row strips whose sum overflows or comes too close to underflow (a row whose true
+ * maximum lies > ~176 log2 units above the sampled one) are redone by the online-softmax kernel in the same call.  lse2 is formed from the sum of the bf16-ROUNDED
+ * weights (the ones the PV product multiplies: O is an exact convex combination of V rows); it differs from the exact value by a row's mean rounding error. */
 size_t vgpa_attn_fwd_w1_workspace_bytes(int64_t B, int64_t H, int64_t S);
 int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
                          const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,
@@ -164,8 +166,7 @@ int32_t vgpa_attn_fwd_w1_res(const void* q, const void* k, const void* v, void* 
                              int64_t B, int64_t H, int64_t S, int64_t head_dim, float scale, int32_t split_mode, void* workspace,
                              size_t ws_bytes, vgpa_stream_t stream);
 /* Redo accounting of vgpa_attn_fwd_w1 / _w1_res: after the call the workspace holds, behind its first B*H uint32 words (max_k |k|^2 per head), one int32 per
- * (batch, head, 256-row strip): non-zero = the strip's rows lay outside what the bound-shifted loop represents (row maximum more than ~160 log2 units below
- * |q| max|k|, or a bound above 1084) and it was redone by the online-softmax kernel inside the same call.  Results never depend on it; time does.
+ * (batch, head, 256-row strip): non-zero = the strip held a row outside what the shifted loop represents (see vgpa_attn_fwd_w1) and it was redone by the online-softmax kernel inside the same call.  Results never depend on it; time does.
  * vgpa_attn_fwd_online_res: same arguments, results and workspace, EVERY strip on the online-softmax kernel -- the faster call when most strips would be flagged
  * (one sweep instead of two).  The host side (transformer.AttentionCore) reads the count on a layer's first calls and switches that layer. */
 int32_t vgpa_attn_fwd_online_res(const void* q, const void* k, const void* v, void* o, void* o_res, int32_t res_kind, float* lse2, const int64_t* q_strides,

@@ -307,11 +307,11 @@ def test_attention_forward_policy_switches_on_the_kernels_own_redo_count():
     assert p.mode == "bound" and p.wants_flags()
     p.observe(0.0); p.calls += 1
     assert p.mode == "bound" and p.wants_flags()
-    p.observe(0.04); p.calls += 1
+    p.observe(0.4); p.calls += 1
     assert p.mode == "bound" and not p.wants_flags()             # two checks done, next re-check at call RECHECK
     p.calls = ops.AttnFwdPolicy.RECHECK
     assert p.wants_flags()
-    p.observe(0.5)
+    p.observe(0.6)
     assert p.mode == "online" and p.switched_at == ops.AttnFwdPolicy.RECHECK and not p.wants_flags()
     q = ops.AttnFwdPolicy(mode="bound", fixed=True)
     q.observe(1.0)

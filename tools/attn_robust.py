@@ -3,7 +3,7 @@ its speed depends on the score distribution -- strips whose rows it cannot repre
 For operands shaped like a trained QK-normed model's (tools/attn_data.py: LayerNorm outputs with gain g and a few outlier channels, every query matched to one key,
 optional sink keys) at the headline shape, per setting:
     ms per launch of the bound-shifted forward (incl. its redo pass), fraction of strips redone, ms of the all-online call, ms of what the layer policy
-    (ops.AttnFwdPolicy: switch to online above 5 % redone) ends up running, each relative to the same kernel on bench.py's N(0,1) operands.
+    (ops.AttnFwdPolicy: switch to the all-online entry above 50 % redone) ends up running, each relative to the same kernel on bench.py's N(0,1) operands.
     python tools/attn_robust.py [--S 17776] [--B 2] [--H 48] [--iters 3] [--json gpurun_out/attn_trained_like.json]"""
 import argparse
 import json

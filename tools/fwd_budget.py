@@ -10,7 +10,8 @@ from collections import OrderedDict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLASSES = OrderedDict([
-    ("mfma 32x32x16 bf16", (r"^v_mfma_", 32.0, "matrix pipe: 8 passes x 4 cycles")),
+    ("mfma 32x32x16 bf16", (r"^v_mfma_f32_32x32x16", 32.0, "matrix pipe: 8 passes x 4 cycles")),
+    ("mfma 16x16x32 bf16 (row sums: sparse selector x packed P)", (r"^v_mfma_f32_16x16x32", 16.0, "matrix pipe: 4 passes; replaces the 32 row-sum adds since round 6 (mfsum)")),
     ("exp2 (v_exp_f32)", (r"^v_exp_f32", 8.0, "one per score; transcendental unit, measured 1.6-2.7 x v_fma_f32; gfx950 has no packed / bf16 form (llvm-mc rejects v_exp_bf16, v_pk_exp_f16)")),
     ("row-sum add (v_add_f32)", (r"^v_add_f32", 4.0, "one per score into 4 partial sums per q-block; v_pk_add_f32 halves the count but holds the matrix pipe ~13 cycles each (r01p_coissue_table)")),
     ("bf16 pack (v_cvt_pk_bf16_f32)", (r"^v_cvt_pk_bf16_f32", 5.8, "one per two scores: the PV product's B operand")),
@@ -66,7 +67,7 @@ def main():
         _, cyc, note = CLASSES[k]
         rows.append((k, n / HS, cyc, n / HS * cyc, note))
     valu = sum(r[3] for r in rows if r[0].startswith(("exp2", "row-sum", "bf16 pack", "address")))
-    mfma = rows[0][3]
+    mfma = sum(r[3] for r in rows if r[0].startswith("mfma"))
     txt = ["| class | instructions per half-step | issue cycles each | cycles per half-step | note |", "|---|---|---|---|---|"]
     for k, n, cyc, tot, note in rows:
         txt.append(f"| {k} | {n:.2f} | {cyc if cyc else '-'} | {tot:.0f} | {note} |")
@@ -81,7 +82,7 @@ def main():
         half_steps = p.get("half_steps_per_launch")
         for c, v in p["counters"].items():
             per = v / half_steps if half_steps else float("nan")
-            st = {"SQ_INSTS_VALU": valu_count(counts), "SQ_INSTS_MFMA": counts["mfma 32x32x16 bf16"] / HS, "SQ_INSTS_VALU_TRANS_F32": counts["exp2 (v_exp_f32)"] / HS,
+            st = {"SQ_INSTS_VALU": valu_count(counts), "SQ_INSTS_MFMA": sum(v for k, v in counts.items() if k.startswith("mfma")) / HS, "SQ_INSTS_VALU_TRANS_F32": counts["exp2 (v_exp_f32)"] / HS,
                   "SQ_INSTS_LDS": counts["LDS fragment reads (ds_read_b128 / ds_read_b64_tr_b16)"] / HS}.get(c)
             txt.append(f"| {c} | {v:.4g} | {per:.2f} | {'' if st is None else f'{st:.2f}'} |")
         for k, v in p.get("derived", {}).items():

@@ -93,16 +93,27 @@ def table(args):
     tn.enable(False)
     for (op, key), (sol, ms_rec) in sorted(rows.items()):
         k = _parse_key(key)
-        if k is None or not op.endswith("_TN") or "BFloat16" not in op or "Scaled" in op:
+        if k is None or not op.endswith("_TN") or "BFloat16" not in op:
             continue
         N, M, K = k["m"], k["n"], k["k"]
         fl = 2.0 * M * N * K
         if fl < args.min_flop:
             continue
-        W = (torch.randn(N, k["lda"], device=dev) / K ** 0.5).bfloat16()[:, :K]
-        x = torch.randn(M, k["ldb"], device=dev).bfloat16()[:, :K]
-        bias = torch.randn(N, device=dev).bfloat16() if op.startswith("GemmAndBias") else None
-        fn = lambda: F.linear(x, W, bias)
+        if op.startswith("ScaledGemm"):
+            # the e4m3 feed-forward GEMMs of cfg5 (ops.frozen_linear_fp8: row-wise scales, bf16 out): torch._scaled_mm(x8 [M,K], w8 [N,K]^T, scale_a [M,1], scale_b [1,N])
+            if "Float8_e4m3fn_Float8_e4m3fn" not in op or "_rw_1_" not in key or k["lda"] != K or k["ldb"] != K:
+                continue
+            x8 = torch.randn(M, K, device=dev).clamp(-3, 3).to(torch.float8_e4m3fn)
+            w8 = torch.randn(N, K, device=dev).clamp(-3, 3).to(torch.float8_e4m3fn)
+            sa, sb = torch.rand(M, 1, device=dev) + 0.5, torch.rand(1, N, device=dev) + 0.5
+            bias = torch.randn(N, device=dev).bfloat16() if key.endswith("bias_BFloat16") else None
+            fn = lambda: torch._scaled_mm(x8, w8.t(), scale_a=sa, scale_b=sb, bias=bias, out_dtype=torch.bfloat16)
+            W = x = None
+        else:
+            W = (torch.randn(N, k["lda"], device=dev) / K ** 0.5).bfloat16()[:, :K]
+            x = torch.randn(M, k["ldb"], device=dev).bfloat16()[:, :K]
+            bias = torch.randn(N, device=dev).bfloat16() if op.startswith("GemmAndBias") else None
+            fn = lambda: F.linear(x, W, bias)
 
         def measure():
             for _ in range(3):
@@ -130,7 +141,7 @@ def table(args):
         tn.enable(False)
         d_ms, t_ms = (res["default"][0] + res["default2"][0]) / 2, (res["tuned"][0] + res["tuned2"][0]) / 2
         d_J, t_J = (res["default"][1] + res["default2"][1]) / 2, (res["tuned"][1] + res["tuned2"][1]) / 2
-        row = {"op": op, "M": M, "N": N, "K": K, "lda_W": k["lda"], "ld_x": k["ldb"], "bias": bias is not None, "solution": sol, "default_ms": d_ms, "tuned_ms": t_ms,
+        row = {"op": op, "key": key, "M": M, "N": N, "K": K, "lda_W": k["lda"], "ld_x": k["ldb"], "bias": bias is not None, "solution": sol, "default_ms": d_ms, "tuned_ms": t_ms,
                "default_J": d_J, "tuned_J": t_J, "speedup": d_ms / t_ms, "default_tflops": fl / d_ms / 1e9, "tuned_tflops": fl / t_ms / 1e9,
                "default_tflop_per_J": fl / d_J / 1e12, "tuned_tflop_per_J": fl / t_J / 1e12}
         out_rows.append(row)
@@ -151,7 +162,7 @@ def prune(args):
     tab = json.load(open(args.table))["rows"]
     keep = {}
     for r in tab:
-        key = f"tn_{r['N']}_{r['M']}_{r['K']}_ld_{r['lda_W']}_{r['ld_x']}_{r['N']}"
+        key = r.get("key") or f"tn_{r['N']}_{r['M']}_{r['K']}_ld_{r['lda_W']}_{r['ld_x']}_{r['N']}"
         gain_t, gain_j = r["default_ms"] / r["tuned_ms"], r["default_J"] / r["tuned_J"]
         ok = r["solution"] != "Default" and gain_t >= args.min_gain and gain_j >= 1.0
         print(f"{r['op']:36s} {key:44s} {r['solution']:26s} time x{gain_t:5.3f} joules x{gain_j:5.3f} -> {'KEEP' if ok else 'default heuristic'}")

@@ -491,10 +491,14 @@ class FwdLoop:
     """forward:  a wave owns two 32-row q-blocks j (Q fragments and O^T accumulators in AGPRs) and streams 64-key K|V tiles; per
        32-key half-tile g:
          A(g): S[g&1][j] = -M[q] + K_g Q_j^T                     8 MFMAs; -M[q] is the srcC of the first k-step (loop-invariant tuple)
-         B(g): P = exp2(S), l[j] += rowsum(P), PK[g&1][j] = bf16(P)   80 VALU (4 partial sums per q-block keep the add chains short).
-               (Measured alternative: the row sums as 4 extra MFMAs against an all-ones operand instead of the 32 adds -- same
-               time, the kernel is power-limited, not issue-limited -- but l then sums the bf16-ROUNDED P and lse2 loses three
-               digits (1e-3 instead of 1e-6); the fp32 sums stay.)
+         B(g): P = exp2(S), PK[g&1][j] = bf16(P)                      48 VALU (32 exp + 16 packs).  The row sums l[j] += rowsum(P) ride the MATRIX pipe since
+               round 6 (mfsum, the default; W1_KNOBS=mfsum=0 restores the 32 v_add_f32 into 4 partial sums per q-block): four v_mfma_f32_16x16x32_bf16 per
+               half-step multiply the packed P registers by a SPARSE selector (2 of its 16 rows hold ones: see mfmas()), 64 matrix-pipe cycles for 128 VALU
+               cycles, and the selector barely toggles the multiplier array: 6.95 -> 6.58 ms and 9.13 -> 8.63 J per launch in one session
+               (profiles/r06_fwd_mfsum_ab.txt).  Round 3 had tried the sums as four FULL 32x32x16 products against an all-ones operand: + 128 pipe cycles at full
+               toggling, same time.  l now sums the bf16-rounded P -- exactly the weights the PV product uses, so O = sum(P~ v) / sum(P~) is a true convex
+               combination -- and lse2 = M' + log2(l~) differs from the exact one by the mean rounding error of a row's weights (<= 2^-9 relative on a one-hot row,
+               ~1e-4 typical): the backward's recomputed P = exp2(s - lse2) is scaled per ROW by that factor, which leaves every row's dS summing to zero.
          C(g): O^T[j] += V_g^T P                                  8 MFMAs on transpose-read V fragments
        half-step(g) issues C(g-1) | A(g+1) | B(g).  M[q] = |q| max_k |k| bounds every score of the row from above (the caller
        computes it), so P <= 1 and the loop carries no running maximum, no rescale and no branch.  Keys past the end must not
@@ -541,7 +545,7 @@ class FwdLoop:
                 cc, db = c >> 1, c & 1
                 d = ar(32 * j + 16 * db, 16)
                 out.append((f"{MFMA} {d}, {ar(self.frag_reg(c), 4)}, {vr(self.PK(pc, j, cc), 4)}, {d}", c))
-                if KNOB.get("mfsum") and db == 1 and j == 1:
+                if KNOB.get("mfsum", 1) and db == 1 and j == 1:
                     # W1_KNOBS=mfsum=1: l[q] += sum_k P[k][q] as a 16x16x32 product of a SPARSE selector against the same packed P registers the PV product
                     # reads.  Read as the B operand of v_mfma_f32_16x16x32_bf16, lane L of the 32x32x16 B fragment (column q = L % 32, keys 8 (L / 32) ..+7 of the
                     # 16-key chunk) is column n' = L % 16, k'-block L / 16: blocks 0, 2 hold q = n' (keys 0-7, 8-15), blocks 1, 3 hold q = n' + 16.  With
@@ -567,7 +571,7 @@ class FwdLoop:
             s0 = self.S(pb, j) + 2 * p
             w = self.PK(pb, j, p >> 2) + (p & 3)
             l0, l1 = 128 + 4 * j + ((2 * p) & 3), 128 + 4 * j + ((2 * p + 1) & 3)
-            if KNOB.get("mfsum"):      # row sums on the matrix pipe (see mfmas): no adds at all
+            if KNOB.get("mfsum", 1):      # row sums on the matrix pipe (see mfmas): no adds at all
                 return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"], [None, None], f"v_cvt_pk_bf16_f32 v{w}, v{s0}, v{s0 + 1}")
             if KNOB.get("pksum"):      # the two row-sum adds as ONE packed add (same fp32 additions in the same order: bit-identical results)
                 return ([f"v_exp_f32 v{s0}, v{s0}", f"v_exp_f32 v{s0 + 1}, v{s0 + 1}"],
@@ -611,7 +615,7 @@ class FwdLoop:
         SAVE_M0, CNT, KREM, TMP = "%0", "%1", "%2", "%3"
         RK, RV, KSTEP, VSTEP, WBASE, NITER, KREM0 = "%[rk]", "%[rv]", "%[kstep]", "%[vstep]", "%[wbase]", "%[niter]", "%[krem]"
         em.raw(f"s_mov_b32 {SAVE_M0}, m0")
-        if KNOB.get("mfsum"):
+        if KNOB.get("mfsum", 1):
             for i in range(4):                                     # the selector operand A' (v158: 0x3f803f80 in lanes 0, 17, 32, 49, else 0)
                 em.raw(f"v_accvgpr_write_b32 a{128 + i}, v158")
         em.raw(f"s_mov_b32 {CNT}, {NITER}")
@@ -1502,9 +1506,9 @@ TARGETS = {"w1_dq_loop.inc": lambda: DqLoop().generate(),
            "w1_gemm_loop.inc": lambda: GemmLoop().generate(),
            "w1_gemm_clobbers.inc": lambda: clobbers([], [(128, 175)]),
            "w1_fwd_loop.inc": lambda: FwdLoop().generate(),
-           "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 127)] + ([(128, 131)] if KNOB.get("mfsum") else [])),
+           "w1_fwd_clobbers.inc": lambda: clobbers([(0, 127), (157, 157)], [(96, 127)] + ([(128, 131)] if KNOB.get("mfsum", 1) else [])),
            # what the C++ around the forward loop must know about the knobs the loop was generated with (attention_w1.hip: selector operand, epilogue)
-           "w1_fwd_knobs.inc": lambda: f"#define W1_FWD_MFSUM {1 if KNOB.get('mfsum') else 0}\n"}
+           "w1_fwd_knobs.inc": lambda: f"#define W1_FWD_MFSUM {1 if KNOB.get('mfsum', 1) else 0}\n"}
 
 
 def main():

@@ -974,12 +974,14 @@ def prescale_q(q, scale=None):
 
 
 class AttnFwdPolicy:
-    """Which forward one attention layer runs, decided from what the kernel itself reports.  "bound": the w1 kernel (softmax shifted by a row bound instead of a
-    running maximum; strips whose rows it cannot represent are flagged and redone inside the same call by the online-softmax kernel -- results never depend on
-    it, time does: + 1.05 launches' worth per flagged strip).  "online": every strip on the online-softmax kernel (vgpa_attn_fwd_online_res), the faster call once
-    more than SWITCH of the strips would be redone.  The flags of a layer's first CHECKS calls (and of every RECHECK-th call after) are read back -- one host
-    sync each -- and the layer switches for good when the flagged fraction exceeds SWITCH.  `fixed` pins the mode (tools, tests)."""
-    SWITCH, CHECKS, RECHECK = 0.05, 2, 1024
+    """Which forward one attention layer runs, decided from what the kernel itself reports.  "bound": the w1 kernel (softmax shifted per row by
+    min(Cauchy-Schwarz bound, sampled row maximum + 64) instead of a running maximum; strips with a row it cannot represent -- the true maximum more than ~176 log2
+    units above the maximum over 64 sampled keys -- are flagged and redone inside the same call by the online-softmax kernel: results never depend on it, time does).
+    "online": every strip on the online-softmax kernel (vgpa_attn_fwd_online_res).  On the data that gets strips flagged (near one-hot rows with a huge score range)
+    the online kernel itself runs 2.3-2.5 x its usual time (its running maximum keeps moving: measured 17.5 ms against 7.2, profiles/r06b_attn_trained_like.txt), so
+    the switch only pays once MORE THAN HALF the strips would be swept twice: SWITCH = 0.5.  The flags of a layer's first CHECKS calls (and of every RECHECK-th call
+    after) are read back -- one host sync each -- and the layer switches for good above SWITCH.  `fixed` pins the mode (tools, tests)."""
+    SWITCH, CHECKS, RECHECK = 0.5, 2, 1024
 
     def __init__(self, mode="bound", fixed=False):
         self.mode, self.fixed = mode, fixed
