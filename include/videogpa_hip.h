@@ -148,7 +148,8 @@ int32_t vgpa_attn_bwd_dq_w1(const void* q, const void* k, const void* v, const v
  * (>= vgpa_attn_fwd_w1_workspace_bytes) is required.  Scores are shifted per row by M' = min(b, m_s + 64), b = the bound |q| max|k|, m_s = the row's maximum
  * over 64 keys spread evenly over the sequence, instead of a running maximum; 256-row strips whose sum overflows or comes too close to underflow (a row whose true
  * maximum lies > ~176 log2 units above the sampled one) are redone by the online-softmax kernel in the same call.  lse2 is formed from the sum of the bf16-ROUNDED
- * weights (the ones the PV product multiplies: O is an exact convex combination of V rows); it differs from the exact value by a row's mean rounding error. */
+ * weights (the ones the PV product multiplies: O is an exact convex combination of V rows); it differs from the exact value by a row's weighted mean rounding error
+ * (<= 2^-8 relative, i.e. 5.6e-3 in log2 units, on a one-hot row; ~ 2e-3 / sqrt(n) on a row spread over n keys: tests/attn_tol.py). */
 size_t vgpa_attn_fwd_w1_workspace_bytes(int64_t B, int64_t H, int64_t S);
 int32_t vgpa_attn_fwd_w1(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides,
                          const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int64_t B, int64_t H, int64_t S,

@@ -287,8 +287,44 @@ def test_attention128_e4m3_flagged_strips_are_redone_on_the_dequantised_operands
     assert (rows[:, 1] - 1).abs().max().item() <= 8e-3, (rows[:, 1] - 1).abs().max().item()        # the head with the outlier: redone rows included
     assert (rows[:, 0] - 1).abs().max().item() <= 8e-3
     ref = torch.softmax(s2 / LOG2E, dim=-1) @ vd
-    got = o.view(B, S, H, 128).permute(0, 2, 1, 3).double()
+    got = o.double()                                       # attention128_fwd_raw returns the [B,H,S,128] view of its token-major storage
     assert ((got - ref).abs() <= 0.03 + 0.03 * ref.abs()).all(), (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("gap,f8", [(126.5, False), (104.0, False), (90.0, False), (126.5, True)])
+def test_attention128_row_between_overflow_of_o_and_overflow_of_l(gap, f8):
+    """as tests/test_gpu_kernels.py::test_attention_row_between_overflow_of_o_and_overflow_of_l, for the head_dim-128 forwards (same sampled shift): one key the
+    64-key sample does not see lifts a row's maximum `gap` log2 units above M' -- the row sum stays finite, the O accumulators overflow; the strip has to be
+    flagged and redone (gap 90: stays on the fast path and must be right there).  The e4m3 forward is run on the same operands (its shift is the row bound)."""
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1280 + int(gap))
+    B, H, S = 1, 2, 1280
+    q, k, v = (torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16() for _ in range(3))
+    scale = 128 ** -0.5
+    LOG2E = 1.4426950408889634
+    row, key = 5, 7
+    assert key % (S // 64) != 0
+    s_row = (q[0, 1, row].double() @ k[0, 1].double().t()) * (scale * LOG2E)
+    ms = s_row[torch.arange(64, device="cuda") * (S // 64)].max().item()
+    want = ms + 64.0 + gap
+    k[0, 1, key] = (q[0, 1, row].float() * (want / (float(q[0, 1, row].double() @ q[0, 1, row].double()) * scale * LOG2E))).bfloat16()
+    v[0, 1, key] = (8.0 * torch.sign(v[0, 1, key].float())).bfloat16()
+    s2 = (q.double() @ k.double().transpose(-1, -2)) * (scale * LOG2E)
+    bound = q[0, 1, row].double().norm() * k[0, 1].double().norm(dim=-1).max() * (scale * LOG2E)
+    got_gap = s2[0, 1, row].max().item() - min(bound.item(), ms + 64.0)
+    assert abs(got_gap - gap) < 1.0, got_gap
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=f8)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    w = torch.softmax(s2 / LOG2E, dim=-1)
+    ref = w @ v.double()
+    lse_ref = torch.logsumexp(s2 / LOG2E, dim=-1) * LOG2E
+    if f8:          # e4m3 operands: the one-hot row is exact to e4m3's rounding of v (8 is representable), the others to the e4m3 model's accuracy
+        assert ((o.double() - ref)[0, 1, row].abs() <= 0.05 + 0.07 * ref[0, 1, row].abs()).all()
+        a, r = o.double().flatten(), ref.flatten()
+        assert float(a @ r / (a.norm() * r.norm())) >= 0.99
+    else:
+        assert ((o.double() - ref).abs() <= 0.02 + 0.008 * ref.abs()).all(), (o.double() - ref).abs().max().item()
+        assert ((lse.double() - lse_ref).abs() <= 2e-3 + 2e-5 * lse_ref.abs()).all()
 
 
 def test_attention128_e4m3_outlier_rows_and_short_sweeps():

@@ -497,7 +497,7 @@ class FwdLoop:
                cycles, and the selector barely toggles the multiplier array: 6.95 -> 6.58 ms and 9.13 -> 8.63 J per launch in one session
                (profiles/r06_fwd_mfsum_ab.txt).  Round 3 had tried the sums as four FULL 32x32x16 products against an all-ones operand: + 128 pipe cycles at full
                toggling, same time.  l now sums the bf16-rounded P -- exactly the weights the PV product uses, so O = sum(P~ v) / sum(P~) is a true convex
-               combination -- and lse2 = M' + log2(l~) differs from the exact one by the mean rounding error of a row's weights (<= 2^-9 relative on a one-hot row,
+               combination -- and lse2 = M' + log2(l~) differs from the exact one by the mean rounding error of a row's weights (<= 2^-8 relative on a one-hot row: tests/attn_tol.py,
                ~1e-4 typical): the backward's recomputed P = exp2(s - lse2) is scaled per ROW by that factor, which leaves every row's dS summing to zero.
          C(g): O^T[j] += V_g^T P                                  8 MFMAs on transpose-read V fragments
        half-step(g) issues C(g-1) | A(g+1) | B(g).  M[q] = |q| max_k |k| bounds every score of the row from above (the caller

@@ -219,6 +219,7 @@ typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
 #define W1H_SLOT_BYTES 32768
 #define W1H_RING_BYTES (4 * W1H_SLOT_BYTES)
 #define W1H_L_MIN 7.888609052210118e-31f   // 2^-100
+#define W1H_L_MAX 1.2676506e30f            // 2^100: as W1_L_MAX (attention_w1.hip) -- a finite row sum next to overflowed O accumulators must flag the strip too
 #define W1H_M_MAX 1024.0f      // as W1_M_MAX (attention_w1.hip): the fp32 accumulator's ulp at |M'| = 1024 is a fiftieth of the weight's bf16 rounding
 #define W1H_SAMPLE_KEYS 64     // as W1_SAMPLE_KEYS / W1_SAMPLE_UP (attention_w1.hip): the shift follows a sampled lower bound of the row maximum
 #define W1H_SAMPLE_UP 64.0f
@@ -396,7 +397,12 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_w1_kernel(const bf16_t* __
         const float M = -nmc[j] * c;
         const int q = q0 + 32 * j + (lane & 31);
         if (q < Sq) {
-            bad = bad || !(l >= W1H_L_MIN && l < INFINITY) || !(M <= W1H_M_MAX);
+            float oabs = 0.f;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oabs += fabsf(o[j][db][i]);
+            bad = bad || !(l >= W1H_L_MIN && l < W1H_L_MAX) || !(M <= W1H_M_MAX) || !(oabs < INFINITY);
             store_col128_res8(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), RES_ROW(ORES, sor, b, h, q), o[j], 1.f / l, hi);
             if (hi == 0) LSE2[(size_t)bh * Sq + q] = M + __builtin_amdgcn_logf(l);
         }
@@ -1247,7 +1253,12 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_f8_kernel(const uint8_t* _
         const float M = -nm[j];
         const int q = q0 + 32 * j + m;
         if (q < Sq) {
-            bad = bad || !(l >= W1H_L_MIN && l < INFINITY) || !(M <= W1H_M_MAX);
+            float oabs = 0.f;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oabs += fabsf(o[j][db][i]);
+            bad = bad || !(l >= W1H_L_MIN && l < W1H_L_MAX) || !(M <= W1H_M_MAX) || !(oabs < INFINITY);
             store_col128_res8(O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s), RES_ROW(ORES, sor, b, h, q), o[j], 1.f / l, hi);
             if (hi == 0) LSE2[(size_t)bh * Sq + q] = M + __builtin_amdgcn_logf(l);
         }

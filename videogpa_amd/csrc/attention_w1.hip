@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 #include "w1_fwd_knobs.inc"                   // W1_FWD_MFSUM: what the generated loop expects around it (tools/gen_w1_asm.py W1_KNOBS; 0 in the product)
 #define W1_FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64] (un-normalised), M[256], l[256] -- layout of attention.hip's split forward
 #define W1_L_MIN 7.8886e-31f                  // 2^-100: below this the row's sum is too close to underflow -> redo
+// ... and above 2^100 too close to overflow: the O accumulators carry sum_j p_j v_j <= l max|v| (a row whose true maximum lies 112-128 above the shift has a FINITE
+// l next to O = +-inf, and 1 / l flushes to zero from 2^126 on).  Found by `bench.py --weights trained_like` (one row of block 38, true maximum 127.7 above M':
+// l = 2^127.7, O = inf, strip not flagged -> NaN loss; tools/attn_fault_repro.py).  The epilogue also checks the accumulators themselves (w1_sum_abs): |v| is the caller's.
+#define W1_L_MAX 1.2676506e30f                // 2^100
 // With the shift at the row BOUND the largest weight of a row is exp2(s_max - M), not 1, so it carries a bf16 rounding error in the
 // numerator (2^-9 relative) that the fp32 denominator does not share; over a few dozen keys these errors average out, over one or
 // two they do not (S = 1: O off by up to 0.4 %).  Rows that short are not a performance case: below this length every strip goes to
@@ -374,7 +378,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w1_kernel(const bf16_t* __res
     for (int j = 0; j < QB; ++j) {
         const int q = q0 + 32 * j + (lane & 31);
         if (q < S) {
-            bad = bad || !(l[j] >= W1_L_MIN && l[j] < INFINITY) || !(-nm[j] <= W1_M_MAX);
+            float oabs = 0.f;                                 // inf / NaN in any accumulator of the row survives the sum (fmaxf would drop a NaN)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oabs += fabsf(o[j][db][i]);
+            bad = bad || !(l[j] >= W1_L_MIN && l[j] < W1_L_MAX) || !(-nm[j] <= W1_M_MAX) || !(oabs < INFINITY);
             const float inv = 1.f / l[j];
             bf16_t* op = O + ((size_t)b * so.b + (size_t)h * so.h + (size_t)q * so.s);
             const size_t ro = (size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s;      // residual row (elements of either kind)
@@ -433,9 +442,10 @@ __global__ __launch_bounds__(256) void w1_fwd_merge_kernel(const float* __restri
     const size_t ro = (size_t)b * sor.b + (size_t)h * sor.h + (size_t)q * sor.s + lane;
     if (res_kind == VGPA_RES_8) ((uint8_t*)ORES)[ro] = (uint8_t)res8_byte(x, xb);
     else if (res_kind == VGPA_RES_BF16) ((bf16_t*)ORES)[ro] = f32_to_bf16(x - bf16_to_f32(xb));
+    const bool obad = __any(!(fabsf(acc) < INFINITY));      // the row's 64 un-normalised outputs live one per lane
     if (lane == 0) {
         LSE2[(int64_t)bh * S + q] = pb[256 * HD + r] + __builtin_amdgcn_logf(L);
-        if (!(L >= W1_L_MIN && L < INFINITY) || !(pb[256 * HD + r] <= W1_M_MAX)) flags[vid] = 1;
+        if (!(L >= W1_L_MIN && L < W1_L_MAX) || !(pb[256 * HD + r] <= W1_M_MAX) || obad) flags[vid] = 1;
     }
 }
 
