@@ -602,6 +602,15 @@ def main_wan(args, C, world, rank, dev, force_dist):
         torch.set_default_dtype(prev)
     with torch.no_grad():
         torch.nn.init.normal_(model.head.head.weight, std=0.02)      # upstream zero-inits the output layer: give the loss a signal
+    if args.weights == "trained_like":      # as for cfg2: QK-norm gains of --qk-gain (+- 20 %), three 3 x outlier channels per head (whole-row RMS-norm: weight [dim])
+        gq = torch.Generator(device=dev).manual_seed(7)
+        with torch.no_grad():
+            for blk in model.blocks:
+                for att in (blk.self_attn, blk.cross_attn):
+                    for nrm in (att.norm_q, att.norm_k):
+                        w = args.qk_gain * (1 + 0.2 * torch.randn(model.dim, generator=gq, device=dev))
+                        w.view(model.num_heads, -1)[:, :3] *= 3.0
+                        nrm.weight.copy_(w.to(nrm.weight.dtype))
     model.enable_fp8(not args.no_fp8, attention=not (args.no_fp8 or args.no_fp8_attn))
     trainer = WanDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2.0 * args.rank_r, "accumulate_grad_batches": 1, "seed": 1234,
                              "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": stride, "tuned_gemms": not args.no_tuned_gemms}, model)
@@ -651,7 +660,8 @@ def main_wan(args, C, world, rank, dev, force_dist):
     if getattr(args, "preflight", None):
         drep["preflight"] = args.preflight
     if rank == 0:
-        named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8, args.no_fp8_attn) == (30, C["frames"], C["height"], C["width"], 64, False, False, False)
+        named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8, args.no_fp8_attn) == (30, C["frames"], C["height"], C["width"], 64, False, False, False) \
+            and args.weights == "bench"
         ms = dt / args.steps * 1e3
         out = {
             "metric": "DPO preference-pair steps/sec, Wan2.2-TI2V-5B 81f@704x1280", "value": world * args.steps / dt, "unit": "pair-steps/s",
