@@ -259,9 +259,13 @@ int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, f
  * with one power-of-two scale per (batch, head) and tensor, v transposed, by two prep kernels; both products run as v_mfma_scale_f32_32x32x64_f8f6f4
  * with the scales -- and a per-tile, per-row power of two for the softmax weights -- on the instruction's E8M0 operands; row sums and lse2 stay fp32.
  * Arguments and results as vgpa_attn128_fwd; the workspace (>= vgpa_attn128_fwd_f8_workspace_bytes, 256-byte aligned) is REQUIRED and is scratch.
+ * The softmax shift of a row is M' = b - n, b = |q8 row| max|k8 row| and n = floor(max(0, b - (m_s + 64))) with m_s the row's maximum over 64 keys spread evenly
+ * over the sweep (as vgpa_attn_fwd_w1; an INTEGER step off the bound, so the e4m3 bits of the weights do not depend on it); 256-row strips with a row it cannot
+ * represent (row sum outside [2^-100, 2^100), M' > 1024, a non-finite accumulator) are redone by the bf16 running-max kernel inside the call.
  * Forward only.  q_deq / k_deq / v_deq (optional, all three or none; bf16 [B,H,S,128] views with their stride triples): the operands the products really ran
- * on, dequantised (q8 2^eq / c rounded to bf16; k8 2^ek and v8 2^ev exactly).  vgpa_attn128_bwd run on THEM with this call's lse2, output and o_res8 is the
- * straight-through gradient of this forward: its recomputed softmax weights are this call's (rows sum to one) and delta = rowsum(dO o O) matches them. */
+ * on, dequantised EXACTLY (an e4m3 value times a power of two is a bf16 number): k8 2^ek, v8 2^ev and q8 2^eq -- the query PRE-SCALED by scale * log2 e.
+ * vgpa_attn128_bwd_prescaled run on THEM with this call's lse2, output and o_res8 is the straight-through gradient of this forward: its recomputed scores are
+ * this call's bit for bit, its softmax weights this call's p / l (rows sum to one) and delta = rowsum(dO o O) matches them. */
 size_t vgpa_attn128_fwd_f8_workspace_bytes(int64_t B, int64_t H, int64_t Sq, int64_t Skv);
 int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void* v, void* o, float* lse2, const int64_t* q_strides, const int64_t* k_strides,
                             const int64_t* v_strides, const int64_t* o_strides, void* o_res8, const int64_t* ores_strides, void* q_deq, void* k_deq,
@@ -275,6 +279,13 @@ int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void
                          const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
                          const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
                          float scale, int32_t dkv_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
+/* vgpa_attn128_bwd for a query that arrives PRE-SCALED by scale * log2 e (q = vgpa_attn128_fwd_f8's q_deq; k = k_deq, v = v_deq): scores are q.k as they stand
+ * (log2 units); dq = scale dS k is the gradient w.r.t. the UNscaled query, dk = ln 2 dS^T q (= scale dS^T q_unscaled).  Everything else as vgpa_attn128_bwd. */
+int32_t vgpa_attn128_bwd_prescaled(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
+                                   void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                   const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                                   const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
+                                   float scale, int32_t dkv_mode, void* workspace, size_t ws_bytes, vgpa_stream_t stream);
 
 /* ---- row kernels of the Wan2.2 denoiser block (WanAttentionBlock / WanRMSNorm / rope_apply of the Wan2.2 checkout imported at
  * train/Wan2.2-TI2V-5B/03_train.py:43-48).  fp32 residual stream, bf16 matmul operands.  Per-token modulation as a table: row

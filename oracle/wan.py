@@ -140,11 +140,14 @@ def f8_operands(q, k, v):
 class _F8Attn(torch.autograd.Function):
     """softmax(q k^T / sqrt(d)) v as videogpa_amd computes it with enable_fp8(attention=True), roundings INJECTED into the oracle's own precision.
     forward (csrc/attention_hd128.hip attn128_fwd_f8_kernel, tools/gen_w1_asm.py::Fwd128F8Loop):
-      s = q8 k8^T (log2 units, exact products, wide accumulation);  M[i] = |q8 row i| max_j |k8 row j| * (1 + 2^-10) >= every score of the row (no running maximum);
+      s = q8 k8^T (log2 units, exact products, wide accumulation);  b[i] = |q8 row i| max_j |k8 row j| * (1 + 2^-10) >= every score of the row (no running maximum);
+      M[i] = b - floor(max(0, b - (m_s + 64))), m_s = the row's maximum over 64 keys spread evenly over the sweep (keys 0, L // 64, ...; sweeps of >= 128 keys) -- an
+      INTEGER step off the bound (round 6: rows far under their bound no longer underflow; the e4m3 bits of the weights do not depend on the step);
       p = exp2(s - M);  l = sum_j p (unquantised);  per 64-key tile and row: x = frexp-exponent(tile sum) - 8 (E8M0 floor 2^-126), P8 = e4m3(p / 2^x) 2^x;
       O = (sum_j P8 v8) / l;  lse2 = M + log2(l).
-    backward (vgpa_attn128_bwd on the DEquantised operands the forward saved -- q8 / c rounded to bf16, k8, v8 exactly -- so that its recomputed
-      P = exp2(c q' k8 - lse2) IS the forward's p / l and every row sums to one): dV = bf16(P)^T dO, dP = dO v8^T, delta = rowsum(dO o O) with O the forward's
+    backward (vgpa_attn128_bwd_prescaled on the DEquantised operands the forward saved, all three exact in bf16 -- q8 itself (the query pre-scaled by
+      c = d^-1/2 log2 e), k8, v8 -- so that its recomputed P = exp2(q8 k8 - lse2) IS the forward's p / l and every row sums to one; round 5 handed over
+      q8 / c rounded to bf16, whose 2^-9 per element tilts a score of +-100 log2 units by several per cent of a weight): dV = bf16(P)^T dO, dP = dO v8^T, delta = rowsum(dO o O) with O the forward's
       own output (unrounded when exact_delta: "Precise delta"), dS = bf16(P o (dP - delta)), dq = d^-1/2 dS k8, dk = d^-1/2 dS^T q' -- the straight-through
       gradient of the quantised forward.  What the injected model leaves between itself and the device: fp32 accumulation order, exp2 / log2 in fp32, and the
       independent realisation of the P8 / bf16 rounding noise.
@@ -161,6 +164,10 @@ class _F8Attn(torch.autograd.Function):
         qn = q8.pow(2).sum(-1, keepdim=True).sqrt()
         kmax = k8.pow(2).sum(-1).amax(dim=-1, keepdim=True).sqrt().unsqueeze(-1)
         M = qn * kmax * 1.0009765625
+        Lk = s.shape[-1]
+        if Lk >= 128:                                                            # W1H_SAMPLE_KEYS = 64, W1H_SAMPLE_UP = 64 (csrc/attention_hd128.hip)
+            ms = s[..., torch.arange(64, device=s.device) * (Lk // 64)].amax(dim=-1, keepdim=True)
+            M = M - torch.floor(torch.clamp(M - (ms + 64.0), min=0.0))
         p = torch.exp2(s - M)
         l = p.sum(-1, keepdim=True)
         Lk = p.shape[-1]
@@ -185,7 +192,7 @@ class _F8Attn(torch.autograd.Function):
             o[:, sl], lse2[:, sl] = _F8Attn._fwd_head(q8[:, sl], k8[:, sl], v8[:, sl], lq_norm)
         o_delta = o if exact_delta else o.bfloat16().to(o.dtype)
         if consistent:
-            ctx.save_for_backward((q8 / c).bfloat16().to(q.dtype), k8, v8, o_delta, lse2)
+            ctx.save_for_backward(q8 / c, k8, v8, o_delta, lse2)          # q8 / c UNrounded: the device keeps q8 and multiplies by 1 where this multiplies by c
         else:
             ctx.save_for_backward(q, k, v, o_delta, lse2)
         ctx.c = c

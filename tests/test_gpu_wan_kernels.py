@@ -175,13 +175,64 @@ def test_attention128_e4m3_forward_vs_fp64(B, H, Sq, Skv, qmul, vmean):
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
 
 
+@pytest.mark.parametrize("gain,expect", [(1.0, "none"), (2.5, "none"), (3.0, "few"), (4.0, "any")])
+def test_attention128_e4m3_forward_keeps_sharp_rows_on_the_e4m3_kernel(gain, expect):
+    """Round 6: the e4m3 forward's shift follows a sampled row maximum too (M' = bound - floor(bound - (sampled maximum + 64)): an integer step off the bound, so
+    the per-tile E8M0 of P moves with it and the P8 bits stay those of the bound-shifted model).  With RMS-normed q / k at a gain of 2.5 (what `bench.py --config cfg5
+    --weights trained_like` runs) every row lies > 100 log2 units under |q8| max|k8|: the bound-shifted kernel flagged EVERY strip and the launch took 14.3 ms instead
+    of 4.1 (profiles/r06_bench_cfg5_trained_like.json, before).  Asserted, against fp64 attention over the operands the kernel itself dequantised (so that only the
+    e4m3 rounding of the weights -- 2^-4 per weight, clamped at 448 -- and the matrix pipe's accumulation are left): lse2 (from the unquantised weights), output cosine
+    >= 0.999 and within 0.15 of the value range per element (a one-hot row carries its weight's rounding whole); the injected oracle model (oracle/wan.py::_F8Attn,
+    which restates the shift) as close; and the fraction of strips handed to the bf16 redo pass."""
+    from oracle import wan as ow
+    from videogpa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(int(gain * 10))
+    B, H, S = 1, 3, 2304
+
+    def rms(t):
+        return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6)
+    w = gain * (1 + 0.2 * torch.randn(H, 1, 128, device="cuda", generator=g))
+    w[..., :3] *= 3.0
+    q = (rms(torch.randn(B, H, S, 128, device="cuda", generator=g)) * w).bfloat16()
+    k = (rms(torch.randn(B, H, S, 128, device="cuda", generator=g)) * w).bfloat16()
+    # every query is matched to one key (cosine 0.6), as a trained attention row is: the row maximum stands far above the sampled keys
+    idx = torch.randperm(S, device="cuda", generator=g)
+    k = (0.8 * k.float() + 0.6 * q.float()[:, :, idx]).bfloat16()
+    v = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    scale = 128 ** -0.5
+    rep = {}
+    deq = tuple(torch.empty(B, S, H * 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=True, deq=deq, report=rep)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    qd, kd, vd = (t.unflatten(-1, (H, 128)).permute(0, 2, 1, 3).double() for t in deq)
+    s2 = qd @ kd.transpose(-1, -2)                                     # log2 units: q_deq is pre-scaled
+    r8 = torch.softmax(s2 * 0.6931471805599453, dim=-1) @ vd
+    l8 = torch.logsumexp(s2 * 0.6931471805599453, -1) / 0.6931471805599453
+
+    def cos(a, r):
+        a, r = a.double().flatten(), r.flatten()
+        return float(a @ r / (a.norm() * r.norm()))
+    # lse2: the scaled e4m3 MFMA sums each 64-term block (srcC = -M' included) with ~13 bits relative to the largest addend -- measured 2.7e-3 at |M'| ~ 25 (gain 1),
+    # 3.1e-2 at ~130 (gain 2.5): 2^-12 |M'|, the same with the bound as the shift (there |M| is larger still); stated as 1e-3 + 5e-4 max|lse2|
+    lerr = (lse.double() - l8).abs().max().item()
+    assert lerr <= 1e-3 + 5e-4 * l8.abs().max().item(), (lerr, l8.abs().max().item())
+    assert cos(o, r8) >= 0.999 and (o.double() - r8).abs().max().item() <= 0.15 * vd.abs().max().item(), (cos(o, r8), (o.double() - r8).abs().max().item())
+    model = ow._F8Attn.apply(q.double(), k.double(), v.double(), True, True)
+    assert cos(model, r8) >= 0.995 and cos(o, model) >= 0.995, (cos(model, r8), cos(o, model))      # the model quantises in fp64: ties fall differently on a few operands
+    f = rep["redo_fraction"]
+    # gain 4 at head_dim 128 is the cliff (the matched key stands > 164 log2 units above the 64 sampled ones in every strip: all redone in bf16, results as exact)
+    assert f == 0.0 if expect == "none" else (f <= 0.5 if expect == "few" else True), (gain, f)
+    print(f"e4m3 forward, gain {gain}: redo fraction {f:.4f}, lse2 error {lerr:.2e} at max|lse2| {l8.abs().max().item():.1f}, cos vs fp64 on its operands {cos(o, r8):.5f}, oracle model {cos(model, r8):.5f}")
+
+
 def test_attention128_e4m3_forward_hands_its_backward_the_operands_it_used():
     """the backward of the e4m3 forward is the straight-through gradient of THAT forward.  vgpa_attn128_fwd_f8 also writes the operands its
-    products ran on, dequantised to bf16 (deq); the bf16 backward kernels run on them.  (i) k_deq / v_deq equal the oracle's e4m3 operands bit for bit, q_deq
-    = bf16(q8 / c) to one bf16 ulp (oracle/wan.py f8_operands: the same power-of-two scales, round to nearest even); (ii) softmax weights recomputed from
-    (q_deq, k_deq) against the forward's lse2 sum to one within 8e-3 per row (the bf16 rounding of q8 / c tilts a row's scores by ~1e-3 along the keys' common
-    component; measured 1e-3 typical, 5e-3 worst of 7 800 rows) -- from the bf16 q, k they miss by several percent; (iii) dq / dk / dv of
-    vgpa_attn128_bwd on the dequantised operands follow the fp64 model of forward + backward (oracle/wan.py::_F8Attn): cosine >= 0.999, norm within 2 %."""
+    products ran on, dequantised to bf16 (deq) -- exactly: an e4m3 value times a power of two is a bf16 number; the bf16 backward kernels run on them.
+    (i) q_deq / k_deq / v_deq equal the oracle's e4m3 operands bit for bit (oracle/wan.py f8_operands: the same power-of-two scales, round to nearest even; q_deq is
+    the query PRE-SCALED by d^-1/2 log2 e); (ii) softmax weights recomputed from (q_deq, k_deq) against the forward's lse2 sum to one within 1e-4 per row (what is
+    left is fp32 accumulation and the fp32 log2 / exp2; round 5 handed over q8 / c rounded to bf16: 5e-3 worst here, tens of per cent on rows with scores of
+    hundreds of log2 units) -- from the bf16 q, k they miss by several percent; (iii) dq / dk / dv of vgpa_attn128_bwd_prescaled on the dequantised operands
+    follow the fp64 model of forward + backward (oracle/wan.py::_F8Attn): cosine >= 0.999, norm within 2 %."""
     from oracle import wan as ow
     from videogpa_amd import ops
     g = torch.Generator(device="cuda").manual_seed(91)
@@ -200,15 +251,15 @@ def test_attention128_e4m3_forward_hands_its_backward_the_operands_it_used():
     qd, kd, vd = (t.unflatten(-1, (H, 128)).permute(0, 2, 1, 3) for t in deq)
     q8, k8, v8, c = ow.f8_operands(q.double(), k.double(), v.double())
     assert torch.equal(kd.double(), k8) and torch.equal(vd.double(), v8)
-    want_q = (q8 / c).bfloat16().double()
-    assert ((qd.double() - want_q).abs() <= 2.0 ** -7 * want_q.abs() + 1e-30).all() and (qd.double() != want_q).double().mean().item() < 0.01
+    # q8 carries the fp32 product q * (scale log2 e) rounded to e4m3: a value that sits on a rounding boundary can land one e4m3 step off the fp64 oracle's
+    assert ((qd.double() - q8).abs() <= 2.0 ** -3 * q8.abs() + 1e-30).all() and (qd.double() != q8).double().mean().item() < 0.01
     LOG2E = 1.4426950408889634
-    rows_deq = torch.exp2((qd.double() @ kd.double().transpose(-1, -2)) * (scale * LOG2E) - lse.double()[..., None]).sum(-1)
+    rows_deq = torch.exp2(qd.double() @ kd.double().transpose(-1, -2) - lse.double()[..., None]).sum(-1)
     rows_bf16 = torch.exp2((q.double() @ k.double().transpose(-1, -2)) * (scale * LOG2E) - lse.double()[..., None]).sum(-1)
-    assert (rows_deq - 1).abs().max().item() <= 8e-3 and (rows_deq - 1).abs().mean().item() <= 1.5e-3, ((rows_deq - 1).abs().max().item(), (rows_deq - 1).abs().mean().item())
+    assert (rows_deq - 1).abs().max().item() <= 1e-4, ((rows_deq - 1).abs().max().item(), (rows_deq - 1).abs().mean().item())
     assert (rows_bf16 - 1).abs().max().item() > 5 * (rows_deq - 1).abs().max().item()
     dq, dk, dv = (torch.empty(B, S, H, 128, dtype=torch.bfloat16, device="cuda").permute(0, 2, 1, 3) for _ in range(3))
-    ops.attention128_bwd_raw(qd, kd, vd, o, do, lse, dq, dk, dv, scale, o_res8=o_res8)
+    ops.attention128_bwd_raw(qd, kd, vd, o, do, lse, dq, dk, dv, scale, o_res8=o_res8, q_prescaled=True)
     qr, kr, vr = (t.double().detach().requires_grad_(True) for t in (q, k, v))
     ow._F8Attn.apply(qr, kr, vr, True, True).backward(do.double())
     worst = {}
@@ -264,31 +315,39 @@ def test_attention128_many_queries_over_short_key_sweeps_vs_fp64(B, H, Sq, Skv):
 
 
 def test_attention128_e4m3_flagged_strips_are_redone_on_the_dequantised_operands():
-    """a strip the e4m3 kernel flags (here: one head whose keys carry a 40 x outlier, so that most rows lie > 100 log2 units below |q8| max|k8| and their
-    sums underflow) is recomputed by the bf16 running-max kernel; with deq buffers supplied that pass runs on the dequantised operands, so the recomputed softmax
-    rows of (q_deq, k_deq) against lse2 sum to one on the flagged rows like on all others, and the output there is the softmax of (q_deq, k_deq, v_deq)."""
+    """a strip the e4m3 kernel flags is recomputed by the bf16 running-max kernel; with deq buffers supplied that pass runs on the dequantised operands
+    (q_deq pre-scaled: c = 1 there), so the recomputed softmax rows of (q_deq, k_deq) against lse2 sum to one on the flagged rows like on all others, and the output
+    there is the softmax of (q_deq, k_deq, v_deq) to bf16 accuracy.  Since round 6 the shift follows a sampled row maximum, so a strip is flagged only when a row's
+    true maximum stands > 164 log2 units above the sampled one: here one head carries a 100 x key at a position the 64-key sample does not visit (scores of +-400
+    log2 units: every strip of that head has such rows).  Rows that stay on the e4m3 kernel are held to the e4m3 tolerance."""
     from videogpa_amd import ops
     g = torch.Generator(device="cuda").manual_seed(92)
     B, H, S = 1, 2, 1280
     tm = lambda t: t.bfloat16().permute(0, 2, 1, 3)
     q = tm(torch.randn(B, S, H, 128, device="cuda", generator=g))
     kk = torch.randn(B, S, H, 128, device="cuda", generator=g)
-    kk[:, 700, 1] *= 40.0                                    # head 1: one huge key
+    assert 707 % (S // 64) != 0
+    kk[:, 707, 1] *= 100.0                                   # head 1: one huge key the sample misses
     k = tm(kk)
     v = tm(torch.randn(B, S, H, 128, device="cuda", generator=g))
     scale = 128 ** -0.5
     deq = tuple(torch.full((B, S, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3))
-    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=True, deq=deq)
+    rep = {}
+    o, lse = ops.attention128_fwd_raw(q, k, v, scale, f8=True, deq=deq, report=rep)
+    flags = rep["strip_flags"]                               # [B, H, 5]
+    assert not flags[:, 0].any() and flags[:, 1].float().mean().item() >= 0.6, flags
     qd, kd, vd = (t.unflatten(-1, (H, 128)).permute(0, 2, 1, 3).double() for t in deq)
     LOG2E = 1.4426950408889634
-    s2 = (qd @ kd.transpose(-1, -2)) * (scale * LOG2E)
+    s2 = qd @ kd.transpose(-1, -2)                            # q_deq is pre-scaled by scale * log2 e
     rows = torch.exp2(s2 - lse.double()[..., None]).sum(-1)
     assert torch.isfinite(o).all() and torch.isfinite(lse).all()
-    assert (rows[:, 1] - 1).abs().max().item() <= 8e-3, (rows[:, 1] - 1).abs().max().item()        # the head with the outlier: redone rows included
-    assert (rows[:, 0] - 1).abs().max().item() <= 8e-3
+    assert (rows - 1).abs().max().item() <= 2e-3, (rows - 1).abs().max().item()        # redone rows (bf16 kernel on the exact operands) and e4m3 rows alike
     ref = torch.softmax(s2 / LOG2E, dim=-1) @ vd
     got = o.double()                                       # attention128_fwd_raw returns the [B,H,S,128] view of its token-major storage
-    assert ((got - ref).abs() <= 0.03 + 0.03 * ref.abs()).all(), (got - ref).abs().max().item()
+    redone = flags.repeat_interleave(256, dim=-1)[..., :S]                                          # [B, H, S]
+    err = (got - ref).abs()
+    assert (err[redone] <= 0.03 + 0.03 * ref[redone].abs()).all(), err[redone].max().item()         # bf16 accuracy where the bf16 kernel ran
+    assert (err[~redone] <= 0.08 * ref.abs().max()).all(), err[~redone].max().item()                # e4m3 weights elsewhere
 
 
 @pytest.mark.parametrize("gap,f8", [(126.5, False), (104.0, False), (90.0, False), (126.5, True)])
@@ -328,8 +387,11 @@ def test_attention128_row_between_overflow_of_o_and_overflow_of_l(gap, f8):
 
 
 def test_attention128_e4m3_outlier_rows_and_short_sweeps():
-    """a 40x query row (bound above 160 -> strip flagged, redone in bf16), a 40x key row (every bound loose), and a 512-key sweep (below
-    ATTN128_F8_MIN_KEYS: the bf16 kernels serve it -- the Wan2.2 cross-attention over the text tokens)"""
+    """a 40x query row, a 40x key row, and a 512-key sweep (below ATTN128_F8_MIN_KEYS: the bf16 kernels serve it -- the Wan2.2 cross-attention over the text
+    tokens).  Until round 6 both outlier cases ended in the bf16 redo pass (the shift was the row bound, and a 40x key makes every bound loose); with the sampled
+    shift they stay on the e4m3 kernel, and the 40x key shows what e4m3 SCORES cost there: the score error grows with |q| |k| (two e4m3 roundings over 128
+    terms: ~2 log2 units against that key), so rows whose weight on it is marginal come out differently -- cosine 0.993 against plain fp64 attention where the
+    diffuse case holds 0.995 (the accuracy of the e4m3 forward scales with the score range)."""
     from videogpa_amd import ops
     g = torch.Generator(device="cuda").manual_seed(78)
     B, H, Sq, Skv = 1, 2, 600, 1200
@@ -346,7 +408,7 @@ def test_attention128_e4m3_outlier_rows_and_short_sweeps():
         ro = torch.softmax((q.double() @ k.double().transpose(-1, -2)) * scale, dim=-1) @ v.double()
         assert torch.isfinite(o).all()
         a, r = o.double().flatten(), ro.flatten()
-        assert float(a @ r / (a.norm() * r.norm())) >= 0.995, which
+        assert float(a @ r / (a.norm() * r.norm())) >= (0.995 if which == "q" else 0.99), which
     q = torch.randn(1, 2, 300, 128, device="cuda", generator=g).bfloat16()
     k, v = (torch.randn(1, 2, 512, 128, device="cuda", generator=g).bfloat16() for _ in range(2))
     o8, l8 = ops.attention128_fwd_raw(q, k, v, scale, f8=True)

@@ -190,7 +190,7 @@ def test_wan_oracle_e4m3_attention_model_known_answers():
     """oracle/wan.py::f8_operands / _F8Attn, the restatement of csrc/attention_hd128.hip's e4m3 forward and of the backward that follows it:
     (i) the dequantised operands lie on the e4m3 grid of their per-head power-of-two scale, within 2^-4 of the inputs, the largest at 224..448 scale units;
     (ii) the forward is softmax attention over THOSE operands up to the e4m3 rounding of the weights (cos >= 0.999 against it, >= 0.995 against plain attention);
-    (iii) the consistent backward's recomputed weights exp2(c q' k8 - lse2) sum to one per row (1e-2: q' = bf16(q8 / c)), the round-4 form's do not;
+    (iii) the consistent backward's recomputed weights exp2(q8 k8 - lse2) sum to one per row (the operands are exact: 1e-9), the round-4 form's do not;
     (iv) with a value tensor that is constant along the keys the true dq, dk vanish (rows of dS sum to zero): the consistent backward is >= 3x closer to that
         than the round-4 form (what is left is the e4m3 rounding of the weights: sum_j Q(p_ij) / l is 1 only to ~2^-4 / sqrt(keys))."""
     from oracle import wan as ow
@@ -212,10 +212,10 @@ def test_wan_oracle_e4m3_attention_model_known_answers():
     assert cos(o, p8 @ v8) >= 0.999
     assert cos(o, torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v) >= 0.995
     lse2 = torch.logsumexp(q8 @ k8.transpose(-1, -2) * math.log(2.0), dim=-1, keepdim=True) / math.log(2.0)
-    qd = (q8 / c).bfloat16().double()
-    rows = torch.exp2((qd @ k8.transpose(-1, -2)) * c - lse2).sum(-1)
+    assert torch.equal(q8.bfloat16().double(), q8)                       # the pre-scaled query is a bf16 number: the device hands it to its backward as is
+    rows = torch.exp2(q8 @ k8.transpose(-1, -2) - lse2).sum(-1)
     rows_r4 = torch.exp2((q @ k.transpose(-1, -2)) * c - lse2).sum(-1)
-    assert (rows - 1).abs().max().item() <= 1e-2 < (rows_r4 - 1).abs().max().item()
+    assert (rows - 1).abs().max().item() <= 1e-9 and 1e-2 < (rows_r4 - 1).abs().max().item()
     vc = torch.randn(B, n, 1, d, generator=g, dtype=torch.float64).bfloat16().double().expand(B, n, L, d).contiguous()
     do = torch.randn(B, n, L, d, generator=g, dtype=torch.float64)
     res = {}

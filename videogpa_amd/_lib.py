@@ -68,6 +68,7 @@ SIGNATURES = {
     "vgpa_attn128_fwd_f8": (I32, [P] * 17 + [I64, I64, I64, I64, F32, P, SZ, P]),
     "vgpa_attn128_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
     "vgpa_attn128_bwd": (I32, [P] * 19 + [I64, I64, I64, I64, F32, I32, P, SZ, P]),
+    "vgpa_attn128_bwd_prescaled": (I32, [P] * 19 + [I64, I64, I64, I64, F32, I32, P, SZ, P]),
     "vgpa_wan_ln_mod_fwd": (I32, [P, I32, P, P, P, P, P, I64, I64, I64, F32, I32, P, I64, P, P, P, P, P]),
     "vgpa_wan_ln_mod_bwd": (I32, [P, P, I32, P, P, P, P, P, I64, I64, I64, P, P, P]),
     "vgpa_wan_ln_mod_fwd_f32": (I32, [P, P, P, P, I64, I64, I64, F32, P, P, P, P]),

@@ -1069,12 +1069,13 @@ __global__ __launch_bounds__(256) void attn128_f8_quant_kernel(const bf16_t* __r
             w[2 * g] = f8_pack4(f[0] * mul, f[1] * mul, f[2] * mul, f[3] * mul);
             w[2 * g + 1] = f8_pack4(f[4] * mul, f[5] * mul, f[6] * mul, f[7] * mul);
         }
-        // the operands the matrix pipe will multiply, DEquantised to bf16 for the backward (vgpa_attn128_fwd_f8, q_deq / k_deq / v_deq): k8 2^ek and
-        // v8 2^ev exactly (an e4m3 value times a power of two is a bf16 number), q8 2^eq / c rounded to bf16
+        // the operands the matrix pipe will multiply, DEquantised to bf16 for the backward (vgpa_attn128_fwd_f8, q_deq / k_deq / v_deq): an e4m3 value times a
+        // power of two IS a bf16 number, so all three are exact -- q_deq = q8 2^eq is q PRE-SCALED by c = scale log2(e) (round 5 wrote q8 2^eq / c, rounded to
+        // bf16: a 2^-9 relative error per element that moves a score of +-100 log2 units by several per cent of a weight; vgpa_attn128_bwd_prescaled takes it as is)
         bf16_t* dq_base = which == 0 ? QD : which == 1 ? KD : VD;
         if (dq_base && tok < S) {
             const TStride sd = which == 0 ? sqd : which == 1 ? skd : svd;
-            const float inv = which == 0 ? ldexpf(1.f / c, eq) : ldexpf(1.f, which == 1 ? ek : ev);
+            const float inv = ldexpf(1.f, which == 0 ? eq : which == 1 ? ek : ev);
             bf16_t* dst = dq_base + ((size_t)b * sd.b + (size_t)h * sd.h + (size_t)tok * sd.s + (size_t)d0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -1171,7 +1172,44 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_f8_kernel(const uint8_t* _
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int u = 0; u < 2; ++u) qf[j][ks][u] = *reinterpret_cast<const u32x4_t*>(row + 64 * ks + 32 * u + 16 * hi);
-        nm[j] = -(sqrtf(QN2[(size_t)bh * Sq + q]) * kmax * 1.0009765625f);      // -M[q]: a hair above |q8 row| max |k8 row| >= every score of the row
+        nm[j] = -(sqrtf(QN2[(size_t)bh * Sq + q]) * kmax * 1.0009765625f);      // -b[q]: a hair above |q8 row| max |k8 row| >= every score of the row
+    }
+    if (Skv >= 2 * W1H_SAMPLE_KEYS) {
+        // Round 6: the shift follows the data here too (attention_w1.hip W1_SAMPLE_UP).  M'[q] = b[q] - n, n = floor(max(0, b - (m_s + 64))) with m_s the row's maximum over
+        // 64 keys spread evenly over the sweep (8 scaled MFMAs per wave on the e4m3 operands themselves).  n is an INTEGER: every p = exp2(s - M') is the bound-shifted
+        // p times 2^n exactly, the per-tile exponent x moves by n with it, so P8 = e4m3(p / 2^x) keeps the bits oracle/wan.py::_F8Attn models -- except that rows whose
+        // scores lie > 100 log2 units under the bound (QK-norm gains >= 2.5: every strip) no longer underflow into the redo pass (measured 14.3 ms per launch there
+        // against 4.1: profiles/r06_bench_cfg5_trained_like.json).  Flags as in the bf16 kernels: l outside [2^-100, 2^100), M' > 1024, a non-finite accumulator.
+        typedef int v8i_t __attribute__((ext_vector_type(8)));
+        const uint32_t step = (uint32_t)Skv / W1H_SAMPLE_KEYS;
+        const int sa = 127 + ek, sb = 127 + eq;
+        float ms[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int kb = 0; kb < W1H_SAMPLE_KEYS / 32; ++kb) {
+            const uint8_t* krow = K8 + ((size_t)bh * Skv + (size_t)(32 * kb + m) * step) * 128;
+            u32x4_t kf[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) kf[ks][u] = *reinterpret_cast<const u32x4_t*>(krow + 64 * ks + 32 * u + 16 * hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const v8i_t a = {(int)kf[ks][0][0], (int)kf[ks][0][1], (int)kf[ks][0][2], (int)kf[ks][0][3], (int)kf[ks][1][0], (int)kf[ks][1][1], (int)kf[ks][1][2], (int)kf[ks][1][3]};
+                    const v8i_t bq = {(int)qf[j][ks][0][0], (int)qf[j][ks][0][1], (int)qf[j][ks][0][2], (int)qf[j][ks][0][3],
+                                      (int)qf[j][ks][1][0], (int)qf[j][ks][1][1], (int)qf[j][ks][1][2], (int)qf[j][ks][1][3]};
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq, acc, 0, 0, 0, sa, 0, sb);      // S^T[key][q] in log2 units: this lane holds 16 keys of column q = m
+                }
+                float mx = acc[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[i]);
+                ms[j] = fmaxf(ms[j], fmaxf(mx, other_half(mx)));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) nm[j] += floorf(fmaxf(0.f, -nm[j] - (ms[j] + W1H_SAMPLE_UP)));      // -M' = -b + n
     }
     {   // C of the first two iterations reads the V8^T halves of ring slots 2 and 3: make them finite (P8 = 0 there)
         const u32x4_t z = {0u, 0u, 0u, 0u};
@@ -1322,7 +1360,7 @@ extern "C" int32_t vgpa_attn128_fwd_f8(const void* q, const void* k, const void*
     // recomputed P = exp2(c q_deq k_deq - lse2) summing to 1 +- several %: ADVICE r5)
     VGPA_LAUNCH(attn128_fwd_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, (const bf16_t*)(deq ? q_deq : q), (const bf16_t*)(deq ? k_deq : k),
                 (const bf16_t*)(deq ? v_deq : v), (bf16_t*)o, lse2, deq ? sqd : mk128(q_strides), deq ? skd : mk128(k_strides), deq ? svd : mk128(v_strides),
-                mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, (const int*)flags, ores, sor);
+                mk128(o_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, deq ? 1.f : c, (const int*)flags, ores, sor);      // q_deq carries c already
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
 }
@@ -1340,11 +1378,12 @@ extern "C" size_t vgpa_attn128_bwd_workspace_bytes(int64_t B, int64_t H, int64_t
 }
 
 // dkv_mode: 0 = the compiler-scheduled dQ and dK/dV kernels, 1 = the w1 kernels, -1 = automatic (w1 dK/dV from 1024 queries on, w1 dQ from 1024 keys on)
-extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
-                                    void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
-                                    const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
-                                    const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
-                                    float scale, int32_t dkv_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+// c: log2-domain multiplier of q.k in the score chains; dq_mul / dk_mul: what dS k and dS^T q are multiplied by on the way out
+static int32_t attn128_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
+                                void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                                const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
+                                float c, float dq_mul, float dk_mul, int32_t dkv_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
     if (!q || !k || !v || !o || !d_o || !lse2 || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || !res8_ok(o_res8, ores_strides, B, H, Sq))
         return VGPA_ERR_INVALID;
     const int64_t* qs[] = {q_strides, o_strides, do_strides, dq_strides};
@@ -1356,7 +1395,6 @@ extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v,
     const int64_t n_qt = (Sq + 127) / 128, n_kt = (Skv + 127) / 128, total = B * H * Sq;
     if (B * H * n_qt >= ((int64_t)1 << 31) || B * H * n_kt >= ((int64_t)1 << 31) || total * 16 >= ((int64_t)1 << 39) || 2 * Sq * 4 >= ((int64_t)1 << 31))
         return VGPA_ERR_INVALID;
-    const float c = scale * LOG2E_F;
     float* delta = (float*)workspace;
     float* stats = delta + total;
     const bool w1 = dkv_mode == 1 || (dkv_mode < 0 && Sq >= attn128_min_sweep());
@@ -1368,23 +1406,44 @@ extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v,
         const int64_t n_q256 = (Sq + 255) / 256;
         VGPA_LAUNCH(attn128_dq_w1x2_kernel, dim3((unsigned)(B * H * n_q256)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                     (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
-                    mk128(dq_strides), (int)Sq, (int)Skv, (int)H, (int)n_q256, c, scale);
+                    mk128(dq_strides), (int)Sq, (int)Skv, (int)H, (int)n_q256, c, dq_mul);
     } else if (w1q)
         VGPA_LAUNCH(attn128_dq_w1_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                     (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
-                    mk128(dq_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, scale);
+                    mk128(dq_strides), (int)Sq, (int)Skv, (int)H, (int)n_qt, c, dq_mul);
     else
         VGPA_LAUNCH(attn128_dq_kernel, dim3((unsigned)(B * H * n_qt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
                     lse2, (const float*)delta, (bf16_t*)dq, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides), mk128(dq_strides), (int)Sq,
-                    (int)Skv, (int)H, (int)n_qt, c, scale);
+                    (int)Skv, (int)H, (int)n_qt, c, dq_mul);
     if (w1)
         VGPA_LAUNCH(attn128_dkv_w1_kernel, dim3((unsigned)(B * H * n_kt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                     (const bf16_t*)d_o, (const float*)stats, (bf16_t*)dk, (bf16_t*)dv, mk128(q_strides), mk128(k_strides), mk128(v_strides), mk128(do_strides),
-                    mk128(dk_strides), mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, scale);
+                    mk128(dk_strides), mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, dk_mul);
     else
         VGPA_LAUNCH(attn128_dkv_kernel, dim3((unsigned)(B * H * n_kt)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                     (const bf16_t*)d_o, lse2, (const float*)delta, (bf16_t*)dk, (bf16_t*)dv, mk128(q_strides), mk128(k_strides), mk128(v_strides),
-                    mk128(do_strides), mk128(dk_strides), mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, scale);
+                    mk128(do_strides), mk128(dk_strides), mk128(dv_strides), (int)Sq, (int)Skv, (int)H, (int)n_kt, c, dk_mul);
     VGPA_CHECK_LAUNCH();
     return VGPA_OK;
+}
+
+extern "C" int32_t vgpa_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
+                                    void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                    const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                                    const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
+                                    float scale, int32_t dkv_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    return attn128_bwd_impl(q, k, v, o, d_o, lse2, dq, dk, dv, q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides, o_res8,
+                            ores_strides, B, H, Sq, Skv, scale * LOG2E_F, scale, scale, dkv_mode, workspace, ws_bytes, stream);
+}
+
+// The backward of vgpa_attn128_fwd_f8 over ITS operands: q = that call's q_deq = q8 2^eq, i.e. the query PRE-SCALED by scale log2(e) (exact in bf16), k = k_deq,
+// v = v_deq.  Scores are q.k as they stand (log2 units: bit for bit the forward's, so P = exp2(q.k - lse2) is the forward's p / l); with q'' = scale log2(e) q the
+// straight-through gradients are dq = scale dS k (unchanged) and dk = ln 2 dS^T q'' (= scale dS^T q).
+extern "C" int32_t vgpa_attn128_bwd_prescaled(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2, void* dq, void* dk,
+                                              void* dv, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                              const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                                              const int64_t* dv_strides, const void* o_res8, const int64_t* ores_strides, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
+                                              float scale, int32_t dkv_mode, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    return attn128_bwd_impl(q, k, v, o, d_o, lse2, dq, dk, dv, q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides, o_res8,
+                            ores_strides, B, H, Sq, Skv, 1.f, scale, 0.6931471805599453f, dkv_mode, workspace, ws_bytes, stream);
 }

@@ -1098,12 +1098,22 @@ def attention128_uses_f8(f8, Skv):
     return bool(f8) and Skv >= ATTN128_F8_MIN_KEYS
 
 
-def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None, deq=None):
+def attention128_f8_redo_fraction(ws, B, H, Sq):
+    """fraction of the (batch, head, 256-row strip) tasks the last vgpa_attn128_fwd_f8 call on workspace `ws` flagged and redid in bf16 (synchronises)"""
+    tasks = B * H * ((Sq + 255) // 256)
+    flags = ws[:4 * (5 * B * H + tasks)].view(torch.int32)[5 * B * H:]
+    return float((flags != 0).float().mean())
+
+
+def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None, deq=None, report=None):
     """q [B,H,Sq,128], k / v [B,H,Skv,128] bf16 views (any batch / head / token strides, last dim contiguous) -> (o, lse2 [B,H,Sq] fp32).
     f8: the e4m3 forward (csrc/attention_hd128.hip, vgpa_attn128_fwd_f8) for sweeps of at least ATTN128_F8_MIN_KEYS keys.
     deq (e4m3 forward only): three bf16 buffers [B, Sq, H*128], [B, Skv, H*128], [B, Skv, H*128] that receive the operands the e4m3 products really ran
-    on, dequantised -- what the backward of THIS forward runs on (attention128_bwd_raw on them recomputes the forward's own softmax weights).
+    on, dequantised EXACTLY (q: times scale * log2 e) -- what the backward of THIS forward runs on (attention128_bwd_raw(..., q_prescaled=True) on them recomputes
+    the forward's own scores bit for bit).
     o_res8: optional uint8 [B, Sq, H*128] buffer that receives eight further mantissa bits of every output value ("Precise delta").
+    report: optional dict; the e4m3 forward stores "redo_fraction" (strips it flagged and redid in bf16) and "strip_flags" (bool [B, H, strips of 256 rows])
+    there -- one host sync.
     o is a [B,H,Sq,128] view of token-major storage [B, Sq, H*128 (+ o_pad)]: the caller's flatten to [B*Sq, H*128] is free, and with
     o_pad it is the head of a `_padded_empty` buffer (the output projection's LoRA tail, see LoraExt)."""
     B, H, Sq, D = q.shape
@@ -1131,6 +1141,9 @@ def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None, deq=Non
         _timed("attn128_fwd_f8", 4.0 * B * H * Sq * Skv * D, lambda: _lib.call(
             "vgpa_attn128_fwd_f8", q, k, v, o, lse, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), rv, rs, dv_[0], dv_[1], dv_[2],
             ds_[0], ds_[1], ds_[2], B, H, Sq, Skv, float(scale), ws, ws_bytes, _stream()))
+        if report is not None:          # tools / tests: what fraction of the strips the e4m3 kernel handed to the bf16 redo pass
+            report["redo_fraction"] = attention128_f8_redo_fraction(ws, B, H, Sq)
+            report["strip_flags"] = (ws[:4 * (5 * B * H + B * H * ((Sq + 255) // 256))].view(torch.int32)[5 * B * H:] != 0).view(B, H, -1).clone()
         return o, lse
     if deq is not None:
         raise ValueError("attention128_fwd_raw: deq buffers are written by the e4m3 forward only (f8=True and at least ATTN128_F8_MIN_KEYS keys)")
@@ -1142,9 +1155,11 @@ def attention128_fwd_raw(q, k, v, scale, o_pad=0, f8=False, o_res8=None, deq=Non
     return o, lse
 
 
-def attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, o_res8=None):
+def attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, o_res8=None, q_prescaled=False):
     """all [B,H,S,128] bf16 views; writes dq, dk, dv in place (they may be strided slices of a fused gradient buffer).  o_res8 (uint8 [B, Sq, H*128], as the
-    forward wrote it): delta = rowsum(dO o O) is formed from the output completed by those eight further mantissa bits ("Precise delta")."""
+    forward wrote it): delta = rowsum(dO o O) is formed from the output completed by those eight further mantissa bits ("Precise delta").
+    q_prescaled: q is the e4m3 forward's q_deq (the query times scale * log2 e, exact): vgpa_attn128_bwd_prescaled -- scores bit for bit the forward's, dq still
+    the gradient w.r.t. the unscaled query."""
     B, H, Sq, D = q.shape
     Skv = k.shape[2]
     rv = None if o_res8 is None else o_res8.unflatten(-1, (H, D)).permute(0, 2, 1, 3)
@@ -1152,7 +1167,7 @@ def attention128_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, o_res8=None):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
     # algorithmic work as SURVEY 8d counts it: backward = 2 x forward (dV, dP, dK, dQ); the S = QK^T recomputes of the split kernels are overhead
     _timed("attn128_bwd" if Skv >= 1024 else "attn128_bwd (short keys)", 8.0 * B * H * Sq * Skv * D, lambda: _lib.call(
-        "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
+        "vgpa_attn128_bwd_prescaled" if q_prescaled else "vgpa_attn128_bwd", q, k, v, o, do, lse, dq, dk, dv, _bhs_strides(q), _bhs_strides(k), _bhs_strides(v), _bhs_strides(o), _bhs_strides(do),
         _bhs_strides(dq), _bhs_strides(dk), _bhs_strides(dv), rv, None if rv is None else _bhs_strides(rv), B, H, Sq, Skv, float(scale),
         -1 if ATTN128_W1 else 0, ws, ws_bytes, _stream()))
 

@@ -296,7 +296,9 @@ class _SelfAttnFn(torch.autograd.Function):
         dqn = torch.empty(B, L, D, dtype=torch.bfloat16, device=q2.device)
         dkn = torch.empty_like(dqn)
         v = heads(q2.view(B, L, W)[:, :, 2 * D:]) if vd is None else heads(vd)
-        ops.attention128_bwd_raw(heads(qn), heads(kn), v, o, heads(do), lse, heads(dqn), heads(dkn), heads(dqkv[:, :, 2 * D:]), hd ** -0.5, o_res8=o_res8)
+        # vd is not None: (qn, kn, vd) are the e4m3 forward's own operands, qn pre-scaled by hd^-1/2 log2(e) (exact): the prescaled backward recomputes its scores bit for bit
+        ops.attention128_bwd_raw(heads(qn), heads(kn), v, o, heads(do), lse, heads(dqn), heads(dkn), heads(dqkv[:, :, 2 * D:]), hd ** -0.5, o_res8=o_res8,
+                                 q_prescaled=vd is not None)
         d2 = dqkv.view(B * L, W)
         _rms_rope_bwd_raw(dqn, D, q2[:, :D], q2.stride(0), rq, wq, cos, sin, L, hd, d2[:, :D], d2.stride(0))
         _rms_rope_bwd_raw(dkn, D, q2[:, D:2 * D], q2.stride(0), rk, wk, cos, sin, L, hd, d2[:, D:2 * D], d2.stride(0))
