@@ -261,7 +261,7 @@ int32_t vgpa_attn128_fwd(const void* q, const void* k, const void* v, void* o, f
  * Arguments and results as vgpa_attn128_fwd; the workspace (>= vgpa_attn128_fwd_f8_workspace_bytes, 256-byte aligned) is REQUIRED and is scratch.
  * The softmax shift of a row is M' = b - n, b = |q8 row| max|k8 row| and n = floor(max(0, b - (m_s + 64))) with m_s the row's maximum over 64 keys spread evenly
  * over the sweep (as vgpa_attn_fwd_w1; an INTEGER step off the bound, so the e4m3 bits of the weights do not depend on it); 256-row strips with a row it cannot
- * represent (row sum outside [2^-100, 2^100), M' > 1024, a non-finite accumulator) are redone by the bf16 running-max kernel inside the call.
+ * represent (row sum outside [2^-100, 2^118), M' > 1024, a non-finite accumulator) are redone by the bf16 running-max kernel inside the call.
  * Forward only.  q_deq / k_deq / v_deq (optional, all three or none; bf16 [B,H,S,128] views with their stride triples): the operands the products really ran
  * on, dequantised EXACTLY (an e4m3 value times a power of two is a bf16 number): k8 2^ek, v8 2^ev and q8 2^eq -- the query PRE-SCALED by scale * log2 e.
  * vgpa_attn128_bwd_prescaled run on THEM with this call's lse2, output and o_res8 is the straight-through gradient of this forward: its recomputed scores are

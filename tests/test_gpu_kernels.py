@@ -407,7 +407,7 @@ def test_attention_extreme_outliers_strip_redo(ops, S):
 def test_attention_row_between_overflow_of_o_and_overflow_of_l(ops, S, gap, split):
     """Round 6, found by `bench.py --weights trained_like` (tools/attn_fault_repro.py: one row of block 38 of the cfg2 model at QK-norm gain 2.5): the w1 forward
     shifts a row by M' = min(bound, sampled maximum + 64).  A key the sample missed whose score lies `gap` = 100-128 log2 units above M' gives a weight 2^gap: the
-    row SUM stays finite (2^gap < 2^128), the O accumulators do not (2^gap |v| overflows) -- a strip must be flagged on the size of l (>= 2^100) and on the
+    row SUM stays finite (2^gap < 2^128), the O accumulators do not (2^gap |v| overflows) -- a strip must be flagged on the size of l (>= 2^118) and on the
     accumulators themselves, not only on l = inf.  gap 90 stays on the fast path and has to be right there."""
     g = torch.Generator().manual_seed(S + int(gap))
     B, H = 1, 2

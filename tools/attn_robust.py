@@ -22,6 +22,8 @@ ap.add_argument("--S", type=int, default=17776)
 ap.add_argument("--B", type=int, default=2)
 ap.add_argument("--H", type=int, default=48)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--S128", type=int, default=18480, help="tokens of the head_dim-128 section (cfg5: 21 x 22 x 40)")
+ap.add_argument("--no-hd128", action="store_true")
 ap.add_argument("--json", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "attn_trained_like.json"))
 a = ap.parse_args()
 B, H, S = a.B, a.H, a.S
@@ -69,6 +71,41 @@ for st in settings:
           f"[bound {stats['bound_log2_mean']:6.1f} log2, gap {stats['gap_bound_minus_rowmax_mean']:6.1f} (max {stats['gap_bound_minus_rowmax_max']:6.1f}), "
           f"row entropy {stats['row_entropy_bits_mean']:5.2f} of {stats['uniform_entropy_bits']:4.1f} bits]", flush=True)
     del q, k, v
+
+# ---- head_dim 128 at the cfg5 self-attention shape (Wan2.2-TI2V-5B: 2 samples x 24 heads x 18 480 tokens): the bf16 w1 forward and the e4m3 forward, both on the
+# sampled shift since round 6.  RMS-normed operands (no mean removal, no bias) with the same gain structure; the e4m3 call reports its redone-strip fraction.
+rows128 = []
+if not a.no_hd128:
+    B2, H2, S2 = 2, 24, a.S128
+
+    def time128(q, k, v, f8):
+        rep = {}
+        ops.attention128_fwd_raw(q, k, v, 128 ** -0.5, f8=f8, report=rep if f8 else None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            ops.attention128_fwd_raw(q, k, v, 128 ** -0.5, f8=f8)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.iters, rep.get("redo_fraction")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q0, k0, v0 = (torch.randn(B2, H2, S2, 128, generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
+    b16, _ = time128(q0, k0, v0, False)
+    b8, f8r = time128(q0, k0, v0, True)
+    rows128.append({"data": "randn", "bf16_ms": b16, "e4m3_ms": b8, "e4m3_redo_fraction": f8r})
+    print(f"head_dim 128  randn                          bf16 {b16:7.3f} ms   e4m3 {b8:7.3f} ms  redo {f8r:6.3f}")
+    del q0, k0, v0
+    for st in (dict(gain=1.0), dict(gain=2.0), dict(gain=2.5), dict(gain=3.0), dict(gain=4.0), dict(gain=1.0, sink_norm=10.0)):
+        q, k, v, stats = trained_like_qkv(B2, H2, S2, d=128, **st)
+        t16, _ = time128(q, k, v, False)
+        t8, fr = time128(q, k, v, True)
+        row = dict(data="trained_like " + " ".join(f"{k_}={v_}" for k_, v_ in st.items()), **stats, bf16_ms=t16, e4m3_ms=t8, e4m3_redo_fraction=fr, bf16_over_randn=t16 / b16, e4m3_over_randn=t8 / b8)
+        rows128.append(row)
+        print(f"head_dim 128  {row['data']:30s} bf16 {t16:7.3f} ms = x{t16 / b16:5.3f}   e4m3 {t8:7.3f} ms = x{t8 / b8:5.3f}  redo {fr:6.3f}   "
+              f"[bound {stats['bound_log2_mean']:6.1f} log2, gap {stats['gap_bound_minus_rowmax_mean']:6.1f}, row entropy {stats['row_entropy_bits_mean']:5.2f} bits]", flush=True)
+        del q, k, v
 os.makedirs(os.path.dirname(a.json), exist_ok=True)
 with open(a.json, "w") as f:
-    json.dump({"shape": {"B": B, "H": H, "S": S, "head_dim": 64}, "switch_threshold": ops.AttnFwdPolicy.SWITCH, "rows": rows}, f, indent=1)
+    json.dump({"shape": {"B": B, "H": H, "S": S, "head_dim": 64}, "switch_threshold": ops.AttnFwdPolicy.SWITCH, "rows": rows,
+               "head_dim_128": {"shape": {"B": 2, "H": 24, "S": a.S128}, "rows": rows128}}, f, indent=1)

@@ -219,7 +219,7 @@ typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
 #define W1H_SLOT_BYTES 32768
 #define W1H_RING_BYTES (4 * W1H_SLOT_BYTES)
 #define W1H_L_MIN 7.888609052210118e-31f   // 2^-100
-#define W1H_L_MAX 1.2676506e30f            // 2^100: as W1_L_MAX (attention_w1.hip) -- a finite row sum next to overflowed O accumulators must flag the strip too
+#define W1H_L_MAX 3.3230699e35f            // 2^118: as W1_L_MAX (attention_w1.hip) -- a finite row sum next to overflowed O accumulators must flag the strip too
 #define W1H_M_MAX 1024.0f      // as W1_M_MAX (attention_w1.hip): the fp32 accumulator's ulp at |M'| = 1024 is a fiftieth of the weight's bf16 rounding
 #define W1H_SAMPLE_KEYS 64     // as W1_SAMPLE_KEYS / W1_SAMPLE_UP (attention_w1.hip): the shift follows a sampled lower bound of the row maximum
 #define W1H_SAMPLE_UP 64.0f
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256, 1) void attn128_fwd_f8_kernel(const uint8_t* _
         // 64 keys spread evenly over the sweep (8 scaled MFMAs per wave on the e4m3 operands themselves).  n is an INTEGER: every p = exp2(s - M') is the bound-shifted
         // p times 2^n exactly, the per-tile exponent x moves by n with it, so P8 = e4m3(p / 2^x) keeps the bits oracle/wan.py::_F8Attn models -- except that rows whose
         // scores lie > 100 log2 units under the bound (QK-norm gains >= 2.5: every strip) no longer underflow into the redo pass (measured 14.3 ms per launch there
-        // against 4.1: profiles/r06_bench_cfg5_trained_like.json).  Flags as in the bf16 kernels: l outside [2^-100, 2^100), M' > 1024, a non-finite accumulator.
+        // against 4.1: profiles/r06_bench_cfg5_trained_like.json).  Flags as in the bf16 kernels: l outside [2^-100, 2^118), M' > 1024, a non-finite accumulator.
         typedef int v8i_t __attribute__((ext_vector_type(8)));
         const uint32_t step = (uint32_t)Skv / W1H_SAMPLE_KEYS;
         const int sa = 127 + ek, sb = 127 + eq;

@@ -169,10 +169,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w1_kernel(const bf16_t* __
 #include "w1_fwd_knobs.inc"                   // W1_FWD_MFSUM: what the generated loop expects around it (tools/gen_w1_asm.py W1_KNOBS; 0 in the product)
 #define W1_FWD_PART_FLOATS (256 * (HD + 2))   // per (task, chunk): O[256][64] (un-normalised), M[256], l[256] -- layout of attention.hip's split forward
 #define W1_L_MIN 7.8886e-31f                  // 2^-100: below this the row's sum is too close to underflow -> redo
-// ... and above 2^100 too close to overflow: the O accumulators carry sum_j p_j v_j <= l max|v| (a row whose true maximum lies 112-128 above the shift has a FINITE
+// ... and above 2^118 too close to overflow: the O accumulators carry sum_j p_j v_j <= l max|v| (a row whose true maximum lies 112-128 above the shift has a FINITE
 // l next to O = +-inf, and 1 / l flushes to zero from 2^126 on).  Found by `bench.py --weights trained_like` (one row of block 38, true maximum 127.7 above M':
-// l = 2^127.7, O = inf, strip not flagged -> NaN loss; tools/attn_fault_repro.py).  The epilogue also checks the accumulators themselves (w1_sum_abs): |v| is the caller's.
-#define W1_L_MAX 1.2676506e30f                // 2^100
+// l = 2^127.7, O = inf, strip not flagged -> NaN loss; tools/attn_fault_repro.py).  2^118 leaves |v| < 2^10 before an accumulator overflows, and the epilogue checks
+// the accumulators themselves (oabs) for whatever |v| the caller brings; a first cut at 2^100 moved the cliff of tools/attn_robust.py in by 18 log2 units of row
+// maximum for nothing (gain 4: 11 % -> 46 % of the strips redone).
+#define W1_L_MAX 3.3230699e35f                // 2^118
 // With the shift at the row BOUND the largest weight of a row is exp2(s_max - M), not 1, so it carries a bf16 rounding error in the
 // numerator (2^-9 relative) that the fp32 denominator does not share; over a few dozen keys these errors average out, over one or
 // two they do not (S = 1: O off by up to 0.4 %).  Rows that short are not a performance case: below this length every strip goes to
