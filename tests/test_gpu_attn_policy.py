@@ -67,7 +67,7 @@ def test_forward_time_against_the_data_at_the_headline_shape(ops):
         10 x sink keys at gain 1, (next to) NO strip is redone (<= 0.2 %; measured 0 - 1 of 6 720) and the launch takes <= 1.25 x its time on bench.py's N(0,1) operands (measured 0.97-1.11 x over four boxes; the cliff this guards
         against is 2.5 x, and three launches per arm at the power cap scatter by several per cent);
       * beyond that (gain 4: 0.3 bits; gain 2 with 10 x sinks) strips get flagged -- the documented cliff: what the policy runs is the cheaper of the two forms
-        (within 20 %) and stays under 2.7 x (round 5's kernel was there from gain 2.5 on: profiles/r06a_attn_trained_like.txt)."""
+        (within 20 %) and stays under 3 x (measured 1.4-1.9 x at gain 4, 2.42-2.50 x on the all-online entry) (round 5's kernel was there from gain 2.5 on: profiles/r06a_attn_trained_like.txt)."""
     from attn_data import trained_like_qkv
     B, H, S = 2, 48, 17776
 
@@ -102,7 +102,7 @@ def test_forward_time_against_the_data_at_the_headline_shape(ops):
         else:
             other = ms(q, k, v, "online" if pol.mode == "bound" else "bound")
             rec["other_form_ms"] = other
-            if not (t <= 1.20 * other and t <= 2.7 * base):
+            if not (t <= 1.20 * other and t <= 3.0 * base):
                 fails.append((name, rec))
         report[name] = rec
         del q, k, v
