@@ -611,7 +611,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
                         w = args.qk_gain * (1 + 0.2 * torch.randn(model.dim, generator=gq, device=dev))
                         w.view(model.num_heads, -1)[:, :3] *= 3.0
                         nrm.weight.copy_(w.to(nrm.weight.dtype))
-    model.enable_fp8(not args.no_fp8, attention=not (args.no_fp8 or args.no_fp8_attn))
+    model.enable_fp8(not args.no_fp8, attention="auto" if (args.fp8_attn_auto and not args.no_fp8) else not (args.no_fp8 or args.no_fp8_attn))
     trainer = WanDPOTrainer({"lora_rank": args.rank_r, "lora_alpha": 2.0 * args.rank_r, "accumulate_grad_batches": 1, "seed": 1234,
                              "enable_gradient_checkpointing": ckpt, "gradient_checkpointing_stride": stride, "tuned_gemms": not args.no_tuned_gemms}, model)
     gB = torch.Generator(device=dev).manual_seed(1)
@@ -661,7 +661,7 @@ def main_wan(args, C, world, rank, dev, force_dist):
         drep["preflight"] = args.preflight
     if rank == 0:
         named = (layers, F_, H_, W_, args.rank_r, ckpt, args.no_fp8, args.no_fp8_attn) == (30, C["frames"], C["height"], C["width"], 64, False, False, False) \
-            and args.weights == "bench"
+            and args.weights == "bench" and not args.fp8_attn_auto
         ms = dt / args.steps * 1e3
         out = {
             "metric": "DPO preference-pair steps/sec, Wan2.2-TI2V-5B 81f@704x1280", "value": world * args.steps / dt, "unit": "pair-steps/s",
@@ -686,6 +686,11 @@ def main_wan(args, C, world, rank, dev, force_dist):
             "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "tuned_gemms": tuned_gemms_report(ops),
         }
+        frep = model.fp8_attention_report()
+        est = [r["estimated_score_error_log2"] for r in frep if r["estimated_score_error_log2"] is not None]
+        out["fp8_attention"] = {"weights": args.weights + (f" (QK-norm gain {args.qk_gain})" if args.weights == "trained_like" else ""),
+                                "mode": "auto" if args.fp8_attn_auto and not args.no_fp8 else "pinned", "layers_on_e4m3": sum(r["fp8_attn"] for r in frep), "layers": len(frep),
+                                "estimated_score_error_log2_max": max(est) if est else None}
         out.update(drep)
         add_kernel_report(out, ops, args.steps, ms, use_pmc=named)
         if not ckpt:
@@ -717,6 +722,8 @@ def main():
     ap.add_argument("--lean", action="store_true", default=None, help="lean activations: the LN output and the normalised q / k are made again in the backward (23 %% fewer saved bytes per block)")
     ap.add_argument("--no-fp8", action="store_true", help="cfg5 only: bf16 feed-forward GEMMs and bf16 attention instead of the e4m3 paths")
     ap.add_argument("--no-fp8-attn", action="store_true", help="cfg5 only: keep the e4m3 feed-forward but run the self-attention forward in bf16")
+    ap.add_argument("--fp8-attn-auto", action="store_true", help="cfg5 only: enable_fp8(attention='auto') -- every self-attention layer decides from its first call's score range "
+                    "whether e4m3 scores are accurate enough (ops.F8AttnPolicy); NOT the BASELINE line (which pins the e4m3 kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="run the vendor GEMMs on hipBLASLt's default heuristic instead of the solutions of videogpa_amd/tuned/ (the A/B of tools/gemm_tune.py)")

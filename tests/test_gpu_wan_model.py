@@ -238,6 +238,54 @@ def test_wan_model_e4m3_self_attention_stays_close_to_the_oracle():
     print("e4m3 self-attention, worst LoRA gradient cosine vs fp64 oracle:", worst["grad_cos"])
 
 
+def test_wan_enable_fp8_attention_auto_keeps_layers_with_a_wide_score_range_on_bf16():
+    """enable_fp8(attention="auto") (ops.F8AttnPolicy): every self-attention layer decides at its first call whether e4m3 scores are accurate enough on its data.
+    With the model's own QK-norm gains (1) every layer stays on the e4m3 forward; with the gains of block 0 raised to 4 (a row bound of ~260 log2 units: an e4m3
+    score would be off by ~1 log2 unit rms) THAT layer runs the bf16 forward, in the reference pass and in the policy pass alike, and the others keep e4m3."""
+    from videogpa_amd import ops
+    pm, state, lora = _build()
+    base = pm.get_base_model()
+    base.enable_fp8(False, attention="auto")
+    assert all(b.self_attn.fp8_attn and b.self_attn.f8_policy is not None for b in base.blocks)
+    with pytest.raises(ValueError):
+        base.enable_fp8(False, attention="maybe")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    C, Fr, H, W = CFG["in_dim"], 3, 32, 48
+    x = [torch.randn(C, Fr, H, W, device="cuda", generator=g).bfloat16().float() for _ in range(2)]
+    L = Fr * (H // 2) * (W // 2)
+    t = torch.tensor([417.0, 902.0], device="cuda")[:, None].expand(2, L).clone()
+    ctx = [torch.randn(n, CFG["text_dim"], device="cuda", generator=g).bfloat16() for n in (20, 32)]
+
+    def run():
+        seen = []
+        orig = ops.attention128_fwd_raw
+
+        def spy(q, k, v, scale, o_pad=0, f8=False, **kw):
+            if k.shape[2] == L:
+                seen.append(bool(f8))
+            return orig(q, k, v, scale, o_pad, f8=f8, **kw)
+        ops.attention128_fwd_raw = spy
+        try:
+            with torch.no_grad():
+                out = pm(x, t=t, context=ctx, seq_len=L)
+        finally:
+            ops.attention128_fwd_raw = orig
+        assert all(torch.isfinite(o).all() for o in out)
+        return seen
+    assert run() == [True] * len(base.blocks)
+    rep = base.fp8_attention_report()
+    assert all(r["fp8_attn"] and 0.0 < r["estimated_score_error_log2"] < 0.5 for r in rep), rep
+    with torch.no_grad():
+        for nrm in (base.blocks[0].self_attn.norm_q, base.blocks[0].self_attn.norm_k):
+            nrm.weight.mul_(4.0)
+    base.enable_fp8(False, attention="auto")                   # fresh policies: the decision is taken once per layer
+    first = run()
+    assert first == [False] + [True] * (len(base.blocks) - 1), first
+    assert run() == first                                      # sticky: the policy pass runs what the reference pass ran
+    rep = base.fp8_attention_report()
+    assert not rep[0]["fp8_attn"] and rep[0]["estimated_score_error_log2"] > 0.5 and all(r["fp8_attn"] for r in rep[1:]), rep
+
+
 def test_wan_adapter_mount_scale_merge_as_the_generate_script_does(tmp_path):
     """generate/Wan2.2-TI2V-5B.py:53-71: PeftModel.from_pretrained on the engine's model, scaling *= lora_weight, merge_and_unload.  The merged
     plain model must reproduce the LoRA-active model at that weight (bf16 weight rounding of the merged delta: 3 % of range, cos >= 0.999)."""

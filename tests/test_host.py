@@ -318,6 +318,32 @@ def test_attention_forward_policy_switches_on_the_kernels_own_redo_count():
     assert q.mode == "bound" and not q.wants_flags()
 
 
+def test_f8_attention_policy_decides_once_from_the_score_range():
+    """ops.F8AttnPolicy (WanModel.enable_fp8(attention="auto")): the estimate is ERR_PER_BOUND x max|q| max|k| scale log2(e) per (batch, head); unit-gain RMS-normed
+    operands stay on the e4m3 forward, gains of 3.5 (a row bound of 200 log2 units) go to bf16; the decision is taken at the first call and kept (reference and policy pass of a step run the same
+    forward), fixed=True never looks at the data."""
+    from videogpa_amd import ops
+    g = torch.Generator().manual_seed(0)
+    B, L, H, d = 1, 96, 2, 128
+
+    def rmsn(gain):
+        t = torch.randn(B, L, H, d, generator=g)
+        return (gain * t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True))).reshape(B, L, H * d).bfloat16()
+    q1, k1, q3, k3 = rmsn(1.0), rmsn(1.0), rmsn(3.5), rmsn(3.5)
+    scale = d ** -0.5
+    e1 = ops.F8AttnPolicy.score_error_estimate(q1, k1, H, scale)
+    want = 0.004 * (128 ** 0.5) ** 2 * scale * 1.4426950408889634            # |q| = |k| = sqrt(128) after the RMS norm
+    assert abs(e1 - want) < 0.02 * want, (e1, want)
+    p = ops.F8AttnPolicy()
+    assert p.use_f8(q1, k1, H, scale) and p.mode == "f8" and p.decided
+    assert p.use_f8(q3, k3, H, scale) and p.mode == "f8"                     # decided: later data does not move it (loss = ln 2 at B = 0 needs both passes alike)
+    p.reset()
+    assert not p.use_f8(q3, k3, H, scale) and p.mode == "bf16" and p.estimated_score_error > 0.5
+    assert not p.use_f8(q1, k1, H, scale)                                    # ... and it stays on bf16 for good
+    f = ops.F8AttnPolicy(fixed=True)
+    assert f.use_f8(q3, k3, H, scale) and f.estimated_score_error is None
+
+
 def test_tuned_gemm_file_is_wired_but_off_without_a_gpu(monkeypatch):
     """ops.use_tuned_gemms: the shipped TunableOp results file names only hipBLASLt solutions of shapes the step issues; without a GPU nothing is switched on, and a
     caller that runs TunableOp its own way is left alone."""

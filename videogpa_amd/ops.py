@@ -1098,6 +1098,42 @@ def attention128_uses_f8(f8, Skv):
     return bool(f8) and Skv >= ATTN128_F8_MIN_KEYS
 
 
+class F8AttnPolicy:
+    """Whether one head_dim-128 self-attention layer runs its forward on e4m3 operands (vgpa_attn128_fwd_f8) or in bf16, decided ONCE from the data of its first call.
+    The e4m3 forward's time no longer depends on the data (sampled shift), its ACCURACY does: q and k each carry a 2^-4 relative rounding per element, so a score
+    q.k (log2 units) is off by ~ ERR_PER_BOUND x |q| |k| scale log2(e) rms -- measured 0.08 log2 units at a row bound of 29 (unit QK-norm gains: the ~5 % per weight of
+    the kernel's tests) and 0.73 at a bound of 180 (gains of 2.5: every weight off by a factor 1.7 rms; tools/f8_sharp_diag.py).  `threshold` (log2 units of rms score
+    error, default 0.5) is where the layer goes to the bf16 forward for good (6.3 ms per launch at the cfg5 shape against 4.1).  fixed=True pins the mode
+    (WanModel.enable_fp8(attention=True): the e4m3 kernel whatever the data).  The decision is taken at the layer's FIRST call only -- the frozen-reference pass of a
+    DPO step -- so that reference and policy pass always run the same forward (loss = ln 2 exactly at B = 0); reset() re-arms it."""
+    ERR_PER_BOUND = 0.004
+
+    def __init__(self, mode="f8", fixed=False, threshold=0.5):
+        self.mode, self.fixed, self.threshold = mode, fixed, float(threshold)
+        self.decided = False
+        self.estimated_score_error = None
+
+    def reset(self):
+        self.decided = False
+
+    @staticmethod
+    def score_error_estimate(q, k, H, scale):
+        """q [B, Lq, H*d], k [B, Lk, H*d] (token-major, as the model holds them) -> estimated rms error of an e4m3 score in log2 units, worst (batch, head)"""
+        B, Lq, D = q.shape
+        d = D // H
+        qn = q.view(B, Lq, H, d).float().pow(2).sum(-1).amax(dim=1).sqrt()          # [B, H]: the longest query row per head
+        kn = k.view(B, k.shape[1], H, d).float().pow(2).sum(-1).amax(dim=1).sqrt()
+        return float((qn * kn).amax()) * float(scale) * LOG2E * F8AttnPolicy.ERR_PER_BOUND
+
+    def use_f8(self, q, k, H, scale):
+        if not self.fixed and not self.decided and self.mode == "f8":
+            self.estimated_score_error = self.score_error_estimate(q, k, H, scale)      # one host sync, once per layer
+            if self.estimated_score_error > self.threshold:
+                self.mode = "bf16"
+        self.decided = True
+        return self.mode == "f8"
+
+
 def attention128_f8_redo_fraction(ws, B, H, Sq):
     """fraction of the (batch, head, 256-row strip) tasks the last vgpa_attn128_fwd_f8 call on workspace `ws` flagged and redid in bf16 (synchronises)"""
     tasks = B * H * ((Sq + 255) // 256)

@@ -256,7 +256,7 @@ class _SelfAttnFn(torch.autograd.Function):
     the output projection's forward resp. the q/k/v projection's backward operand (ops.LoraExt)."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, wk, cos, sin, H, eps, o_pad, grad_pad, f8=False, precise_delta=None):
+    def forward(ctx, qkv, wq, wk, cos, sin, H, eps, o_pad, grad_pad, f8=False, precise_delta=None, f8_policy=None):
         B, L, W = qkv.shape
         D = W // 3
         hd = D // H
@@ -274,6 +274,8 @@ class _SelfAttnFn(torch.autograd.Function):
         # e4m3 forward with a backward to come: the backward runs on the operands the forward's products really used (dequantised to bf16 by the forward's
         # own quantisation pass), so that its recomputed softmax weights ARE the forward's and delta = rowsum(dO o O) matches them -- the straight-through
         # gradient of this forward.  They replace the normalised q / k among the saved tensors; the dequantised v is the one tensor this adds.
+        if f8 and f8_policy is not None:      # enable_fp8(attention="auto"): the layer's first call decides from the score range whether e4m3 scores are accurate enough
+            f8 = f8_policy.use_f8(qn, kn, H, hd ** -0.5)
         deq = None
         if ops.attention128_uses_f8(f8, L) and ctx.needs_input_grad[0]:
             deq = tuple(torch.empty(B, L, D, dtype=torch.bfloat16, device=qkv.device) for _ in range(3))
@@ -302,7 +304,7 @@ class _SelfAttnFn(torch.autograd.Function):
         d2 = dqkv.view(B * L, W)
         _rms_rope_bwd_raw(dqn, D, q2[:, :D], q2.stride(0), rq, wq, cos, sin, L, hd, d2[:, :D], d2.stride(0))
         _rms_rope_bwd_raw(dkn, D, q2[:, D:2 * D], q2.stride(0), rk, wk, cos, sin, L, hd, d2[:, D:2 * D], d2.stride(0))
-        return dqkv, None, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _FfnFp8Fn(torch.autograd.Function):
@@ -446,6 +448,7 @@ class WanSelfAttention(nn.Module):
         self._fused = None
         self._qkv_ext = None
         self.fp8_attn = False
+        self.f8_policy = None                 # ops.F8AttnPolicy with enable_fp8(attention="auto")
         self.precise_delta = "int8" if ops.precise_delta_default() else None     # ops.py "Precise delta"; WanModel.set_precise_delta changes it per model
 
     def _heads(self, t, B, S):
@@ -497,7 +500,7 @@ class WanSelfAttention(nn.Module):
         else:
             qkv = ops.frozen_linear(x, W, b)
         o = _SelfAttnFn.apply(qkv.view(B, L, 3 * self.dim), self.norm_q.weight, self.norm_k.weight, rope[0] if rope else None, rope[1] if rope else None,
-                              self.num_heads, self.norm_q.eps, out_pad, in_pad, bool(self.fp8_attn), self.precise_delta)
+                              self.num_heads, self.norm_q.eps, out_pad, in_pad, bool(self.fp8_attn), self.precise_delta, self.f8_policy)
         return self.o(o.reshape(B * L, self.dim))
 
 
@@ -722,10 +725,21 @@ class WanModel(nn.Module):
         v_mfma_scale_f32_32x32x64_f8f6f4, power-of-two scales on the instruction's E8M0 operands); its backward runs the bf16 kernels on the forward's own operands, dequantised
         (_SelfAttnFn: the straight-through gradient of the e4m3 forward -- softmax rows that sum to one, delta consistent with them); the 512-key
         cross-attention stays bf16.
+        attention="auto": each self-attention layer decides at its first call whether e4m3 SCORES are accurate enough on its data (ops.F8AttnPolicy: the score error
+        grows with |q| |k|; a layer whose estimated rms score error exceeds `F8AttnPolicy.threshold` = 0.5 log2 units keeps the bf16 forward) -- for checkpoints
+        whose QK-norm gains are not known to be small; True pins the e4m3 kernel (what bench.py measures).
         The LoRA-carrying q/k/v/o projections stay in bf16."""
+        if attention not in (None, True, False, "auto"):
+            raise ValueError(f'enable_fp8: attention is True, False, None (= enabled) or "auto", got {attention!r}')
         for blk in self.blocks:
             blk.fp8_ffn = enabled
             blk.self_attn.fp8_attn = bool(enabled if attention is None else attention)
+            blk.self_attn.f8_policy = ops.F8AttnPolicy() if attention == "auto" else None
+
+    def fp8_attention_report(self):
+        """per block: whether the self-attention forward runs e4m3 and, under attention="auto", the estimated score error the decision was taken on"""
+        return [{"block": i, "fp8_attn": bool(b.self_attn.fp8_attn) and (b.self_attn.f8_policy is None or b.self_attn.f8_policy.mode == "f8"),
+                 "estimated_score_error_log2": None if b.self_attn.f8_policy is None else b.self_attn.f8_policy.estimated_score_error} for i, b in enumerate(self.blocks)]
 
     def set_precise_delta(self, mode="int8"):
         """what both attentions of every block of THIS model keep of their output beyond its bf16 rounding for the backward's delta: "int8" (default, one
