@@ -30,6 +30,21 @@ def base_state_dict(cfg):
     return {k: v.to(torch.bfloat16) for k, v in sd.items()}
 
 
+def trained_like_state_dict(cfg, qk_gain=2.5):
+    """base_state_dict with the QK-norm affines of a TRAINED model's shape (round 6; bench.py --weights trained_like): gains of qk_gain +- 20 %, three 3 x outlier
+    channels, biases of 0.1 qk_gain -- sharp attention rows with scores spread over +-100 log2 units instead of the nearly flat rows unit gains give."""
+    sd = base_state_dict(cfg)
+    g = torch.Generator().manual_seed(7)
+    for k in sorted(sd):
+        if k.endswith(("attn1.norm_q.weight", "attn1.norm_k.weight")):
+            w = qk_gain * (1 + 0.2 * torch.randn(sd[k].shape[0], generator=g))
+            w[:3] *= 3.0
+            sd[k] = w.to(torch.bfloat16)
+        elif k.endswith(("attn1.norm_q.bias", "attn1.norm_k.bias")):
+            sd[k] = (0.1 * qk_gain * torch.randn(sd[k].shape[0], generator=g)).to(torch.bfloat16)
+    return sd
+
+
 def lora_state_dict(cfg, variant):
     r, b_std = VARIANTS[variant]
     lora = ocv.init_lora(cfg, r=r, seed=1, b_std=b_std)
