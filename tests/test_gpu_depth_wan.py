@@ -238,6 +238,7 @@ def _run(mode):
     assert not fails, fails[:12]
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+# default: the BASELINE configs[4] arithmetic (fp8); the bf16 arm (79 s more of a whole GPU; profiles/r06_cfg5_depth_parity_bf16.json) with VGPA_GPU_FULL=1
+@pytest.mark.parametrize("mode", ["bf16", "fp8"] if os.environ.get("VGPA_GPU_FULL", "0") == "1" else ["fp8"])
 def test_cfg5_full_depth_pair_step_matches_the_oracle_block_by_block(mode):
     _run(mode)

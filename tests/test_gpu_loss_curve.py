@@ -36,7 +36,10 @@ OPT_STEPS, ACCUM, N_PAIRS = 20, 2, 4
 CONF = {"beta": 1.0, "learning_rate": 6e-5, "weight_decay": 0.01, "warmup_steps": 2, "max_steps": OPT_STEPS, "accumulate_grad_batches": ACCUM, "gradient_clip_val": 1.0}
 TIMESTEPS = (417, 83, 901, 640)
 LOSS_TOL, MOVE_MIN, DRIFT_MAX = 1e-3, 1e-2, 0.35
-MODES = {"int8": ("int8", False), "int8_lean": ("int8", True), "plain": (None, False)}
+# VGPA_GPU_FULL=1: also the lean-activation arm (bit-identical to the default: asserted) and the textbook-delta arm (what the precise delta buys: profiles/r06_loss_curve_width.json
+# holds all three); the default suite runs the product's default mode only -- the four longest tests of the suite took 6 of its 10 minutes
+FULL = os.environ.get("VGPA_GPU_FULL", "0") == "1"
+MODES = {"int8": ("int8", False), "int8_lean": ("int8", True), "plain": (None, False)} if FULL else {"int8": ("int8", False)}
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -156,9 +159,10 @@ def test_loss_curve_at_model_width_tracks_the_fp32_oracle_loop():
             fails.append((mode, "adapter drift", drift / travelled))
     if first - last < MOVE_MIN:
         fails.append(("the curve does not move", first, last))
-    report["int8_lean_bit_identical_to_int8"] = curves["int8"] == curves["int8_lean"]
-    if not report["int8_lean_bit_identical_to_int8"]:
-        fails.append(("lean activations changed the losses", [i for i, (a, b) in enumerate(zip(curves["int8"], curves["int8_lean"])) if a != b][:5]))
+    if "int8_lean" in curves:
+        report["int8_lean_bit_identical_to_int8"] = curves["int8"] == curves["int8_lean"]
+        if not report["int8_lean_bit_identical_to_int8"]:
+            fails.append(("lean activations changed the losses", [i for i, (a, b) in enumerate(zip(curves["int8"], curves["int8_lean"])) if a != b][:5]))
     report["failures"] = [repr(f) for f in fails]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "loss_curve_width.json"), "w") as f:
