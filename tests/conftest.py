@@ -17,3 +17,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+_LONG = ("test_gpu_depth.py", "test_gpu_depth_wan.py", "test_gpu_loss_curve.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    """the three minute-long full-depth / full-width oracle comparisons run LAST: whatever limit a harness puts on the GPU suite, the 220 short tests report first"""
+    items.sort(key=lambda it: any(str(it.fspath).endswith(n) for n in _LONG))
+
+
+def pytest_runtest_setup(item):
+    """... and start from an empty caching allocator (they take 150-210 GB of the 288): whatever the tests before them left cached is returned first"""
+    if any(str(item.fspath).endswith(n) for n in _LONG):
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            gc.collect()
+            torch.cuda.empty_cache()
+
